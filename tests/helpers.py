@@ -1,0 +1,71 @@
+"""Shared parity-check helpers (golden fixtures, tolerances)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import recipe as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+LAYER_CASES = ['layer_b1_8x8_d1', 'layer_b2_8x8_d2', 'layer_b1_14x21_d2', 'layer_b1_13x30_d1', 'layer_b1_60x60_d2']
+GTC_CASES = ['gtc_b2_8x8_k8', 'gtc_b1_13x30_k100']
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| -- the 'relative fp32 tolerance' of BASELINE.json's north_star."""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def layer_case_inputs(g, dtype=torch.float32):
+    b, h, w, depth = [int(v) for v in g['meta']]
+    st = R.layer_state(depth, seed=0, dtype=dtype)
+    x = R.synth_input('x', (b, 4, 256, h, w), seed=1, dtype=dtype)
+    gy = R.synth_input('g', (b, 256, h, w), seed=2, scale=1.0, dtype=dtype)
+    return b, h, w, depth, st, x, gy
+
+
+def check_layer_forward(g, y_target, tol):
+    """y_target [B,256,H,W]: the target frame of the layer output."""
+    s = int(g['y_stride'])
+    e = rel_err(y_target[:, :, ::s, ::s].cpu(), g['y'])
+    assert e < tol, 'forward rel err %.3e >= %.1e' % (e, tol)
+    yd = y_target.double().cpu()
+    stats = np.array([yd.sum().item(), yd.abs().sum().item(), (yd ** 2).sum().item()])
+    # full-tensor statistics catch errors outside the strided sample
+    assert abs(stats[1] - g['y_stats'][1]) / g['y_stats'][1] < 10 * tol
+    assert abs(stats[2] - g['y_stats'][2]) / g['y_stats'][2] < 10 * tol
+    return e
+
+
+def check_layer_backward(g, dx, param_grads, tol):
+    s = int(g['y_stride'])
+    e = rel_err(dx[:, :, :, ::s, ::s].cpu(), g['dx'])
+    assert e < tol, 'dx rel err %.3e >= %.1e' % (e, tol)
+    worst = ('', 0.0)
+    for key, ref in g.items():
+        if not key.startswith('p/'):
+            continue
+        _, kind, name = key.split('/', 2)
+        got = param_grads[name].detach().double().cpu()
+        if kind == 'gnorm':
+            err = abs(got.norm().item() - float(ref)) / max(float(ref), 1e-30)
+        elif kind == 'g':
+            err = rel_err(got, ref)
+        elif kind == 'gsum0':
+            err = rel_err(got.sum(0), ref)
+        elif kind == 'gsum1':
+            err = rel_err(got.sum(1), ref)
+        elif kind == 'gsumlast':
+            err = rel_err(got.sum(-1), ref)
+        else:
+            raise KeyError(key)
+        if err > worst[1]:
+            worst = (key, err)
+        assert err < tol, '%s rel err %.3e >= %.1e' % (key, err, tol)
+    return e, worst
