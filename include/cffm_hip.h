@@ -1,0 +1,145 @@
+/* cffm_hip.h -- C ABI of libcffm_hip.so: the MI355X-native (gfx950) CFFM hot path.
+ *
+ * The reference (GuoleiSun/VSS-CFFM) is pure Python; it has no FFI for this path.  The entry points
+ * below are what a binding of the reference's hot-path *modules* needs, one per module / stage, with
+ * plain device pointers and sizes (no torch types):
+ *
+ *   cffm_layer_forward / _backward   <->  BasicLayer3d3.forward            cffm_transformer.py:917-927
+ *   cffm_block_forward / _backward   <->  CffmTransformerBlock3d3.forward  cffm_transformer.py:709-832
+ *   cffm_ln_pool_fwd / _bwd          <->  CFFA: norm1 + pad + pool_layers / pool_layers_clips
+ *                                                                           cffm_transformer.py:716-805
+ *   cffm_bias_assemble / _scatter    <->  relative-position bias gathers    cffm_transformer.py:536-587
+ *   cffm_attn_fwd / _bwd             <->  WindowAttention3d3.forward (CFM)  cffm_transformer.py:364-606
+ *   cffm_linear_*                    <->  nn.Linear (qkv :374, proj :602, Mlp :10-26)
+ *   cffm_residual_ln, cffm_bias_gelu, cffm_residual_out  <->  residual/norm2/Mlp glue  :823-824
+ *   cffm_gtc_*                       <->  BasicLayer_cluster / WindowAttention_cluster (CFFM++)
+ *                                                         pvt/swin_transformer_2d.py:1103-1148, :208-262
+ *
+ * Conventions: every pointer is a DEVICE pointer (fp32 unless stated) borrowed for the duration of
+ * the call; `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously on it;
+ * functions return 0 on success, otherwise a negative code and cffm_last_error() describes it
+ * (mirrors the reference's Python asserts: wrong T / shape is an error, not UB).  Single-threaded per
+ * process (one process per GPU).  C = 256, 8 heads, window 7 are fixed as in cffm_head.py:74-95.
+ */
+#ifndef CFFM_HIP_H
+#define CFFM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFFM_ABI_VERSION 1
+
+typedef struct cffm_geom {
+    int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
+    int Hp, Wp, gy, gx; /* padded to multiples of 7; windows per side                        */
+    int nW, HW, RC;     /* windows per clip; H0*W0; token rows per clip = 64*nW (49 + 15)    */
+} cffm_geom;
+
+/* parameters of one CffmTransformerBlock3d3 (state_dict names in SURVEY.md Appendix C) */
+typedef struct cffm_block_params {
+    const float *norm1_w, *norm1_b;
+    const float *pool_w[4], *pool_b[4]; /* pool_layers.0, pool_layers_clips.{0,1,2}: [49],[49],[9],[4] / [1] */
+    const float *rpb_own;               /* attn.relative_position_bias_table [169,8]                         */
+    const float *rpb_ring;              /* attn.relative_position_bias_table_to_neighbors [1,8,49,132]      */
+    const float *rpb_pool[4];           /* ..._to_windows.0 [8,121], ..._to_windows_clips.{0,1,2} [8,169|121|81] */
+    const float *qkv_w, *qkv_b;         /* [768,256], [768] */
+    const float *proj_w, *proj_b;       /* [256,256], [256] */
+    const float *norm2_w, *norm2_b;
+    const float *fc1_w, *fc1_b;         /* [1024,256], [1024] */
+    const float *fc2_w, *fc2_b;         /* [256,1024], [256]  */
+} cffm_block_params;
+
+/* same fields, writable: gradients (every field is fully written by cffm_block_backward) */
+typedef struct cffm_block_grads {
+    float *norm1_w, *norm1_b;
+    float *pool_w[4], *pool_b[4];
+    float *rpb_own, *rpb_ring, *rpb_pool[4];
+    float *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} cffm_block_grads;
+
+/* float offsets of the activations one block saves for its backward (inside its slice of `saved`) */
+typedef struct cffm_block_ws {
+    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, total;
+} cffm_block_ws;
+
+int cffm_abi_version(void);
+const char* cffm_last_error(void);
+int cffm_geom_init(cffm_geom* g, int B, int H0, int W0);
+int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* out);
+long cffm_layer_saved_floats(const cffm_geom* g, int depth);  /* NHWC stack + depth * block_ws.total */
+long cffm_layer_scratch_floats(const cffm_geom* g);
+
+/* ---- stage level (each is one kernel; used by the parity tests and by the block functions) ---- */
+/* dst[n][c][r] = src[n][r][c] for n < batch (element strides src_bs / dst_bs between batches) */
+int cffm_transpose(const float* src, float* dst, int batch, int rows, int cols, long src_bs, long dst_bs, void* stream);
+int cffm_pool_matrix(const float* const pool_w[4], float* M /*[15*49]*/, void* stream);
+int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream);
+int cffm_ln_pool_fwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
+                     const float* gamma, const float* beta, const float* M, const float* const pool_b[4],
+                     float* zall, float* mean, float* rstd, void* stream);
+int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
+                     const float* gamma, const float* beta, const float* M, const float* mean, const float* rstd,
+                     const float* dzall, const float* dres /* [B*HW,256] added to the target-frame grad, may be NULL */,
+                     float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs,
+                     float* dgamma, float* dbeta, float* dM, float* const dpool_b[4], void* stream);
+int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias /*[8,64,304]*/,
+                       float* biasT /*[8,304,64] or NULL*/, void* stream);
+int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* const dpool[4], void* stream);
+int cffm_attn_fwd(const cffm_geom* g, const float* qkv /*[B*RC,768] raw (no bias)*/, const float* qkv_b,
+                  const int* key_src /*[nW,304]*/, const int* q_dst /*[nW,49]*/, const float* bias,
+                  float* ao /*[B*HW,256]*/, float* lse /*[B*nW*8,64]*/, void* stream);
+int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
+                  const float* bias, const float* biasT, const float* ao, const float* dao, const float* lse,
+                  float* dqkv /*[B*RC,768], overwritten*/, float* dbiasT /*[8,304,64], overwritten*/, void* stream);
+/* y[M,N] = x[M,K] w[N,K]^T ;  dx[M,K] = dy[M,N] w[N,K] ;  dw[N,K] = dy[M,N]^T x[M,K]   (row-major, no bias) */
+int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream);
+int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream);
+int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream);
+int cffm_colsum(const float* a, long rows, int cols, float* out /* overwritten */, void* stream);
+int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
+                     const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,
+                     long nrows, void* stream);
+/* dx1 = (dres or 0) + LNbwd(dz2); dgamma/dbeta are accumulated (zeroed first when zero_grads != 0) */
+int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, const float* gamma, const float* dz2,
+                         const float* dres /* may be NULL */, float* dx1, float* dgamma, float* dbeta, long nrows,
+                         int zero_grads, void* stream);
+int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, int cols, void* stream);
+int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact_inout, long rows, int cols, void* stream);
+int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float* out, long rows, void* stream);
+
+/* ---- CFFM++ global temporal context (WindowAttention_cluster, pvt/swin_transformer_2d.py:208-262) ---- */
+int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
+                       long nrows, void* stream);
+/* q_raw [B*T,256] = LN(x) Wq^T without bias, kv_raw [B*K,512] = LN(centers) Wkv^T without bias; softmax over the K
+ * prototypes per (token, head); o [B*T,256]; lse [B*T,8] */
+int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, float* o, float* lse,
+                      int B, int T, int K, void* stream);
+int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, const float* o,
+                      const float* dout, const float* lse, float* dq_raw, float* dkv /* overwritten */, int B, int T, int K,
+                      void* stream);
+
+/* ---- block / layer level ---- */
+/* x_ref: NHWC frames 0..2 [B,3,HW,256] (batch stride ref_bs), x_tgt NHWC target [B,HW,256] (stride tgt_bs);
+ * writes the block's saved activations into `ws` (layout: cffm_block_ws_layout; ws[x2] is the output). */
+int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const float* x_ref, long ref_bs,
+                       const float* x_tgt, long tgt_bs, const int* key_src, const int* q_dst, float* ws,
+                       float* scratch, void* stream);
+int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
+                        const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
+                        const int* q_dst, const float* ws, const float* dout /*[B*HW,256]*/,
+                        float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs,
+                        float* scratch, void* stream);
+/* x [B,4,256,H0,W0] -> y_tgt [B,256,H0,W0] (frames 0..2 of the reference's output equal the input) */
+int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* params, const float* x_nchw,
+                       float* y_tgt_nchw, const int* key_src, const int* q_dst, float* saved, float* scratch,
+                       void* stream);
+/* dy_tgt [B,256,H0,W0] -> dx [B,4,256,H0,W0] (gradient through the hot path only; the pass-through of
+ * frames 0..2 is the caller's torch.cat) and every parameter gradient of every block */
+int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
+                        const float* dy_tgt_nchw, float* dx_nchw, const int* key_src, const int* q_dst,
+                        const float* saved, float* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes binding of libcffm_hip.so (C ABI: include/cffm_hip.h).
+
+The product path loads ONLY ``libcffm_hip.so`` (built by ``__graft_entry__.build()`` with hipcc for
+gfx950) and raises if it is missing -- there is no CPU fallback.  ``bind(path)`` is the generic
+signature binder; the test-suite uses it to load the emulator build of the same sources
+(tests/emu.py) and ``_override`` is the single seam through which it does so.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
+ABI_VERSION = 1
+
+vp, ci, cl = C.c_void_p, C.c_int, C.c_long
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, ci) for n in ('B', 'H0', 'W0', 'Hp', 'Wp', 'gy', 'gx', 'nW', 'HW', 'RC')]
+
+
+class BlockPtrs(C.Structure):
+    """cffm_block_params / cffm_block_grads (same field order)."""
+    _fields_ = [('norm1_w', vp), ('norm1_b', vp), ('pool_w', vp * 4), ('pool_b', vp * 4), ('rpb_own', vp),
+                ('rpb_ring', vp), ('rpb_pool', vp * 4), ('qkv_w', vp), ('qkv_b', vp), ('proj_w', vp), ('proj_b', vp),
+                ('norm2_w', vp), ('norm2_b', vp), ('fc1_w', vp), ('fc1_b', vp), ('fc2_w', vp), ('fc2_b', vp)]
+
+
+class BlockWs(C.Structure):
+    _fields_ = [(n, cl) for n in ('mean1', 'rstd1', 'M', 'zall', 'qkv', 'bias', 'biasT', 'lse', 'ao', 'x1', 'mean2',
+                                  'rstd2', 'z2', 'hraw', 'act', 'x2', 'total')]
+
+
+GP, BP = C.POINTER(Geom), C.POINTER(BlockPtrs)
+P4 = vp * 4
+
+SIGNATURES = {
+    'cffm_abi_version': (ci, []),
+    'cffm_last_error': (C.c_char_p, []),
+    'cffm_geom_init': (ci, [GP, ci, ci, ci]),
+    'cffm_block_ws_layout': (ci, [GP, C.POINTER(BlockWs)]),
+    'cffm_layer_saved_floats': (cl, [GP, ci]),
+    'cffm_layer_scratch_floats': (cl, [GP]),
+    'cffm_transpose': (ci, [vp, vp, ci, ci, ci, cl, cl, vp]),
+    'cffm_pool_matrix': (ci, [P4, vp, vp]),
+    'cffm_pool_matrix_bwd': (ci, [vp, P4, vp]),
+    'cffm_ln_pool_fwd': (ci, [GP, vp, cl, vp, cl, vp, vp, vp, P4, vp, vp, vp, vp]),
+    'cffm_ln_pool_bwd': (ci, [GP, vp, cl, vp, cl, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp, cl, vp, vp, vp, P4, vp]),
+    'cffm_bias_assemble': (ci, [vp, vp, P4, vp, vp, vp]),
+    'cffm_bias_scatter': (ci, [vp, vp, vp, P4, vp]),
+    'cffm_attn_fwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'cffm_attn_bwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'cffm_linear_fwd': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_bwd_input': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_bwd_weight': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_colsum': (ci, [vp, cl, ci, vp, vp]),
+    'cffm_residual_ln': (ci, [vp, cl, ci, vp, vp, vp, vp, vp, vp, vp, vp, cl, vp]),
+    'cffm_ln_bwd_residual': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp]),
+    'cffm_layernorm_fwd': (ci, [vp, vp, vp, vp, vp, vp, cl, vp]),
+    'cffm_bias_gelu': (ci, [vp, vp, vp, cl, ci, vp]),
+    'cffm_gelu_bwd': (ci, [vp, vp, vp, cl, ci, vp]),
+    'cffm_residual_out': (ci, [vp, vp, vp, vp, cl, vp]),
+    'cffm_block_forward': (ci, [GP, BP, vp, cl, vp, cl, vp, vp, vp, vp, vp]),
+    'cffm_block_backward': (ci, [GP, BP, BP, vp, cl, vp, cl, vp, vp, vp, vp, vp, cl, ci, vp, cl, vp, vp]),
+    'cffm_layer_forward': (ci, [GP, ci, BP, vp, vp, vp, vp, vp, vp, vp]),
+    'cffm_layer_backward': (ci, [GP, ci, BP, BP, vp, vp, vp, vp, vp, vp, vp]),
+    'cffm_gtc_attn_fwd': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    'cffm_gtc_attn_bwd': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+}
+
+
+class CffmError(RuntimeError):
+    pass
+
+
+def bind(path):
+    """Load a library exporting the C ABI of include/cffm_hip.h and attach the signatures."""
+    lib = C.CDLL(path)
+    missing = [n for n in SIGNATURES if not hasattr(lib, n)]
+    if missing:
+        raise CffmError('%s does not export %s' % (path, ', '.join(missing)))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.cffm_abi_version() != ABI_VERSION:
+        raise CffmError('%s: ABI version %d, expected %d' % (path, lib.cffm_abi_version(), ABI_VERSION))
+    return lib
+
+
+_lib = None
+_override = None   # set only by tests/emu.py (emulator build of the same kernel sources)
+
+
+def get():
+    """The product library.  Raises CffmError when it has not been built: no fallback."""
+    global _lib
+    if _override is not None:
+        return _override
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise CffmError('libcffm_hip.so is missing (%s): build it with `python -c "import __graft_entry__ as g; '
+                            'g.build()"`; the CFFM hot path has no CPU fallback' % LIB_PATH)
+        _lib = bind(LIB_PATH)
+    return _lib
+
+
+def check(rc, lib):
+    if rc != 0:
+        raise CffmError('libcffm_hip: %s (code %d)' % (lib.cffm_last_error().decode(), rc))

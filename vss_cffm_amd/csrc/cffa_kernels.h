@@ -1,0 +1,257 @@
+// cffa_kernels.h -- Coarse-to-Fine Feature Assembling (CFFA) kernels + layout transposes.
+//
+// Reference semantics: CffmTransformerBlock3d3.forward, cffm_transformer.py:709-805
+// (LayerNorm on all frames :716, zero padding :721-724, target window pooling :741-776,
+// per-reference-frame bilinear resize + window pooling :780-805), restated in SURVEY.md A.1-A.6.
+//
+// MI355X design: HBM-bound.  One workgroup per (window, frame, clip) reads its 49 pixels x 256
+// channels as 1 KiB coalesced rows (one wave per pixel, one f32x4 per lane), LayerNorms them in
+// registers and reduces them against the composed [15 x 49] window-local pooling matrix
+// (learned pool weights x constant bilinear taps), so the LayerNormed reference frames never
+// reach HBM -- only 15 pooled rows per window do, plus the target frame's tokens in window-major
+// order (which makes every later per-window access contiguous).
+#pragma once
+#include "cffm_common.h"
+
+// --------------------------------------------------------------------------- batched transpose
+// dst[n][c][r] = src[n][r][c]; src rows x cols, batch strides given (elements).
+// NCHW -> NHWC : rows = C, cols = H*W.   NHWC -> NCHW : rows = H*W, cols = C.
+__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, float* __restrict__ dst,
+                                                    int rows, int cols, long src_bs, long dst_bs) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const float* s = src + (long)blockIdx.z * src_bs;
+    float* d = dst + (long)blockIdx.z * dst_bs;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = 0; k < 16; ++k) {
+        int r = r0 + ty + 4 * k, c = c0 + tx;
+        tile[ty + 4 * k][tx] = (r < rows && c < cols) ? s[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {
+        int c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < rows && c < cols) d[(long)c * rows + r] = tile[tx][ty + 4 * k];
+    }
+}
+
+// --------------------------------------------------------------------------- pooling matrix
+// Cell g of a window is a fixed linear functional of the window's 49 LayerNormed pixels
+// (SURVEY.md A.6 "window-locality"): g=0 target pool, g=1 frame t-9 (7x7 pool), g=2..5 frame t-6
+// (7->6 bilinear, 3x3 pool, 2x2 cells), g=6..14 frame t-3 (7->6 bilinear, 2x2 pool, 3x3 cells).
+// Bilinear 7->6, align_corners=False: output r in 0..5 reads source r and r+1 with weights
+// (11-2r)/12 and (1+2r)/12 (F.interpolate at cffm_transformer.py:795; scale 7/6 is window periodic).
+__device__ __forceinline__ float bil_tap(int r, int p) {
+    if (p == r) return (11.f - 2.f * r) * (1.f / 12.f);
+    if (p == r + 1) return (1.f + 2.f * r) * (1.f / 12.f);
+    return 0.f;
+}
+
+// which pool weight vector / geometry a cell uses
+__device__ __forceinline__ void cell_geom(int g, int& grp, int& u, int& v, int& wsg) {
+    if (g == 0) { grp = 0; u = v = 0; wsg = 7; }
+    else if (g == 1) { grp = 1; u = v = 0; wsg = 7; }
+    else if (g < 6) { grp = 2; u = (g - 2) >> 1; v = (g - 2) & 1; wsg = 3; }
+    else { grp = 3; u = (g - 6) / 3; v = (g - 6) % 3; wsg = 2; }
+}
+
+struct PoolW { const float* w[4]; };  // pool_layers.0, pool_layers_clips.{0,1,2} weights
+struct PoolWG { float* w[4]; };
+
+__global__ void __launch_bounds__(256) k_pool_matrix(PoolW pw, float* __restrict__ M) {
+    for (int e = threadIdx.x; e < CFFM_NCELL * CFFM_WA; e += 256) {
+        const int g = e / CFFM_WA, i = e % CFFM_WA, py = i / 7, px = i % 7;
+        int grp, u, v, wsg;
+        cell_geom(g, grp, u, v, wsg);
+        float m;
+        if (grp < 2) {
+            m = pw.w[grp][i];
+        } else {
+            m = 0.f;
+            for (int a = 0; a < wsg; ++a)
+                for (int b = 0; b < wsg; ++b)
+                    m += pw.w[grp][a * wsg + b] * bil_tap(wsg * u + a, py) * bil_tap(wsg * v + b, px);
+        }
+        M[e] = m;
+    }
+}
+
+// dW_pool[grp][k] = sum_{g in grp, i} dM[g][i] * dM[g][i]/dw
+__global__ void __launch_bounds__(128) k_pool_matrix_bwd(const float* __restrict__ dM, PoolWG gw) {
+    const int t = threadIdx.x;
+    int grp, k;
+    if (t < 49) { grp = 0; k = t; }
+    else if (t < 98) { grp = 1; k = t - 49; }
+    else if (t < 107) { grp = 2; k = t - 98; }
+    else if (t < 111) { grp = 3; k = t - 107; }
+    else return;
+    float acc = 0.f;
+    if (grp < 2) {
+        acc = dM[grp * CFFM_WA + k];
+    } else {
+        const int wsg = grp == 2 ? 3 : 2, ncell = grp == 2 ? 2 : 3, g0 = grp == 2 ? 2 : 6;
+        const int a = k / wsg, b = k % wsg;
+        for (int u = 0; u < ncell; ++u)
+            for (int v = 0; v < ncell; ++v)
+                for (int i = 0; i < CFFM_WA; ++i)
+                    acc += dM[(g0 + u * ncell + v) * CFFM_WA + i] * bil_tap(wsg * u + a, i / 7) * bil_tap(wsg * v + b, i % 7);
+    }
+    gw.w[grp][k] = acc;
+}
+
+// --------------------------------------------------------------------------- geometry helpers
+struct Geo {
+    int B, H0, W0, Hp, Wp, gy, gx, nW, HW, RC;  // RC = 64*nW rows per clip in the token-row space
+};
+// token-row space of one clip: [0,49nW) target tokens window-major | [49nW,50nW) P0 | [50nW,51nW) f0
+// | [51nW,55nW) f1 (2gy x 2gx) | [55nW,64nW) f2 (3gy x 3gx)
+__device__ __forceinline__ int cell_row(const Geo& G, int wy, int wx, int g) {
+    const int w = wy * G.gx + wx;
+    if (g == 0) return 49 * G.nW + w;
+    if (g == 1) return 50 * G.nW + w;
+    if (g < 6) { int u = (g - 2) >> 1, v = (g - 2) & 1; return 51 * G.nW + (2 * wy + u) * (2 * G.gx) + 2 * wx + v; }
+    int u = (g - 6) / 3, v = (g - 6) % 3;
+    return 55 * G.nW + (3 * wy + u) * (3 * G.gx) + 3 * wx + v;
+}
+__device__ __forceinline__ void frame_cells(int frame, int& g0, int& ncell) {
+    if (frame == 3) { g0 = 0; ncell = 1; }
+    else if (frame == 0) { g0 = 1; ncell = 1; }
+    else if (frame == 1) { g0 = 2; ncell = 4; }
+    else { g0 = 6; ncell = 9; }
+}
+
+struct PoolB { const float* b[4]; };
+struct PoolBG { float* b[4]; };
+__device__ __forceinline__ int frame_group(int frame) { return frame == 3 ? 0 : frame + 1; }
+
+// --------------------------------------------------------------------------- LN1 + pad + pool (forward)
+// grid (nW, 4 frames, B), 256 threads.  x_ref [B,3,HW,C] (batch stride ref_bs), x_tgt [B,HW,C]
+// (batch stride tgt_bs), both NHWC.  Writes zall rows (target tokens incl. zero rows of padded
+// pixels; pooled rows incl. pool bias) and the per-pixel LayerNorm statistics.
+__global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
+                                                      const float* __restrict__ x_tgt, long tgt_bs,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ M, PoolB pb,
+                                                      float* __restrict__ zall, float* __restrict__ mean_out,
+                                                      float* __restrict__ rstd_out) {
+    __shared__ float sM[9 * CFFM_WA];
+    __shared__ float red[4][9][CFFM_C];
+    const int w = blockIdx.x, frame = blockIdx.y, b = blockIdx.z;
+    const int wy = w / G.gx, wx = w % G.gx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int g0, ncell;
+    frame_cells(frame, g0, ncell);
+    for (int e = threadIdx.x; e < ncell * CFFM_WA; e += 256) sM[e] = M[g0 * CFFM_WA + e];
+    __syncthreads();
+    const float* xf = (frame == 3) ? x_tgt + (long)b * tgt_bs : x_ref + (long)b * ref_bs + (long)frame * G.HW * CFFM_C;
+    const f32x4 gm = *(const f32x4*)(gamma + 4 * lane), bt = *(const f32x4*)(beta + 4 * lane);
+    f32x4 acc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = wave; i < CFFM_WA; i += 4) {
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        const bool valid = (y < G.H0) && (x < G.W0);  // wave-uniform
+        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const long pix = (long)y * G.W0 + x;
+            const f32x4 xv = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
+            const float mu = wave_sum(xv[0] + xv[1] + xv[2] + xv[3]) * (1.f / CFFM_C);
+            const f32x4 d = xv - mu;
+            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / CFFM_C);
+            const float rs = 1.f / sqrtf(var + CFFM_LN_EPS);
+            z = d * rs * gm + bt;
+            if (lane == 0) {
+                mean_out[((long)b * 4 + frame) * G.HW + pix] = mu;
+                rstd_out[((long)b * 4 + frame) * G.HW + pix] = rs;
+            }
+        }
+        if (frame == 3) *(f32x4*)(zall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane) = z;
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+                if (c < ncell) acc[c] += sM[c * CFFM_WA + i] * z;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+        if (c < ncell) *(f32x4*)(&red[wave][c][4 * lane]) = acc[c];
+    __syncthreads();
+    const float pbias = pb.b[frame_group(frame)][0];
+    for (int c = 0; c < ncell; ++c) {
+        const int ch = threadIdx.x;
+        const float s = red[0][c][ch] + red[1][c][ch] + red[2][c][ch] + red[3][c][ch] + pbias;
+        zall[((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + ch] = s;
+    }
+}
+
+// --------------------------------------------------------------------------- LN1 + pad + pool (backward)
+// Inputs: dzall (gradient of every token row: target tokens + pooled cells).  Outputs: dx for the
+// frame (NHWC; `accum` adds to what is there), dgamma/dbeta (atomics), dM [15,49] (atomics),
+// dpool_bias (atomics).
+__global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
+                                                      const float* __restrict__ x_tgt, long tgt_bs,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ M, const float* __restrict__ mean_in,
+                                                      const float* __restrict__ rstd_in, const float* __restrict__ dzall,
+                                                      const float* __restrict__ dres,
+                                                      float* __restrict__ dx_ref, long dref_bs, int accum_ref,
+                                                      float* __restrict__ dx_tgt, long dtgt_bs,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      float* __restrict__ dM, PoolBG dpb) {
+    __shared__ float sM[9 * CFFM_WA];
+    __shared__ float sdP[9][CFFM_C];
+    __shared__ float red[4][2][CFFM_C];
+    const int w = blockIdx.x, frame = blockIdx.y, b = blockIdx.z;
+    const int wy = w / G.gx, wx = w % G.gx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int g0, ncell;
+    frame_cells(frame, g0, ncell);
+    for (int e = threadIdx.x; e < ncell * CFFM_WA; e += 256) sM[e] = M[g0 * CFFM_WA + e];
+    float bsum = 0.f;
+    for (int c = 0; c < ncell; ++c) {
+        const float v = dzall[((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + threadIdx.x];
+        sdP[c][threadIdx.x] = v;
+        bsum += v;
+    }
+    bsum = wave_sum(bsum);
+    if (lane == 0) atomicAdd(dpb.b[frame_group(frame)], bsum);
+    __syncthreads();
+    const float* xf = (frame == 3) ? x_tgt + (long)b * tgt_bs : x_ref + (long)b * ref_bs + (long)frame * G.HW * CFFM_C;
+    float* dxf = (frame == 3) ? dx_tgt + (long)b * dtgt_bs : dx_ref + (long)b * dref_bs + (long)frame * G.HW * CFFM_C;
+    const bool accum = (frame == 3) ? false : (accum_ref != 0);
+    const f32x4 gm = *(const f32x4*)(gamma + 4 * lane), bt = *(const f32x4*)(beta + 4 * lane);
+    f32x4 ag = (f32x4){0.f, 0.f, 0.f, 0.f}, ab = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = wave; i < CFFM_WA; i += 4) {
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        if (!((y < G.H0) && (x < G.W0))) continue;  // padded pixel: z is the constant 0
+        const long pix = (long)y * G.W0 + x;
+        const f32x4 xv = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
+        const float mu = mean_in[((long)b * 4 + frame) * G.HW + pix];
+        const float rs = rstd_in[((long)b * 4 + frame) * G.HW + pix];
+        const f32x4 xh = (xv - mu) * rs;
+        const f32x4 z = xh * gm + bt;
+        f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (frame == 3) dz = *(const f32x4*)(dzall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane);
+        for (int c = 0; c < ncell; ++c) {
+            const f32x4 dp = *(const f32x4*)(&sdP[c][4 * lane]);
+            dz += sM[c * CFFM_WA + i] * dp;
+            const float dm = wave_sum(dp[0] * z[0] + dp[1] * z[1] + dp[2] * z[2] + dp[3] * z[3]);
+            if (lane == 0) atomicAdd(dM + (g0 + c) * CFFM_WA + i, dm);
+        }
+        ag += dz * xh;
+        ab += dz;
+        const f32x4 gz = dz * gm;
+        const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
+        const float m2 = wave_sum(gz[0] * xh[0] + gz[1] * xh[1] + gz[2] * xh[2] + gz[3] * xh[3]) * (1.f / CFFM_C);
+        f32x4 dx = (gz - m1 - xh * m2) * rs;
+        if (frame == 3 && dres) dx += *(const f32x4*)(dres + ((long)b * G.HW + pix) * CFFM_C + 4 * lane);
+        float* dst = dxf + pix * CFFM_C + 4 * lane;
+        if (accum) dx += *(const f32x4*)dst;
+        *(f32x4*)dst = dx;
+    }
+    *(f32x4*)(&red[wave][0][4 * lane]) = ag;
+    *(f32x4*)(&red[wave][1][4 * lane]) = ab;
+    __syncthreads();
+    const int ch = threadIdx.x;
+    atomicAdd(dgamma + ch, red[0][0][ch] + red[1][0][ch] + red[2][0][ch] + red[3][0][ch]);
+    atomicAdd(dbeta + ch, red[0][1][ch] + red[1][1][ch] + red[2][1][ch] + red[3][1][ch]);
+}

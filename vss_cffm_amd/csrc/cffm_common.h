@@ -1,0 +1,128 @@
+// cffm_common.h -- shared device helpers for the CFFM hot-path kernels (gfx950 / CDNA4).
+#pragma once
+#ifdef CFFM_EMU
+#include "hipemu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+// ---- fixed problem constants of the reference head (cffm_head.py:74-95) ------------------------
+#define CFFM_C 256         // embed_dim of every CFFM config
+#define CFFM_HEADS 8
+#define CFFM_HD 32
+#define CFFM_WS 7
+#define CFFM_WA 49         // window area
+#define CFFM_NKEY 289      // 49 own + 132 ring + 25 + 49 + 25 + 9
+#define CFFM_NKEY_PAD 304  // 19 MFMA key tiles of 16
+#define CFFM_NQ_PAD 64
+#define CFFM_NCELL 15      // pooled cells per window: 1 (target) + 1 + 4 + 9
+#define CFFM_HID 1024
+#define CFFM_LN_EPS 1e-5f
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#if defined(CFFM_EMU) && defined(CFFM_EMU_F32)
+typedef float f16;  // emulator-only switch: MFMA operands keep fp32, to separate logic errors from f16 rounding
+#else
+typedef _Float16 f16;
+#endif
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef CFFM_EMU
+#define CFFM_DYN_SMEM(name) char* name = emu::g_blk->dynsmem
+#define CFFM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    emu::launch(dim3 grid, dim3 block, (shmem), [=]() { kernel(__VA_ARGS__); })
+#else
+#define CFFM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define CFFM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3 grid, dim3 block, (shmem), (stream), __VA_ARGS__)
+#endif
+
+// ---- wave (64 lanes) reductions ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ---- MFMA wrappers (CDNA4). Fragment maps used throughout (cdna_hip_programming.md section 3):
+//   16x16x32 f16:  A: lane l holds A[i = l&15][k = 8*(l>>4) + 0..7]
+//                  B: lane l holds B[k = 8*(l>>4) + 0..7][j = l&15]
+//                  C/D: reg r of lane l is C[row = 4*(l>>4) + r][col = l&15]
+//   Only the (l&15) <-> i/j maps and the C/D map matter for correctness: any bijection between the
+//   8 k-slots of a lane group and actual k indices gives the same product as long as A and B use
+//   the same one -- the PV / dK / dV contractions below exploit exactly that.
+//   16x16x4 f32:   A: lane l holds A[i = l&15][k = l>>4];  B: B[k = l>>4][j = l&15];  C/D as above.
+__device__ __forceinline__ f32x4 mfma16x16x32_f16(f16x8 a, f16x8 b, f32x4 c) {
+#ifdef CFFM_EMU
+    struct Frag { float a[8], b[8]; } mine;
+    for (int j = 0; j < 8; ++j) { mine.a[j] = (float)a[j]; mine.b[j] = (float)b[j]; }
+    int lane = emu::lane_linear() & 63;
+    auto s = emu::deposit(&mine, sizeof(mine));
+    int col = lane & 15, g = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg) {
+            const Frag* fa = reinterpret_cast<const Frag*>(s[row + 16 * kg]);
+            const Frag* fb = reinterpret_cast<const Frag*>(s[col + 16 * kg]);
+            for (int j = 0; j < 8; ++j) acc += fa->a[j] * fb->b[j];
+        }
+        c[r] = acc;
+    }
+    emu::release();
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ f32x4 mfma16x16x4_f32(float a, float b, f32x4 c) {
+#ifdef CFFM_EMU
+    struct Frag { float a, b; } mine{a, b};
+    int lane = emu::lane_linear() & 63;
+    auto s = emu::deposit(&mine, sizeof(mine));
+    int col = lane & 15, g = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            const Frag* fa = reinterpret_cast<const Frag*>(s[row + 16 * k]);
+            const Frag* fb = reinterpret_cast<const Frag*>(s[col + 16 * k]);
+            acc = fmaf(fa->a, fb->b, acc);
+        }
+        c[r] = acc;
+    }
+    emu::release();
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ f16x4 to_f16x4(f32x4 v) {
+    f16x4 r;
+    r[0] = (f16)v[0]; r[1] = (f16)v[1]; r[2] = (f16)v[2]; r[3] = (f16)v[3];
+    return r;
+}
+__device__ __forceinline__ f16x8 cat_f16x4(f16x4 lo, f16x4 hi) {
+    f16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,438 @@
+// cffm_hip.hip -- C-ABI entry points of libcffm_hip.so (see include/cffm_hip.h) and the host-side
+// orchestration of one CFFM block / layer on a HIP stream.  gfx950 only.
+#include "cfm_attn_kernels.h"
+#include "rowops_kernels.h"
+#include "gtc_kernels.h"
+#include "gemm.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/cffm_hip.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define CHECK_LAUNCH(name)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) return fail(-2, "%s: launch failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+#define REQUIRE(cond, ...) \
+    do { if (!(cond)) return fail(-1, __VA_ARGS__); } while (0)
+#define TRY(call) \
+    do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+static Geo to_geo(const cffm_geom* g) {
+    Geo G;
+    G.B = g->B; G.H0 = g->H0; G.W0 = g->W0; G.Hp = g->Hp; G.Wp = g->Wp; G.gy = g->gy; G.gx = g->gx;
+    G.nW = g->nW; G.HW = g->HW; G.RC = g->RC;
+    return G;
+}
+
+extern "C" {
+
+int cffm_abi_version(void) { return CFFM_ABI_VERSION; }
+const char* cffm_last_error(void) { return g_err; }
+
+int cffm_geom_init(cffm_geom* g, int B, int H0, int W0) {
+    REQUIRE(g, "geom_init: null");
+    REQUIRE(B >= 1 && H0 >= 1 && W0 >= 1, "geom_init: bad sizes B=%d H0=%d W0=%d", B, H0, W0);
+    g->B = B; g->H0 = H0; g->W0 = W0;
+    g->Hp = (H0 + 6) / 7 * 7; g->Wp = (W0 + 6) / 7 * 7;
+    g->gy = g->Hp / 7; g->gx = g->Wp / 7;
+    g->nW = g->gy * g->gx; g->HW = H0 * W0; g->RC = 64 * g->nW;
+    return 0;
+}
+
+static long up(long v) { return (v + 63) / 64 * 64; }  // keep every carve 256-B aligned
+
+int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* o) {
+    REQUIRE(g && o, "ws_layout: null");
+    const long B = g->B, HW = g->HW, RC = g->RC, nW = g->nW;
+    long p = 0;
+    o->mean1 = p; p += up(B * 4 * HW);
+    o->rstd1 = p; p += up(B * 4 * HW);
+    o->M = p; p += up(CFFM_NCELL * CFFM_WA);
+    o->zall = p; p += up(B * RC * CFFM_C);
+    o->qkv = p; p += up(B * RC * 768);
+    o->bias = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
+    o->biasT = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
+    o->lse = p; p += up(B * nW * CFFM_HEADS * CFFM_NQ_PAD);
+    o->ao = p; p += up(B * HW * CFFM_C);
+    o->x1 = p; p += up(B * HW * CFFM_C);
+    o->mean2 = p; p += up(B * HW);
+    o->rstd2 = p; p += up(B * HW);
+    o->z2 = p; p += up(B * HW * CFFM_C);
+    o->hraw = p; p += up(B * HW * CFFM_HID);
+    o->act = p; p += up(B * HW * CFFM_HID);
+    o->x2 = p; p += up(B * HW * CFFM_C);
+    o->total = p;
+    return 0;
+}
+
+long cffm_layer_saved_floats(const cffm_geom* g, int depth) {
+    cffm_block_ws w;
+    if (cffm_block_ws_layout(g, &w)) return -1;
+    return up((long)g->B * 4 * g->HW * CFFM_C) + depth * w.total;
+}
+
+// scratch carve (floats): fwd uses [0, BHW*C); bwd uses all of it
+struct Scratch { long a, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, total; };
+static Scratch scratch_layout(const cffm_geom* g) {
+    const long B = g->B, HW = g->HW, RC = g->RC;
+    Scratch s;
+    long p = 0;
+    s.a = p; p += up(B * HW * CFFM_C);
+    s.b = p; p += up(B * HW * CFFM_C);
+    s.dz2 = p; p += up(B * HW * CFFM_C);
+    s.dao = p; p += up(B * HW * CFFM_C);
+    s.dact = p; p += up(B * HW * CFFM_HID);
+    s.dqkv = p; p += up(B * RC * 768);
+    s.dzall = p; p += up(B * RC * CFFM_C);
+    s.dM = p; p += up(CFFM_NCELL * CFFM_WA);
+    s.dbiasT = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
+    s.dxs = p; p += up(B * 4 * HW * CFFM_C);
+    s.total = p;
+    return s;
+}
+long cffm_layer_scratch_floats(const cffm_geom* g) { return scratch_layout(g).total; }
+
+// ------------------------------------------------------------------------------------------- stages
+int cffm_transpose(const float* src, float* dst, int batch, int rows, int cols, long src_bs, long dst_bs, void* stream) {
+    REQUIRE(src && dst && batch > 0 && rows > 0 && cols > 0, "transpose: bad arguments");
+    CFFM_LAUNCH(k_transpose, ((cols + 63) / 64, (rows + 63) / 64, batch), (256), 0, (hipStream_t)stream, src, dst, rows, cols,
+                src_bs, dst_bs);
+    CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+int cffm_pool_matrix(const float* const pool_w[4], float* M, void* stream) {
+    PoolW pw;
+    for (int i = 0; i < 4; ++i) { REQUIRE(pool_w[i], "pool_matrix: null weight %d", i); pw.w[i] = pool_w[i]; }
+    CFFM_LAUNCH(k_pool_matrix, (1), (256), 0, (hipStream_t)stream, pw, M);
+    CHECK_LAUNCH("pool_matrix");
+    return 0;
+}
+
+int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream) {
+    PoolWG gw;
+    for (int i = 0; i < 4; ++i) gw.w[i] = dpool_w[i];
+    CFFM_LAUNCH(k_pool_matrix_bwd, (1), (128), 0, (hipStream_t)stream, dM, gw);
+    CHECK_LAUNCH("pool_matrix_bwd");
+    return 0;
+}
+
+int cffm_ln_pool_fwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
+                     const float* gamma, const float* beta, const float* M, const float* const pool_b[4],
+                     float* zall, float* mean, float* rstd, void* stream) {
+    REQUIRE(g && x_ref && x_tgt && zall, "ln_pool_fwd: null");
+    PoolB pb;
+    for (int i = 0; i < 4; ++i) pb.b[i] = pool_b[i];
+    CFFM_LAUNCH(k_ln_pool_fwd, (g->nW, 4, g->B), (256), 0, (hipStream_t)stream, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma,
+                beta, M, pb, zall, mean, rstd);
+    CHECK_LAUNCH("ln_pool_fwd");
+    return 0;
+}
+
+int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
+                     const float* gamma, const float* beta, const float* M, const float* mean, const float* rstd,
+                     const float* dzall, const float* dres, float* dx_ref, long dref_bs, int accum_ref,
+                     float* dx_tgt, long dtgt_bs, float* dgamma, float* dbeta, float* dM, float* const dpool_b[4],
+                     void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PoolBG pb;
+    for (int i = 0; i < 4; ++i) { pb.b[i] = dpool_b[i]; hipMemsetAsync(dpool_b[i], 0, sizeof(float), st); }
+    hipMemsetAsync(dgamma, 0, CFFM_C * sizeof(float), st);
+    hipMemsetAsync(dbeta, 0, CFFM_C * sizeof(float), st);
+    hipMemsetAsync(dM, 0, CFFM_NCELL * CFFM_WA * sizeof(float), st);
+    CFFM_LAUNCH(k_ln_pool_bwd, (g->nW, 4, g->B), (256), 0, st, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma, beta, M, mean, rstd,
+                dzall, dres, dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, dgamma, dbeta, dM, pb);
+    CHECK_LAUNCH("ln_pool_bwd");
+    return 0;
+}
+
+int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias, float* biasT, void* stream) {
+    BiasTables t;
+    t.own = own; t.ring = ring;
+    for (int i = 0; i < 4; ++i) t.pool[i] = pool[i];
+    const int n = CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD;
+    CFFM_LAUNCH(k_bias_assemble, ((n + 255) / 256), (256), 0, (hipStream_t)stream, t, bias, biasT);
+    CHECK_LAUNCH("bias_assemble");
+    return 0;
+}
+
+int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* const dpool[4], void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    BiasTablesG t;
+    t.own = down; t.ring = dring;
+    static const int pool_n[4] = {8 * 121, 8 * 169, 8 * 121, 8 * 81};
+    hipMemsetAsync(down, 0, 169 * 8 * sizeof(float), st);
+    for (int i = 0; i < 4; ++i) { t.pool[i] = dpool[i]; hipMemsetAsync(dpool[i], 0, pool_n[i] * sizeof(float), st); }
+    const int n = CFFM_HEADS * CFFM_NKEY * CFFM_WA;
+    CFFM_LAUNCH(k_bias_scatter, ((n + 255) / 256), (256), 0, st, dbiasT, t);
+    CHECK_LAUNCH("bias_scatter");
+    return 0;
+}
+
+int cffm_attn_fwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
+                  const float* bias, float* ao, float* lse, void* stream) {
+    REQUIRE(g && qkv && key_src && q_dst && bias && ao && lse, "attn_fwd: null");
+    CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), qkv, qkv_b,
+                key_src, q_dst, bias, ao, lse);
+    CHECK_LAUNCH("attn_fwd");
+    return 0;
+}
+
+static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
+    const int total = g->B * g->nW;
+    int ng = total < 32 ? total : 32;  // 8 heads x 32 groups = one 512-thread workgroup per CU
+    *per_group = (total + ng - 1) / ng;
+    return (total + *per_group - 1) / *per_group;
+}
+
+int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
+                  const float* bias, const float* biasT, const float* ao, const float* dao, const float* lse,
+                  float* dqkv, float* dbiasT, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    REQUIRE(g && qkv && biasT && dao && dqkv && dbiasT, "attn_bwd: null");
+    hipMemsetAsync(dqkv, 0, (size_t)g->B * g->RC * 768 * sizeof(float), st);
+    hipMemsetAsync(dbiasT, 0, (size_t)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD * sizeof(float), st);
+    int per;
+    const int ng = attn_bwd_groups(g, &per);
+    CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (512), ATT_BWD_LDS, st, to_geo(g), qkv, qkv_b, key_src, q_dst, bias, biasT, ao,
+                dao, lse, dqkv, dbiasT, per);
+    CHECK_LAUNCH("attn_bwd");
+    return 0;
+}
+
+int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream) {
+    return gemm_nt(x, w, y, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_fwd: gemm failed") : 0;
+}
+int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream) {
+    return gemm_nn(dy, w, dx, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_input: gemm failed") : 0;
+}
+int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream) {
+    return gemm_tn(dy, x, dw, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_weight: gemm failed") : 0;
+}
+
+int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    REQUIRE(cols % 256 == 0, "colsum: cols must be a multiple of 256");
+    hipMemsetAsync(out, 0, cols * sizeof(float), st);
+    int slices = (int)((rows + 63) / 64);
+    if (slices > 128) slices = 128;
+    CFFM_LAUNCH(k_colsum, (cols / 256, slices), (256), 0, st, a, rows, cols, out);
+    CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
+                     const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,
+                     long nrows, void* stream) {
+    CFFM_LAUNCH(k_residual_ln, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, xt, xt_bs, rows_per_batch, yraw, bproj,
+                gamma, beta, x1, z2, mean, rstd, nrows);
+    CHECK_LAUNCH("residual_ln");
+    return 0;
+}
+
+int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, const float* gamma, const float* dz2,
+                         const float* dres, float* dx1, float* dgamma, float* dbeta, long nrows, int zero_grads, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_grads) {
+        hipMemsetAsync(dgamma, 0, CFFM_C * sizeof(float), st);
+        hipMemsetAsync(dbeta, 0, CFFM_C * sizeof(float), st);
+    }
+    const int rpb = 32;
+    CFFM_LAUNCH(k_ln_bwd_residual, ((unsigned)((nrows + rpb - 1) / rpb)), (256), 0, st, x1, mean, rstd, gamma, dz2, dres, dx1,
+                dgamma, dbeta, nrows, rpb);
+    CHECK_LAUNCH("ln_bwd_residual");
+    return 0;
+}
+
+static unsigned ew_grid(long n4) {
+    long b = (n4 + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, int cols, void* stream) {
+    REQUIRE(cols % 4 == 0, "bias_gelu: cols %% 4");
+    const long n4 = rows * cols / 4;
+    CFFM_LAUNCH(k_bias_gelu, (ew_grid(n4)), (256), 0, (hipStream_t)stream, hraw, b1, act, n4, cols / 4);
+    CHECK_LAUNCH("bias_gelu");
+    return 0;
+}
+int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, int cols, void* stream) {
+    const long n4 = rows * cols / 4;
+    CFFM_LAUNCH(k_gelu_bwd, (ew_grid(n4)), (256), 0, (hipStream_t)stream, hraw, b1, dact, n4, cols / 4);
+    CHECK_LAUNCH("gelu_bwd");
+    return 0;
+}
+int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float* out, long rows, void* stream) {
+    const long n4 = rows * CFFM_C / 4;
+    CFFM_LAUNCH(k_residual_out, (ew_grid(n4)), (256), 0, (hipStream_t)stream, x1, oraw, b2, out, n4);
+    CHECK_LAUNCH("residual_out");
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------- CFFM++ (GTC) stages
+int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
+                       long nrows, void* stream) {
+    CFFM_LAUNCH(k_layernorm, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, x, gamma, beta, z, mean, rstd, nrows);
+    CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, float* o, float* lse,
+                      int B, int T, int K, void* stream) {
+    REQUIRE(K >= 1 && K <= 512, "gtc_attn_fwd: K=%d outside 1..512", K);
+    CFFM_LAUNCH(k_gtc_attn_fwd, ((T + GTC_TOK - 1) / GTC_TOK, CFFM_HEADS, B), (256), (size_t)2 * K * CFFM_HD * sizeof(float),
+                (hipStream_t)stream, q_raw, q_b, kv_raw, kv_b, o, lse, T, K);
+    CHECK_LAUNCH("gtc_attn_fwd");
+    return 0;
+}
+
+int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, const float* o,
+                      const float* dout, const float* lse, float* dq_raw, float* dkv, int B, int T, int K, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    REQUIRE(K >= 1 && K <= 256, "gtc_attn_bwd: K=%d outside 1..256", K);
+    hipMemsetAsync(dkv, 0, (size_t)B * K * 512 * sizeof(float), st);
+    CFFM_LAUNCH(k_gtc_attn_bwd, ((T + GTC_TOK - 1) / GTC_TOK, CFFM_HEADS, B), (256), (size_t)4 * K * CFFM_HD * sizeof(float), st, q_raw,
+                q_b, kv_raw, kv_b, o, dout, lse, dq_raw, dkv, T, K);
+    CHECK_LAUNCH("gtc_attn_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- block
+int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const float* x_ref, long ref_bs,
+                       const float* x_tgt, long tgt_bs, const int* key_src, const int* q_dst, float* ws,
+                       float* scratch, void* stream) {
+    REQUIRE(g && p && ws && scratch, "block_forward: null");
+    cffm_block_ws L;
+    cffm_block_ws_layout(g, &L);
+    const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
+    float* yraw = scratch;  // [NP,256] transient (proj output, later fc2 output)
+    TRY(cffm_pool_matrix(p->pool_w, ws + L.M, stream));
+    TRY(cffm_ln_pool_fwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
+                         ws + L.mean1, ws + L.rstd1, stream));
+    TRY(cffm_linear_fwd(ws + L.zall, p->qkv_w, ws + L.qkv, NR, 768, CFFM_C, stream));
+    TRY(cffm_bias_assemble(p->rpb_own, p->rpb_ring, p->rpb_pool, ws + L.bias, ws + L.biasT, stream));
+    TRY(cffm_attn_fwd(g, ws + L.qkv, p->qkv_b, key_src, q_dst, ws + L.bias, ws + L.ao, ws + L.lse, stream));
+    TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
+    TRY(cffm_residual_ln(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
+                         ws + L.mean2, ws + L.rstd2, NP, stream));
+    TRY(cffm_linear_fwd(ws + L.z2, p->fc1_w, ws + L.hraw, NP, CFFM_HID, CFFM_C, stream));
+    TRY(cffm_bias_gelu(ws + L.hraw, p->fc1_b, ws + L.act, NP, CFFM_HID, stream));
+    TRY(cffm_linear_fwd(ws + L.act, p->fc2_w, yraw, NP, CFFM_C, CFFM_HID, stream));
+    TRY(cffm_residual_out(ws + L.x1, yraw, p->fc2_b, ws + L.x2, NP, stream));
+    return 0;
+}
+
+int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
+                        const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
+                        const int* q_dst, const float* ws, const float* dout, float* dx_ref, long dref_bs,
+                        int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, void* stream) {
+    REQUIRE(g && p && gr && ws && dout && scratch, "block_backward: null");
+    cffm_block_ws L;
+    cffm_block_ws_layout(g, &L);
+    const Scratch S = scratch_layout(g);
+    const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
+    float* dx1 = scratch + S.b;
+    float* dz2 = scratch + S.dz2;
+    float* dao = scratch + S.dao;
+    float* dact = scratch + S.dact;
+    float* dqkv = scratch + S.dqkv;
+    float* dzall = scratch + S.dzall;
+    float* dM = scratch + S.dM;
+    float* dbiasT = scratch + S.dbiasT;
+    // x2 = x1 + act W2^T + b2
+    TRY(cffm_colsum(dout, NP, CFFM_C, gr->fc2_b, stream));
+    TRY(cffm_linear_bwd_weight(dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID, stream));
+    TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
+    // act = gelu(hraw + b1); hraw = z2 W1^T
+    TRY(cffm_gelu_bwd(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, stream));
+    TRY(cffm_colsum(dact, NP, CFFM_HID, gr->fc1_b, stream));
+    TRY(cffm_linear_bwd_weight(dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C, stream));
+    TRY(cffm_linear_bwd_input(dact, p->fc1_w, dz2, NP, CFFM_HID, CFFM_C, stream));
+    // z2 = LN2(x1); x1 also feeds the residual
+    TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1, stream));
+    // x1 = xt + ao Wp^T + bp
+    TRY(cffm_colsum(dx1, NP, CFFM_C, gr->proj_b, stream));
+    TRY(cffm_linear_bwd_weight(dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C, stream));
+    TRY(cffm_linear_bwd_input(dx1, p->proj_w, dao, NP, CFFM_C, CFFM_C, stream));
+    // attention
+    TRY(cffm_attn_bwd(g, ws + L.qkv, p->qkv_b, key_src, q_dst, ws + L.bias, ws + L.biasT, ws + L.ao, dao, ws + L.lse, dqkv,
+                      dbiasT, stream));
+    TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, stream));
+    // qkv = zall Wqkv^T (+ bias inside the attention kernel)
+    TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
+    TRY(cffm_linear_bwd_weight(dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C, stream));
+    TRY(cffm_linear_bwd_input(dqkv, p->qkv_w, dzall, NR, 768, CFFM_C, stream));
+    // CFFA
+    TRY(cffm_ln_pool_bwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1,
+                         dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, gr->norm1_w, gr->norm1_b, dM, gr->pool_b, stream));
+    TRY(cffm_pool_matrix_bwd(dM, gr->pool_w, stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- layer
+int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* params, const float* x_nchw,
+                       float* y_tgt_nchw, const int* key_src, const int* q_dst, float* saved, float* scratch,
+                       void* stream) {
+    REQUIRE(g && params && x_nchw && y_tgt_nchw && saved && scratch && depth >= 1, "layer_forward: bad arguments");
+    cffm_block_ws L;
+    cffm_block_ws_layout(g, &L);
+    const long HW = g->HW, img = HW * CFFM_C;
+    float* xs = saved;  // NHWC stack [B,4,HW,C]
+    float* blk0 = saved + up((long)g->B * 4 * img);
+    TRY(cffm_transpose(x_nchw, xs, g->B * 4, CFFM_C, (int)HW, img, img, stream));
+    for (int i = 0; i < depth; ++i) {
+        float* ws = blk0 + (long)i * L.total;
+        const float* tgt = (i == 0) ? xs + 3 * img : blk0 + (long)(i - 1) * L.total + L.x2;
+        const long tgt_bs = (i == 0) ? 4 * img : img;
+        TRY(cffm_block_forward(g, &params[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, ws, scratch, stream));
+    }
+    TRY(cffm_transpose(blk0 + (long)(depth - 1) * L.total + L.x2, y_tgt_nchw, g->B, (int)HW, CFFM_C, img, img, stream));
+    return 0;
+}
+
+int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
+                        const float* dy_tgt_nchw, float* dx_nchw, const int* key_src, const int* q_dst,
+                        const float* saved, float* scratch, void* stream) {
+    REQUIRE(g && params && grads && dy_tgt_nchw && dx_nchw && saved && scratch && depth >= 1, "layer_backward: bad arguments");
+    cffm_block_ws L;
+    cffm_block_ws_layout(g, &L);
+    const Scratch S = scratch_layout(g);
+    const long HW = g->HW, img = HW * CFFM_C;
+    const float* xs = saved;
+    const float* blk0 = saved + up((long)g->B * 4 * img);
+    float* dxs = scratch + S.dxs;   // NHWC gradient stack [B,4,HW,C]
+    float* dcur = scratch + S.a;    // gradient of the current block's output target [B,HW,C]
+    TRY(cffm_transpose(dy_tgt_nchw, dcur, g->B, CFFM_C, (int)HW, img, img, stream));
+    for (int i = depth - 1; i >= 0; --i) {
+        const float* ws = blk0 + (long)i * L.total;
+        const float* tgt = (i == 0) ? xs + 3 * img : blk0 + (long)(i - 1) * L.total + L.x2;
+        const long tgt_bs = (i == 0) ? 4 * img : img;
+        // the target-frame gradient goes to the stack for block 0, otherwise back into `dcur`
+        // (block_backward has consumed `dout` by the time ln_pool_bwd writes dx_tgt)
+        float* dtgt = (i == 0) ? dxs + 3 * img : dcur;
+        const long dtgt_bs = (i == 0) ? 4 * img : img;
+        TRY(cffm_block_backward(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, ws, dcur, dxs, 4 * img,
+                                i != depth - 1, dtgt, dtgt_bs, scratch, stream));
+    }
+    TRY(cffm_transpose(dxs, dx_nchw, g->B * 4, (int)HW, CFFM_C, img, img, stream));
+    return 0;
+}
+
+}  // extern "C"
+
+#ifdef CFFM_EMU
+#include "hipemu_impl.h"
+#endif

@@ -1,0 +1,368 @@
+// cfm_attn_kernels.h -- Cross-frame Feature Mining (CFM): fused windowed multi-head cross-attention.
+//
+// Reference semantics: WindowAttention3d3.forward, cffm_transformer.py:364-606 -- 49 target-window
+// queries against 289 assembled keys (49 own | 132 cyclic 3-px ring :389-418 | 25 pooled-target
+// :426-468 | 49+25+9 pooled reference-frame cells :470-518), 6 additive position biases + unfold
+// padding masks (:536-587), softmax (:597), attn @ V (:601).  SURVEY.md A.3-A.8.
+//
+// MI355X design (the reference materialises k_all/v_all (48 MB/clip) and the 37 MB attention matrix):
+//  * nothing is materialised: a workgroup owns one (clip, window, head); its 289 K/V rows are gathered
+//    straight from the q/k/v GEMM output through a host-built key table (roll / unfold / cat / masks of
+//    the reference become one int32 row index per key, -1 = unfold zero padding) as 128-B row
+//    segments (one (token, head) slice = exactly one cache line), converted to f16 and staged in LDS;
+//  * blockIdx.x % 8 == head, so (as dispatched today) one XCD serves one head: its L2 holds the 64-ch
+//    slice of every token and the per-head bias table, and neighbouring windows' overlapping
+//    ring / pooled keys hit in that L2;
+//  * QK^T is computed transposed (S^T = K Q^T, one 16x16x32 f16 MFMA per 16 keys since hd = 32 is
+//    exactly one K-step) so the softmax row lives in the registers of 4 lanes: the reduction is
+//    76 in-register ops + 2 wave shuffles, and P (un-normalised, <= 1) feeds the PV MFMA as the B
+//    operand straight from registers (the k-slot <-> key bijection is shared with the V^T image
+//    in LDS), accumulating in f32.  f16 operands / f32 accumulate keep the block output within
+//    ~1e-4 of the fp32 reference (bf16 would miss the 1e-3 contract: SURVEY.md fact 10).
+//  * LDS rows are padded to 80 B (K, Q) so the 16 rows of an MFMA fragment hit 16 distinct 16-B
+//    slots (conflict-free ds_read_b128), and the transposed image has a row stride of 4*odd dwords
+//    (conflict-free ds_read_b64).
+#pragma once
+#include "cffa_kernels.h"
+
+#define ATT_KS_STRIDE 40   // halfs per K/V/Q row in LDS (32 + 8 pad = 80 B)
+#define ATT_VT_STRIDE 328  // halfs per row of a [32][keys] transposed image (164 dwords = 4*41)
+#define ATT_QT_STRIDE 72   // halfs per row of a [32][64 queries] transposed image (36 dwords = 4*9)
+
+#define ATT_FWD_LDS ((CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 64 * ATT_KS_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4)
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+
+// grid: B*nW*8 workgroups (head fastest), 256 threads = 4 waves x 16 queries.
+__global__ void __launch_bounds__(256) k_cfm_attn_fwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
+                                                       const int* __restrict__ key_src, const int* __restrict__ q_dst,
+                                                       const float* __restrict__ bias, float* __restrict__ ao,
+                                                       float* __restrict__ lse_out) {
+    CFFM_DYN_SMEM(smem);
+    f16* Ks = (f16*)smem;
+    f16* Vt = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+    f16* Qs = Vt + 32 * ATT_VT_STRIDE;
+    float* vflag = (float*)(Qs + 64 * ATT_KS_STRIDE);
+
+    const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* ksrc = key_src + w * CFFM_NKEY_PAD;
+    const float* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;
+    const float scale = 0.17677669529663687f;  // 32^-0.5 (cffm_transformer.py:248,528)
+
+    // ---- stage: key validity, K rows, V transposed, Q rows (bias of the qkv Linear added here) ----
+    for (int n = tid; n < CFFM_NKEY_PAD; n += 256) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
+    for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 256)
+        Vt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
+    {
+        const int ch = lane >> 3;
+        const f32x4 bk = ld4(bqkv + 256 + h * CFFM_HD + 4 * ch), bv = ld4(bqkv + 512 + h * CFFM_HD + 4 * ch);
+        for (int it = 0; it < 5; ++it) {
+            const int pr = (it * 4 + wave) * 8 + (lane & 7);
+            if (pr < CFFM_NKEY_PAD / 2) {
+                const int n0 = 2 * pr, s0 = ksrc[n0], s1 = ksrc[n0 + 1];
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 k0 = z, k1 = z, v0 = z, v1 = z;
+                if (s0 >= 0) { k0 = ld4(base + (long)s0 * 768 + 256 + 4 * ch) + bk; v0 = ld4(base + (long)s0 * 768 + 512 + 4 * ch) + bv; }
+                if (s1 >= 0) { k1 = ld4(base + (long)s1 * 768 + 256 + 4 * ch) + bk; v1 = ld4(base + (long)s1 * 768 + 512 + 4 * ch) + bv; }
+                *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0);
+                *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1);
+                for (int e = 0; e < 4; ++e) {
+                    f16x2 pv; pv[0] = (f16)v0[e]; pv[1] = (f16)v1[e];
+                    *(f16x2*)(Vt + (4 * ch + e) * ATT_VT_STRIDE + n0) = pv;
+                }
+            }
+        }
+        for (int it = tid; it < 64 * 8; it += 256) {
+            const int i = it >> 3, c = it & 7;
+            f32x4 q = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i < CFFM_WA) q = (ld4(base + (long)(w * CFFM_WA + i) * 768 + 4 * c) + ld4(bqkv + h * CFFM_HD + 4 * c)) * scale;
+            *(f16x4*)(Qs + i * ATT_KS_STRIDE + 4 * c) = to_f16x4(q);
+        }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column -----------------
+    const int qcol = 16 * wave + (lane & 15), g = lane >> 4;
+    const f16x8 qfrag = *(const f16x8*)(Qs + qcol * ATT_KS_STRIDE + 8 * g);
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
+    f32x4 s[19];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 19; ++t) {
+        const f16x8 kf = *(const f16x8*)(Ks + (16 * t + (lane & 15)) * ATT_KS_STRIDE + 8 * g);
+        f32x4 acc = mfma16x16x32_f16(kf, qfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
+        acc += ld4(brow + 16 * t) + *(const f32x4*)(vflag + 16 * t + 4 * g);
+        s[t] = acc;
+        m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 19; ++t) {
+        f32x4 p;
+        p[0] = expf(s[t][0] - m); p[1] = expf(s[t][1] - m); p[2] = expf(s[t][2] - m); p[3] = expf(s[t][3] - m);
+        s[t] = p;
+        l += (p[0] + p[1]) + (p[2] + p[3]);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+
+    // ---- O^T = V^T P^T : A = V^T[d][key-slots] from LDS, B = P^T from registers ----------------------
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kt = 0; kt < 10; ++kt) {
+        const f16x4 lo = to_f16x4(s[2 * kt]);
+        const f16x4 hi = (2 * kt + 1 < 19) ? to_f16x4(s[(2 * kt + 1 < 19) ? 2 * kt + 1 : 0]) : (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        const f16x8 pf = cat_f16x4(lo, hi);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f16* vr = Vt + (16 * mt + (lane & 15)) * ATT_VT_STRIDE + 32 * kt + 4 * g;
+            const f16x8 vf = cat_f16x4(*(const f16x4*)vr, *(const f16x4*)(vr + 16));
+            o[mt] = mfma16x16x32_f16(vf, pf, o[mt]);
+        }
+    }
+
+    // ---- epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821) ------------
+    if (g == 0) lse_out[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol] = (qcol < CFFM_WA) ? m + logf(l) : 0.f;
+    if (qcol < CFFM_WA) {
+        const int dst = q_dst[w * CFFM_WA + qcol];
+        if (dst >= 0) {
+            const float inv = 1.f / l;
+            float* orow = ao + ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 4 * g;
+            *(f32x4*)(orow) = o[0] * inv;
+            *(f32x4*)(orow + 16) = o[1] * inv;
+        }
+    }
+}
+
+// =====================================================================================================
+// Backward.  grid (8 heads, NG groups), 512 threads; each workgroup walks the windows of its group for
+// one head.  Waves 0-3 ("query owners": 16 queries x all keys, S^T orientation) produce dQ and the
+// position-bias gradient, which stays in registers across the windows of the group; waves 4-7 ("key
+// owners": 16-key tiles x all 64 queries, S orientation) produce dK and dV for their keys and add them
+// to the shared token rows (ring / pooled keys are read by several windows) with f32 atomics.
+// dO is rescaled per window by a power of two so every f16 gradient operand sits near 1 (training-size
+// gradients of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
+// =====================================================================================================
+#define ATT_BWD_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
+                     CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
+
+__global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
+                                                       const int* __restrict__ key_src, const int* __restrict__ q_dst,
+                                                       const float* __restrict__ bias, const float* __restrict__ biasT,
+                                                       const float* __restrict__ ao, const float* __restrict__ dao,
+                                                       const float* __restrict__ lse_in, float* __restrict__ dqkv,
+                                                       float* __restrict__ dbiasT, int per_group) {
+    CFFM_DYN_SMEM(smem);
+    f16* Qs = (f16*)smem;
+    f16* dOs = Qs + 64 * ATT_KS_STRIDE;
+    f16* Ks = dOs + 64 * ATT_KS_STRIDE;
+    f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+    f16* Kt = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+    f16* Qt = Kt + 32 * ATT_VT_STRIDE;
+    f16* dOt = Qt + 32 * ATT_QT_STRIDE;
+    float* vflag = (float*)(dOt + 32 * ATT_QT_STRIDE);
+    float* slse = vflag + CFFM_NKEY_PAD;
+    float* sD = slse + 64;
+    float* smax = sD + 64;
+
+    const int h = blockIdx.x, grp = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const float scale = 0.17677669529663687f;
+    const int wb0 = grp * per_group;
+    const int wb1 = (wb0 + per_group < G.B * G.nW) ? wb0 + per_group : G.B * G.nW;
+
+    f32x4 dB[19];
+#pragma unroll
+    for (int t = 0; t < 19; ++t) dB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int wb = wb0; wb < wb1; ++wb) {
+        const int w = wb % G.nW, b = wb / G.nW;
+        const int* ksrc = key_src + w * CFFM_NKEY_PAD;
+        const float* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;
+
+        // ---------------- stage --------------------------------------------------------------------
+        for (int n = tid; n < CFFM_NKEY_PAD; n += 512) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
+        for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 512)
+            Kt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
+        if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid];
+        {   // K (row-major + transposed) and V (row-major); lane -> (row pair, 4-channel chunk)
+            const int ch = lane >> 3;
+            const f32x4 bk = ld4(bqkv + 256 + h * CFFM_HD + 4 * ch), bv = ld4(bqkv + 512 + h * CFFM_HD + 4 * ch);
+            for (int it = 0; it < 3; ++it) {
+                const int pr = (it * 8 + wave) * 8 + (lane & 7);
+                if (pr < CFFM_NKEY_PAD / 2) {
+                    const int n0 = 2 * pr, s0 = ksrc[n0], s1 = ksrc[n0 + 1];
+                    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    f32x4 k0 = z, k1 = z, v0 = z, v1 = z;
+                    if (s0 >= 0) { k0 = ld4(base + (long)s0 * 768 + 256 + 4 * ch) + bk; v0 = ld4(base + (long)s0 * 768 + 512 + 4 * ch) + bv; }
+                    if (s1 >= 0) { k1 = ld4(base + (long)s1 * 768 + 256 + 4 * ch) + bk; v1 = ld4(base + (long)s1 * 768 + 512 + 4 * ch) + bv; }
+                    *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0);
+                    *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1);
+                    *(f16x4*)(Vs + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v0);
+                    *(f16x4*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v1);
+                    for (int e = 0; e < 4; ++e) {
+                        f16x2 pk; pk[0] = (f16)k0[e]; pk[1] = (f16)k1[e];
+                        *(f16x2*)(Kt + (4 * ch + e) * ATT_VT_STRIDE + n0) = pk;
+                    }
+                }
+            }
+        }
+        // Q (threads 0..255) and dO / D (threads 256..511); item = (query pair, chunk); chunk = lane & 7 so
+        // the 8 chunks of a query sit in 8 adjacent lanes (D is reduced with xor-shuffles 1,2,4)
+        const int pr = (tid & 255) >> 3, c = tid & 7, i0 = 2 * pr, i1 = i0 + 1;
+        f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        float d0 = 0.f, d1 = 0.f, amax = 0.f;
+        if (tid < 256) {
+            const f32x4 bq = ld4(bqkv + h * CFFM_HD + 4 * c);
+            if (i0 < CFFM_WA) r0 = (ld4(base + (long)(w * CFFM_WA + i0) * 768 + 4 * c) + bq) * scale;
+            if (i1 < CFFM_WA) r1 = (ld4(base + (long)(w * CFFM_WA + i1) * 768 + 4 * c) + bq) * scale;
+        } else {
+            const int t0 = (i0 < CFFM_WA) ? q_dst[w * CFFM_WA + i0] : -1, t1 = (i1 < CFFM_WA) ? q_dst[w * CFFM_WA + i1] : -1;
+            if (t0 >= 0) {
+                const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c;
+                r0 = ld4(dao + off);
+                const f32x4 ov = ld4(ao + off);
+                d0 = r0[0] * ov[0] + r0[1] * ov[1] + r0[2] * ov[2] + r0[3] * ov[3];
+            }
+            if (t1 >= 0) {
+                const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c;
+                r1 = ld4(dao + off);
+                const f32x4 ov = ld4(ao + off);
+                d1 = r1[0] * ov[0] + r1[1] * ov[1] + r1[2] * ov[2] + r1[3] * ov[3];
+            }
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
+        }
+        d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64); d0 += __shfl_xor(d0, 4, 64);
+        d1 += __shfl_xor(d1, 1, 64); d1 += __shfl_xor(d1, 2, 64); d1 += __shfl_xor(d1, 4, 64);
+        amax = wave_max(amax);
+        if (lane == 0) smax[wave] = amax;
+        __syncthreads();
+        // power-of-two rescale of dO so that max|dO * sc| is in [1,2)
+        const float am = fmaxf(fmaxf(smax[4], smax[5]), fmaxf(smax[6], smax[7]));
+        int ex = 0;
+        if (am > 0.f) frexpf(am, &ex);
+        const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f;
+        const float isc = 1.f / sc;
+        {
+            f16* rowm = (tid < 256) ? Qs : dOs;
+            f16* trn = (tid < 256) ? Qt : dOt;
+            if (tid >= 256) {
+                r0 *= sc; r1 *= sc;
+                if (c == 0) { sD[i0] = d0 * sc; sD[i1] = d1 * sc; }
+            }
+            *(f16x4*)(rowm + i0 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r0);
+            *(f16x4*)(rowm + i1 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r1);
+            for (int e = 0; e < 4; ++e) {
+                f16x2 pq; pq[0] = (f16)r0[e]; pq[1] = (f16)r1[e];
+                *(f16x2*)(trn + (4 * c + e) * ATT_QT_STRIDE + i0) = pq;
+            }
+        }
+        __syncthreads();
+
+        if (wave < 4) {
+            // ---------------- role A: query owners -> dQ, dBias ----------------------------------------
+            const int qcol = 16 * wave + l15;
+            const f16x8 qfrag = *(const f16x8*)(Qs + qcol * ATT_KS_STRIDE + 8 * g);
+            const f16x8 dofrag = *(const f16x8*)(dOs + qcol * ATT_KS_STRIDE + 8 * g);
+            const float lq = slse[qcol], Dq = sD[qcol];
+            const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
+            f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kt = 0; kt < 10; ++kt) {
+                f16x4 dsh[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = 2 * kt + u;
+                    if (t < 19) {
+                        const f16x8 kf = *(const f16x8*)(Ks + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
+                        const f16x8 vf = *(const f16x8*)(Vs + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
+                        f32x4 sv = mfma16x16x32_f16(kf, qfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
+                        const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});
+                        sv += ld4(brow + 16 * t) + *(const f32x4*)(vflag + 16 * t + 4 * g);
+                        f32x4 ds;
+                        for (int r = 0; r < 4; ++r) ds[r] = expf(sv[r] - lq) * (dp[r] - Dq);
+                        dB[t < 19 ? t : 0] += ds * isc;
+                        dsh[u] = to_f16x4(ds);
+                    } else {
+                        dsh[u] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                    }
+                }
+                const f16x8 dsf = cat_f16x4(dsh[0], dsh[1]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16* kr = Kt + (16 * mt + l15) * ATT_VT_STRIDE + 32 * kt + 4 * g;
+                    const f16x8 ka = cat_f16x4(*(const f16x4*)kr, *(const f16x4*)(kr + 16));
+                    dq[mt] = mfma16x16x32_f16(ka, dsf, dq[mt]);
+                }
+            }
+            if (qcol < CFFM_WA) {
+                float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
+                *(f32x4*)(drow) = dq[0] * (scale * isc);
+                *(f32x4*)(drow + 16) = dq[1] * (scale * isc);
+            }
+        } else {
+            // ---------------- role B: key owners -> dK, dV ---------------------------------------------
+            for (int t = wave - 4; t < 19; t += 4) {
+                const int key = 16 * t + l15;
+                const f16x8 kfrag = *(const f16x8*)(Ks + key * ATT_KS_STRIDE + 8 * g);
+                const f16x8 vfrag = *(const f16x8*)(Vs + key * ATT_KS_STRIDE + 8 * g);
+                const float vf = vflag[key];
+                const float* btrow = biasT + ((long)h * CFFM_NKEY_PAD + key) * CFFM_NQ_PAD + 4 * g;
+                f16x4 ph[4], dsh[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f16x8 qa = *(const f16x8*)(Qs + (16 * mt + l15) * ATT_KS_STRIDE + 8 * g);
+                    const f16x8 da = *(const f16x8*)(dOs + (16 * mt + l15) * ATT_KS_STRIDE + 8 * g);
+                    f32x4 sv = mfma16x16x32_f16(qa, kfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    const f32x4 dp = mfma16x16x32_f16(da, vfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    sv += ld4(btrow + 16 * mt) + vf;
+                    const f32x4 lq = *(const f32x4*)(slse + 16 * mt + 4 * g), Dq = *(const f32x4*)(sD + 16 * mt + 4 * g);
+                    f32x4 p, ds;
+                    for (int r = 0; r < 4; ++r) { p[r] = expf(sv[r] - lq[r]); ds[r] = p[r] * (dp[r] - Dq[r]); }
+                    ph[mt] = to_f16x4(p);
+                    dsh[mt] = to_f16x4(ds);
+                }
+                f32x4 dv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+                f32x4 dk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 pf = cat_f16x4(ph[2 * ks], ph[2 * ks + 1]);
+                    const f16x8 sf = cat_f16x4(dsh[2 * ks], dsh[2 * ks + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const f16* orow = dOt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
+                        const f16* qrow = Qt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
+                        dv[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)orow, *(const f16x4*)(orow + 16)), pf, dv[dt]);
+                        dk[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)qrow, *(const f16x4*)(qrow + 16)), sf, dk[dt]);
+                    }
+                }
+                const int src = ksrc[key];
+                if (src >= 0) {
+                    float* drow = dqkv + ((long)b * G.RC + src) * 768 + h * CFFM_HD + 4 * g;
+                    for (int dt = 0; dt < 2; ++dt)
+                        for (int r = 0; r < 4; ++r) {
+                            atomicAdd(drow + 256 + 16 * dt + r, dk[dt][r] * isc);
+                            atomicAdd(drow + 512 + 16 * dt + r, dv[dt][r] * isc);
+                        }
+                }
+            }
+        }
+        __syncthreads();  // LDS is restaged for the next window
+    }
+
+    if (wave < 4) {
+        const int qcol = 16 * wave + l15;
+        if (qcol < CFFM_WA) {
+#pragma unroll
+            for (int t = 0; t < 19; ++t)
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * t + 4 * g + r;
+                    if (key < CFFM_NKEY) atomicAdd(dbiasT + ((long)h * CFFM_NKEY_PAD + key) * CFFM_NQ_PAD + qcol, dB[t][r]);
+                }
+        }
+    }
+}

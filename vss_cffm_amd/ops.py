@@ -1,0 +1,242 @@
+"""Torch-facing operators of the CFFM hot path: thin plumbing over the C ABI (include/cffm_hip.h).
+
+PyTorch supplies device memory, the current HIP stream and autograd bookkeeping; all arithmetic of
+the hot path happens inside libcffm_hip.so.  Tensors must be fp32, contiguous and on the GPU; a CPU
+tensor raises (there is no CPU fallback -- the reference's CPU path is the oracle under oracle/,
+which this package never imports).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, geometry
+
+# field order of one block's parameters as the autograd function receives them (state_dict keys of
+# CffmTransformerBlock3d3) -> (struct field, index inside an array field)
+BLOCK_PARAM_KEYS = (
+    ('norm1.weight', 'norm1_w', None), ('norm1.bias', 'norm1_b', None),
+    ('pool_layers.0.weight', 'pool_w', 0), ('pool_layers.0.bias', 'pool_b', 0),
+    ('pool_layers_clips.0.weight', 'pool_w', 1), ('pool_layers_clips.0.bias', 'pool_b', 1),
+    ('pool_layers_clips.1.weight', 'pool_w', 2), ('pool_layers_clips.1.bias', 'pool_b', 2),
+    ('pool_layers_clips.2.weight', 'pool_w', 3), ('pool_layers_clips.2.bias', 'pool_b', 3),
+    ('attn.relative_position_bias_table', 'rpb_own', None),
+    ('attn.relative_position_bias_table_to_neighbors', 'rpb_ring', None),
+    ('attn.relative_position_bias_table_to_windows.0', 'rpb_pool', 0),
+    ('attn.relative_position_bias_table_to_windows_clips.0', 'rpb_pool', 1),
+    ('attn.relative_position_bias_table_to_windows_clips.1', 'rpb_pool', 2),
+    ('attn.relative_position_bias_table_to_windows_clips.2', 'rpb_pool', 3),
+    ('attn.qkv.weight', 'qkv_w', None), ('attn.qkv.bias', 'qkv_b', None),
+    ('attn.proj.weight', 'proj_w', None), ('attn.proj.bias', 'proj_b', None),
+    ('norm2.weight', 'norm2_w', None), ('norm2.bias', 'norm2_b', None),
+    ('mlp.fc1.weight', 'fc1_w', None), ('mlp.fc1.bias', 'fc1_b', None),
+    ('mlp.fc2.weight', 'fc2_w', None), ('mlp.fc2.bias', 'fc2_b', None),
+)
+NPB = len(BLOCK_PARAM_KEYS)   # tensors per block
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(t):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def _require_device(t, what):
+    if _lib._override is None and not t.is_cuda:
+        raise _lib.CffmError('%s: the CFFM hot path runs only on the GPU (got a %s tensor); there is no CPU '
+                             'fallback' % (what, t.device))
+    if t.dtype != torch.float32:
+        raise _lib.CffmError('%s: fp32 expected, got %s' % (what, t.dtype))
+
+
+def make_geom(lib, b, h0, w0):
+    g = _lib.Geom()
+    _lib.check(lib.cffm_geom_init(C.byref(g), b, h0, w0), lib)
+    return g
+
+
+_table_cache = {}
+
+
+def device_tables(h0, w0, device):
+    key = (h0, w0, str(device))
+    if key not in _table_cache:
+        ks, qd = geometry.tables(h0, w0)
+        _table_cache[key] = (torch.from_numpy(np.ascontiguousarray(ks)).to(device),
+                             torch.from_numpy(np.ascontiguousarray(qd)).to(device))
+    return _table_cache[key]
+
+
+def block_ptrs(tensors):
+    """26 tensors in BLOCK_PARAM_KEYS order -> a cffm_block_params / cffm_block_grads struct."""
+    s = _lib.BlockPtrs()
+    for t, (_, field, idx) in zip(tensors, BLOCK_PARAM_KEYS):
+        if idx is None:
+            setattr(s, field, t.data_ptr())
+        else:
+            getattr(s, field)[idx] = t.data_ptr()
+    return s
+
+
+def block_ws_layout(lib, g):
+    w = _lib.BlockWs()
+    _lib.check(lib.cffm_block_ws_layout(C.byref(g), C.byref(w)), lib)
+    return w
+
+
+class _LayerFn(torch.autograd.Function):
+    """BasicLayer3d3.forward (cffm_transformer.py:917-927) as one custom op: x [B,T,256,H,W] and the
+    26*depth block parameters -> the new target frame [B,256,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, depth, *params):
+        lib = _lib.get()
+        _require_device(x, 'cffm layer input')
+        if x.dim() != 5 or x.shape[2] != 256:
+            raise _lib.CffmError('expected x [B,T,256,H,W], got %s' % (tuple(x.shape),))
+        if x.shape[1] != 4:
+            # the reference indexes reference frames 0..2 and the target [-1] (cffm_transformer.py:780-792)
+            raise IndexError('CFFM block needs T == 4 frames (3 reference + target), got T=%d' % x.shape[1])
+        assert len(params) == NPB * depth
+        b, _, _, h0, w0 = x.shape
+        x = x.contiguous()
+        params = [p.detach().contiguous() for p in params]
+        g = make_geom(lib, b, h0, w0)
+        key_src, q_dst = device_tables(h0, w0, x.device)
+        saved = torch.empty(lib.cffm_layer_saved_floats(C.byref(g), depth), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.cffm_layer_scratch_floats(C.byref(g)), dtype=torch.float32, device=x.device)
+        y = torch.empty(b, 256, h0, w0, dtype=torch.float32, device=x.device)
+        pstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(params[i * NPB:(i + 1) * NPB]) for i in range(depth)])
+        _lib.check(lib.cffm_layer_forward(C.byref(g), depth, pstructs, _ptr(x), _ptr(y), _ptr(key_src), _ptr(q_dst),
+                                          _ptr(saved), _ptr(scratch), _stream(x)), lib)
+        ctx.depth, ctx.geom_args = depth, (b, h0, w0)
+        ctx.save_for_backward(saved, key_src, q_dst, *params)
+        ctx.scratch = scratch
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.get()
+        saved, key_src, q_dst, *params = ctx.saved_tensors
+        depth = ctx.depth
+        b, h0, w0 = ctx.geom_args
+        g = make_geom(lib, b, h0, w0)
+        dy = dy.contiguous()
+        grads = [torch.empty_like(p) for p in params]
+        dx = torch.empty(b, 4, 256, h0, w0, dtype=torch.float32, device=dy.device)
+        pstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(params[i * NPB:(i + 1) * NPB]) for i in range(depth)])
+        gstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(grads[i * NPB:(i + 1) * NPB]) for i in range(depth)])
+        _lib.check(lib.cffm_layer_backward(C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src),
+                                           _ptr(q_dst), _ptr(saved), _ptr(ctx.scratch), _stream(dy)), lib)
+        return (dx, None) + tuple(grads)
+
+
+def cffm_layer(x, depth, params):
+    """x [B,4,256,H,W]; params: flat list of 26*depth tensors (BLOCK_PARAM_KEYS order per block).
+    Returns the reference's output [B,4,256,H,W]: frames 0..2 are the input, frame 3 is new."""
+    y = _LayerFn.apply(x, depth, *params)
+    return torch.cat([x[:, :-1], y.unsqueeze(1)], dim=1)       # cffm_transformer.py:826
+
+
+# ---------------------------------------------------------------------------------------------- GTC
+GTC_PARAM_KEYS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.qkv_cluster.weight',
+                  'attn.qkv_cluster.bias', 'attn.proj_cluster.weight', 'attn.proj_cluster.bias', 'norm2.weight',
+                  'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias')
+
+
+class _GtcBlockFn(torch.autograd.Function):
+    """SwinTransformerBlock_cluster.forward (pvt/swin_transformer_2d.py:605-665), shift 0:
+    x [B,T,256], centers [B,K,256] -> [B,T,256].  The host sequences the stage-level C entry points."""
+
+    @staticmethod
+    def forward(ctx, x, centers, *p):
+        lib = _lib.get()
+        _require_device(x, 'gtc input')
+        _require_device(centers, 'gtc centers')
+        n1w, n1b, qw, qb, kvw, kvb, pw, pb, n2w, n2b, w1, b1, w2, b2 = [t.detach().contiguous() for t in p]
+        x, centers = x.contiguous(), centers.contiguous()
+        b, t, c = x.shape
+        k = centers.shape[1]
+        nt, nk, st = b * t, b * k, _stream(x)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=x.device)
+        z, mean1, rstd1 = new(nt, c), new(nt), new(nt)
+        cn, cmean, crstd = new(nk, c), new(nk), new(nk)
+        ck = lambda rc: _lib.check(rc, lib)
+        ck(lib.cffm_layernorm_fwd(_ptr(x), _ptr(n1w), _ptr(n1b), _ptr(z), _ptr(mean1), _ptr(rstd1), nt, st))
+        ck(lib.cffm_layernorm_fwd(_ptr(centers), _ptr(n1w), _ptr(n1b), _ptr(cn), _ptr(cmean), _ptr(crstd), nk, st))
+        qraw, kvraw = new(nt, c), new(nk, 2 * c)
+        ck(lib.cffm_linear_fwd(_ptr(z), _ptr(qw), _ptr(qraw), nt, c, c, st))          # q third only (:219-220)
+        ck(lib.cffm_linear_fwd(_ptr(cn), _ptr(kvw), _ptr(kvraw), nk, 2 * c, c, st))
+        ao, lse = new(nt, c), new(nt, 8)
+        ck(lib.cffm_gtc_attn_fwd(_ptr(qraw), _ptr(qb), _ptr(kvraw), _ptr(kvb), _ptr(ao), _ptr(lse), b, t, k, st))
+        yraw = new(nt, c)
+        ck(lib.cffm_linear_fwd(_ptr(ao), _ptr(pw), _ptr(yraw), nt, c, c, st))
+        x1, z2, mean2, rstd2 = new(nt, c), new(nt, c), new(nt), new(nt)
+        ck(lib.cffm_residual_ln(_ptr(x), nt * c, nt, _ptr(yraw), _ptr(pb), _ptr(n2w), _ptr(n2b), _ptr(x1), _ptr(z2),
+                                _ptr(mean2), _ptr(rstd2), nt, st))
+        hraw, act = new(nt, 4 * c), new(nt, 4 * c)
+        ck(lib.cffm_linear_fwd(_ptr(z2), _ptr(w1), _ptr(hraw), nt, 4 * c, c, st))
+        ck(lib.cffm_bias_gelu(_ptr(hraw), _ptr(b1), _ptr(act), nt, 4 * c, st))
+        ck(lib.cffm_linear_fwd(_ptr(act), _ptr(w2), _ptr(yraw), nt, c, 4 * c, st))
+        out = new(b, t, c)
+        ck(lib.cffm_residual_out(_ptr(x1), _ptr(yraw), _ptr(b2), _ptr(out), nt, st))
+        ctx.save_for_backward(x, centers, z, mean1, rstd1, cn, cmean, crstd, qraw, kvraw, ao, lse, x1, z2, mean2, rstd2,
+                              hraw, act, n1w, n1b, qw, qb, kvw, kvb, pw, pb, n2w, n2b, w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.get()
+        (x, centers, z, mean1, rstd1, cn, cmean, crstd, qraw, kvraw, ao, lse, x1, z2, mean2, rstd2, hraw, act,
+         n1w, n1b, qw, qb, kvw, kvb, pw, pb, n2w, n2b, w1, b1, w2, b2) = ctx.saved_tensors
+        dout = dout.contiguous()
+        b, t, c = x.shape
+        k = centers.shape[1]
+        nt, nk, st = b * t, b * k, _stream(x)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=x.device)
+        ck = lambda rc: _lib.check(rc, lib)
+        g = {n: torch.empty_like(v) for n, v in dict(n1w=n1w, n1b=n1b, qb=qb, kvw=kvw, kvb=kvb, pw=pw, pb=pb, n2w=n2w,
+                                                     n2b=n2b, w1=w1, b1=b1, w2=w2, b2=b2).items()}
+        gqw = torch.zeros_like(qw)                 # rows 256.. (unused k,v thirds) keep a zero gradient
+        gqb = torch.zeros_like(qb)
+        ck(lib.cffm_colsum(_ptr(dout), nt, c, _ptr(g['b2']), st))
+        ck(lib.cffm_linear_bwd_weight(_ptr(dout), _ptr(act), _ptr(g['w2']), nt, c, 4 * c, st))
+        dact = new(nt, 4 * c)
+        ck(lib.cffm_linear_bwd_input(_ptr(dout), _ptr(w2), _ptr(dact), nt, c, 4 * c, st))
+        ck(lib.cffm_gelu_bwd(_ptr(hraw), _ptr(b1), _ptr(dact), nt, 4 * c, st))
+        ck(lib.cffm_colsum(_ptr(dact), nt, 4 * c, _ptr(g['b1']), st))
+        ck(lib.cffm_linear_bwd_weight(_ptr(dact), _ptr(z2), _ptr(g['w1']), nt, 4 * c, c, st))
+        dz2, dx1 = new(nt, c), new(nt, c)
+        ck(lib.cffm_linear_bwd_input(_ptr(dact), _ptr(w1), _ptr(dz2), nt, 4 * c, c, st))
+        ck(lib.cffm_ln_bwd_residual(_ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2w), _ptr(dz2), _ptr(dout), _ptr(dx1),
+                                    _ptr(g['n2w']), _ptr(g['n2b']), nt, 1, st))
+        ck(lib.cffm_colsum(_ptr(dx1), nt, c, _ptr(g['pb']), st))
+        ck(lib.cffm_linear_bwd_weight(_ptr(dx1), _ptr(ao), _ptr(g['pw']), nt, c, c, st))
+        dao = new(nt, c)
+        ck(lib.cffm_linear_bwd_input(_ptr(dx1), _ptr(pw), _ptr(dao), nt, c, c, st))
+        dq, dkv = new(nt, c), new(nk, 2 * c)
+        ck(lib.cffm_gtc_attn_bwd(_ptr(qraw), _ptr(qb), _ptr(kvraw), _ptr(kvb), _ptr(ao), _ptr(dao), _ptr(lse), _ptr(dq),
+                                 _ptr(dkv), b, t, k, st))
+        ck(lib.cffm_colsum(_ptr(dq), nt, c, _ptr(gqb), st))                       # first 256 entries
+        ck(lib.cffm_linear_bwd_weight(_ptr(dq), _ptr(z), _ptr(gqw), nt, c, c, st))  # first 256 rows
+        ck(lib.cffm_colsum(_ptr(dkv), nk, 2 * c, _ptr(g['kvb']), st))
+        ck(lib.cffm_linear_bwd_weight(_ptr(dkv), _ptr(cn), _ptr(g['kvw']), nk, 2 * c, c, st))
+        dz, dcn = new(nt, c), new(nk, c)
+        ck(lib.cffm_linear_bwd_input(_ptr(dq), _ptr(qw), _ptr(dz), nt, c, c, st))
+        ck(lib.cffm_linear_bwd_input(_ptr(dkv), _ptr(kvw), _ptr(dcn), nk, 2 * c, c, st))
+        dx, dcenters = new(b, t, c), new(b, k, c)
+        ck(lib.cffm_ln_bwd_residual(_ptr(x), _ptr(mean1), _ptr(rstd1), _ptr(n1w), _ptr(dz), _ptr(dx1), _ptr(dx),
+                                    _ptr(g['n1w']), _ptr(g['n1b']), nt, 1, st))
+        ck(lib.cffm_ln_bwd_residual(_ptr(centers), _ptr(cmean), _ptr(crstd), _ptr(n1w), _ptr(dcn), None, _ptr(dcenters),
+                                    _ptr(g['n1w']), _ptr(g['n1b']), nk, 0, st))     # same norm1 (:622): accumulate
+        return (dx, dcenters, g['n1w'], g['n1b'], gqw, gqb, g['kvw'], g['kvb'], g['pw'], g['pb'], g['n2w'], g['n2b'],
+                g['w1'], g['b1'], g['w2'], g['b2'])
+
+
+def gtc_block(x, centers, params):
+    """params: 14 tensors in GTC_PARAM_KEYS order."""
+    return _GtcBlockFn.apply(x, centers, *params)
