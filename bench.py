@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the CFFM hot path (CFFA + CFM, BasicLayer3d3 depth 2 = CFFM-B1 head) on MI355X.
+
+Metric (BASELINE.json): clips/s, forward + backward, CFFM-B1 480x480 T=4.  A "step" is one forward +
+backward pass of the hot path (`decoder_focal` of the CFFM-B1 head: [B,4,256,60,60] fp32, B = 2 clips per
+GPU as the reference's samples_per_gpu=2) over one batch of synthetic clips already resident in HBM,
+followed by the AdamW update of the hot path's parameters.  N > 1: one process per GPU (torchrun), the
+module wrapped in DistributedDataParallel on RCCL (gradient all-reduce over xGMI, overlapped with backward),
+clips sharded over ranks (weak scaling).
+
+Prints ONE JSON line (rank 0).  Besides the contract's fields it carries
+  roofline     -- the CFM attention forward kernel, timed live with HIP events on the launch stream
+                  (per-stage events inside libcffm_hip.so), against the HBM roofline; MFMA fraction alongside
+  kernels      -- per-stage ms/step breakdown of the timed region (same events)
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm, validated against the reference) timed
+                  on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TF = 2500.0    # dense f16/bf16 MFMA peak
+GRID, DEPTH, T = 60, 2, 4    # CFFM-B1, 480x480 -> 1/8 scale 60x60; depths=2 (local_configs/cffm/B1)
+
+
+def algorithmic_bytes_attn_fwd(b, nw, hw):
+    """minimum traffic of the attention kernel per clip-block, fp32: q/k/v of the 49*nW target
+    rows (768 ch) + k/v of the 15*nW pooled rows (512 ch) read once, output of the H0*W0 valid tokens written."""
+    return b * ((49 * nw * 768 + 15 * nw * 512) * 4 + hw * 256 * 4)
+
+
+def attn_flops(b, nw):
+    return b * 4 * nw * 8 * 49 * 289 * 32       # QK^T + AV, unpadded
+
+
+def cpu_baseline(max_seconds=25.0):
+    """The oracle (CPU restatement of the reference, kind "port") on the host cores: forward + backward of
+    the same hot path on single clips of the same shape."""
+    from oracle import cffm_oracle as O, recipe as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = {k: v.requires_grad_(True) for k, v in R.layer_state(DEPTH, seed=0).items()}
+    x = R.synth_input('x', (1, T, 256, GRID, GRID), seed=1).requires_grad_(True)
+
+    def one():
+        y = O.layer_forward(x, st, DEPTH)
+        y[:, -1].square().mean().backward()
+
+    one()  # warm-up
+    t0, n = time.time(), 0
+    while n < 3 or (time.time() - t0 < max_seconds and n < 12):
+        one()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {'value': round(1.0 / dt, 4), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d x (1 clip [1,4,256,60,60], depth 2, fwd+bwd) after 1 warm-up, torch %d threads' % (n, cores),
+            'ms_per_clip': round(dt * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=2, help='clips per GPU (reference samples_per_gpu=2)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-stage-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')  # RCCL on ROCm
+    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    import vss_cffm_amd as V
+    from vss_cffm_amd import _lib
+    lib = _lib.get()  # raises without the HIP library: no fallback
+
+    torch.manual_seed(0)
+    layer = V.BasicLayer3d3(dim=256, depth=DEPTH, num_heads=8, window_size=7, expand_size=3, pool_method='fc',
+                            focal_level=2, focal_window=5, focal_l_clips=[1, 2, 3], focal_kernel_clips=[7, 5, 3])
+    with torch.no_grad():  # "trained-like" synthetic weights: sharper softmax than default init
+        for n, p in layer.named_parameters():
+            if n.endswith('attn.qkv.weight'):
+                p.normal_(0, 0.08)
+            elif 'relative_position_bias_table' in n:
+                p.normal_(0, 0.5)
+    layer.to(dev)
+    model = layer
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local_rank], gradient_as_bucket_view=True,
+                                                          broadcast_buffers=False)
+    opt = torch.optim.AdamW(layer.parameters(), lr=6e-5, weight_decay=0.01, fused=True)
+    gen = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    b = args.batch
+    x = (torch.randn(b, T, 256, GRID, GRID, generator=gen) * 1.5).to(dev)
+    gy = (torch.randn(b, 256, GRID, GRID, generator=gen) / (b * 256 * GRID * GRID)).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y = model(x)
+        (y[:, -1] * gy).sum().backward()
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    stage_timing = not args.no_stage_timing
+    nst = lib.cffm_profile_stage_count()
+    ms_buf, n_buf = (C.c_float * nst)(), (C.c_int * nst)()
+    if stage_timing:
+        lib.cffm_profile_collect(ms_buf, n_buf)
+        lib.cffm_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if stage_timing:
+        lib.cffm_profile_enable(0)
+        lib.cffm_profile_collect(ms_buf, n_buf)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        nw, hw = ((GRID + 6) // 7) ** 2, GRID * GRID
+        stages = {}
+        for i in range(nst):
+            if n_buf[i]:
+                stages[lib.cffm_profile_stage_name(i).decode()] = {
+                    'ms_per_step': round(ms_buf[i] / args.steps, 4), 'launches_per_step': n_buf[i] / args.steps,
+                    'avg_us': round(1e3 * ms_buf[i] / n_buf[i], 2)}
+        roof = None
+        if 'cfm_attn_fwd' in stages:
+            dur_s = stages['cfm_attn_fwd']['avg_us'] * 1e-6
+            by = algorithmic_bytes_attn_fwd(b, nw, hw)
+            ach = by / dur_s / 1e9
+            tf = attn_flops(b, nw) / dur_s / 1e12
+            roof = {'kernel': 'k_cfm_attn_fwd', 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'algorithmic_bytes_per_launch': by, 'avg_launch_us': stages['cfm_attn_fwd']['avg_us'],
+                    'mfma_achieved_tflops': round(tf, 2), 'mfma_peak_tflops': MFMA_F16_PEAK_TF,
+                    'mfma_frac': round(tf / MFMA_F16_PEAK_TF, 5),
+                    'note': 'timed live with HIP events on the launch stream inside the timed region; '
+                            'traffic (PMC) is collected by separate rocprofv3 --pmc passes, see profiles/'}
+        out = {
+            'metric': 'clips/sec (fwd+bwd) CFFM-B1 480x480 T=4 hot path (CFFA+CFM, decoder_focal depth 2)',
+            'value': round(world * b * args.steps / dt, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (f16 MFMA operands, f32 accumulate, in QK^T/AV only)',
+            'data': 'synthetic',
+            'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
+                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world,
+                       'grad_allreduce': 'RCCL (DDP)' if world > 1 else 'none'},
+            'roofline': roof, 'kernels': stages,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        elif world == 1:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

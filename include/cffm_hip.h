@@ -69,6 +69,12 @@ int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* out);
 long cffm_layer_saved_floats(const cffm_geom* g, int depth);  /* NHWC stack + depth * block_ws.total */
 long cffm_layer_scratch_floats(const cffm_geom* g);
 
+/* ---- optional per-stage HIP-event timing on the caller's stream (bench.py's live roofline numbers) ---- */
+int cffm_profile_enable(int on);
+int cffm_profile_stage_count(void);
+const char* cffm_profile_stage_name(int i);
+int cffm_profile_collect(float* ms /*[stage_count]*/, int* calls /*[stage_count]*/); /* synchronises, sums, clears */
+
 /* ---- stage level (each is one kernel; used by the parity tests and by the block functions) ---- */
 /* dst[n][c][r] = src[n][r][c] for n < batch (element strides src_bs / dst_bs between batches) */
 int cffm_transpose(const float* src, float* dst, int batch, int rows, int cols, long src_bs, long dst_bs, void* stream);

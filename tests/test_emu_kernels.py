@@ -1,0 +1,156 @@
+"""Kernel LOGIC on the CPU: the HIP kernel sources executed by the fiber emulator (tests/emu.py,
+vss_cffm_amd/csrc/hipemu.h) through the same C ABI and the same Python host code as on the GPU,
+compared with the golden vectors of the reference and with oracle intermediates.  The numbers that
+count are the -m gpu tests; this file exists because the build container has no GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cffm_oracle as O, recipe as R
+from tests import emu, helpers as H
+from vss_cffm_amd import _lib, geometry, ops
+
+FWD_TOL = 5e-4   # f16 MFMA operands, f32 accumulate (SURVEY.md 8d tolerance ladder)
+BWD_TOL = 2e-3
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def flat_params(st, depth):
+    return [st['blocks.%d.%s' % (i, k)].clone().requires_grad_(True) for i in range(depth) for k, _, _ in ops.BLOCK_PARAM_KEYS]
+
+
+@pytest.mark.parametrize('case', ['layer_b1_8x8_d1', 'layer_b2_8x8_d2', 'layer_b1_14x21_d2', 'layer_b1_13x30_d1'])
+def test_layer_against_reference_golden(case):
+    g = H.load_golden(case)
+    b, h, w, depth, st, x, gy = H.layer_case_inputs(g)
+    params = flat_params(st, depth)
+    x.requires_grad_(True)
+    with emu.active():
+        y = ops.cffm_layer(x, depth, params)
+        assert torch.equal(y[:, :-1], x[:, :-1])
+        H.check_layer_forward(g, y[:, -1].detach(), FWD_TOL)
+        (y[:, -1] * gy).sum().backward()
+    pg = {'blocks.%d.%s' % (i, k): params[i * ops.NPB + j].grad for i in range(depth)
+          for j, (k, _, _) in enumerate(ops.BLOCK_PARAM_KEYS)}
+    H.check_layer_backward(g, x.grad, pg, BWD_TOL)
+
+
+def test_stages_against_oracle_intermediates():
+    run_stage_checks(emu.lib(), torch.device('cpu'))
+
+
+def run_stage_checks(lib, device):
+    """CFFA (fp32, tight tolerance), bias assembly (exact) and CFM attention, one stage at a time."""
+    b, h0, w0 = 2, 13, 16
+    st = R.layer_state(1, seed=21)
+    p = O.split_block_params(st, 0)
+    x = R.synth_input('x', (b, 4, h0, w0, 256), seed=22)              # NHWC
+    _, it = O.block_forward(x, p, want=True)
+    p = {k: v.to(device) for k, v in p.items()}
+    x = x.to(device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
+    g = ops.make_geom(lib, b, h0, w0)
+    nw, rc, hw = g.nW, g.RC, g.HW
+    f = lambda *s: torch.zeros(*s, device=device)
+    # --- pooling matrix + LN/pool
+    pw = (C.c_void_p * 4)(*[p[k].data_ptr() for k in ('pool_layers.0.weight', 'pool_layers_clips.0.weight',
+                                                        'pool_layers_clips.1.weight', 'pool_layers_clips.2.weight')])
+    pb = (C.c_void_p * 4)(*[p[k].data_ptr() for k in ('pool_layers.0.bias', 'pool_layers_clips.0.bias',
+                                                        'pool_layers_clips.1.bias', 'pool_layers_clips.2.bias')])
+    M = f(15 * 49)
+    assert lib.cffm_pool_matrix(pw, P(M), stream) == 0
+    zall, mean, rstd = f(b * rc, 256), f(b * 4 * hw), f(b * 4 * hw)
+    xs = x.contiguous()
+    assert lib.cffm_ln_pool_fwd(C.byref(g), P(xs), 4 * hw * 256, P(xs[:, 3]), 4 * hw * 256, P(p['norm1.weight']),
+                                P(p['norm1.bias']), P(M), pb, P(zall), P(mean), P(rstd), stream) == 0
+    zall = zall.view(b, rc, 256)
+    zc = zall.cpu()
+    hp, wp = O.padded_size(h0, w0)
+    win = torch.from_numpy(O.window_pixels(hp, wp))
+    zt = it['zt'].reshape(b, hp * wp, 256)
+    assert H.rel_err(zc[:, :49 * nw], zt[:, win.view(-1)]) < 1e-5
+    off = 49 * nw
+    for pg_ in it['pooled']:
+        n = pg_.shape[1] * pg_.shape[2]
+        assert H.rel_err(zc[:, off:off + n], pg_.reshape(b, n, 256)) < 1e-5, off
+        off += n
+    assert off == rc
+    # --- bias
+    bias, biasT = f(8, 64, 304), f(8, 304, 64)
+    rp = (C.c_void_p * 4)(*[p[k].data_ptr() for k in ('attn.relative_position_bias_table_to_windows.0',
+                                                        'attn.relative_position_bias_table_to_windows_clips.0',
+                                                        'attn.relative_position_bias_table_to_windows_clips.1',
+                                                        'attn.relative_position_bias_table_to_windows_clips.2')])
+    assert lib.cffm_bias_assemble(P(p['attn.relative_position_bias_table']),
+                                  P(p['attn.relative_position_bias_table_to_neighbors']), rp, P(bias), P(biasT), stream) == 0
+    assert torch.equal(bias[:, :49, :289].cpu(), it['bias'])
+    assert torch.equal(biasT.transpose(1, 2), bias)
+    assert float(bias[:, 49:].abs().max()) == 0 and float(bias[:, :, 289:].abs().max()) == 0
+    # --- attention on the library's own zall -> qkv
+    qkv = f(b * rc, 768)
+    assert lib.cffm_linear_fwd(P(zall), P(p['attn.qkv.weight']), P(qkv), b * rc, 768, 256, stream) == 0
+    ks, qd = geometry.tables(h0, w0)
+    ks, qd = torch.from_numpy(np.array(ks)).to(device), torch.from_numpy(np.array(qd)).to(device)
+    ao, lse = f(b * hw, 256), f(b * nw * 8, 64)
+    assert lib.cffm_attn_fwd(C.byref(g), P(qkv), P(p['attn.qkv.bias']), P(ks), P(qd), P(bias), P(ao), P(lse), stream) == 0
+    ao_ref = torch.zeros(b, hp * wp, 256)
+    ao_ref[:, win.view(-1)] = it['ao'].reshape(b, nw * 49, 256)
+    ao_ref = ao_ref.view(b, hp, wp, 256)[:, :h0, :w0].reshape(b * hw, 256)
+    assert H.rel_err(ao.cpu(), ao_ref) < 2e-3   # raw attention output (no residual): f16 operand rounding of q,k,p,v
+
+
+def test_transpose_roundtrip_ragged():
+    lib = emu.lib()
+    src = torch.randn(3, 70, 130)
+    dst, back = torch.zeros(3, 130, 70), torch.zeros(3, 70, 130)
+    assert lib.cffm_transpose(P(src), P(dst), 3, 70, 130, 70 * 130, 70 * 130, None) == 0
+    assert torch.equal(dst, src.transpose(1, 2))
+    assert lib.cffm_transpose(P(dst), P(back), 3, 130, 70, 70 * 130, 70 * 130, None) == 0
+    assert torch.equal(back, src)
+
+
+def test_t_not_4_raises_like_reference():
+    with emu.active():
+        with pytest.raises(IndexError):
+            ops.cffm_layer(torch.zeros(1, 2, 256, 8, 8), 1, [torch.zeros(1)] * ops.NPB)
+
+
+@pytest.mark.parametrize('case', H.GTC_CASES)
+def test_gtc_against_reference_golden(case):
+    with emu.active():
+        run_gtc_case(case, torch.device('cpu'))
+
+
+def run_gtc_case(case, device):
+    import vss_cffm_amd as V
+    g = H.load_golden(case)
+    b, h, w, k = [int(v) for v in g['meta']]
+    m = V.BasicLayer_cluster(dim=256, depth=1, num_heads=8, window_size=7)
+    m.load_state_dict(R.gtc_layer_state(1, seed=3), strict=False)
+    m.to(device)
+    x = R.synth_input('gx', (b, h * w, 256), seed=4).to(device).requires_grad_(True)
+    c = R.synth_input('gc', (b, k, 256), seed=5).to(device).requires_grad_(True)
+    gg = R.synth_input('gg', (b, h * w, 256), seed=6, scale=1.0).to(device)
+    y = m(x, h, w, c)[0]
+    (y * gg).sum().backward()
+    assert H.rel_err(y.detach(), g['y']) < 1e-5            # fp32 VALU path: tight tolerance
+    assert H.rel_err(x.grad, g['dx']) < 2e-5 and H.rel_err(c.grad, g['dc']) < 2e-5
+    no_grad = set(str(s) for s in g['no_grad_keys'])
+    pg = {}
+    for kk, prm in m.named_parameters():
+        if kk in no_grad:
+            assert prm.grad is None
+        else:
+            pg[kk] = prm.grad
+    for key, ref in g.items():
+        if key.startswith('p/g/'):
+            assert H.rel_err(pg[key[4:]], ref) < 2e-5, key
+        elif key.startswith('p/gsum0/'):
+            assert H.rel_err(pg[key[8:]].sum(0), ref) < 2e-5, key
+        elif key.startswith('p/gsum1/'):
+            assert H.rel_err(pg[key[8:]].sum(1), ref) < 2e-5, key

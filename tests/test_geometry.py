@@ -1,0 +1,39 @@
+"""Host logic: the product's gather tables (vss_cffm_amd/geometry.py) against the oracle's index maps."""
+import numpy as np
+import pytest
+
+from oracle import cffm_oracle as O
+from vss_cffm_amd import geometry as G
+
+
+@pytest.mark.parametrize('h0,w0', [(8, 8), (14, 21), (13, 30), (60, 60), (64, 64), (60, 108), (7, 7), (1, 1)])
+def test_tables_match_oracle_maps(h0, w0):
+    key_src, q_dst = G.tables(h0, w0)
+    hp, wp = O.padded_size(h0, w0)
+    gy, gx = hp // 7, wp // 7
+    nw = gy * gx
+    assert key_src.shape == (nw, 304) and q_dst.shape == (nw, 49)
+    win, ring = O.window_pixels(hp, wp), O.ring_pixels(hp, wp)
+    # token row -> padded pixel, to compare with the oracle's pixel-indexed maps
+    row_pix = np.zeros(nw * 49, dtype=np.int64)
+    row_pix[np.arange(nw * 49)] = win.reshape(-1)
+    assert np.array_equal(row_pix[key_src[:, :49]], win)
+    assert np.array_equal(row_pix[key_src[:, 49:181]], ring)
+    n = 181
+    for (off, s, kk, pad) in G.POOLED_GROUPS:
+        cells = O.unfold_cells(gy, gx, s, kk, pad)
+        got = key_src[:, n:n + kk * kk]
+        assert np.array_equal(got >= 0, cells >= 0)
+        assert np.array_equal(np.where(got >= 0, got - off * nw, -1), cells)
+        n += kk * kk
+    assert n == 289 and (key_src[:, 289:] == -1).all()
+    y, x = win // wp, win % wp
+    assert np.array_equal(q_dst, np.where((y < h0) & (x < w0), y * w0 + x, -1))
+    # every unpadded pixel is the destination of exactly one query
+    d = q_dst[q_dst >= 0]
+    assert d.size == h0 * w0 and np.unique(d).size == d.size
+
+
+def test_row_space_is_64_rows_per_window():
+    key_src, _ = G.tables(60, 60)
+    assert key_src.max() < 64 * 81

@@ -41,6 +41,10 @@ SIGNATURES = {
     'cffm_block_ws_layout': (ci, [GP, C.POINTER(BlockWs)]),
     'cffm_layer_saved_floats': (cl, [GP, ci]),
     'cffm_layer_scratch_floats': (cl, [GP]),
+    'cffm_profile_enable': (ci, [ci]),
+    'cffm_profile_stage_count': (ci, []),
+    'cffm_profile_stage_name': (C.c_char_p, [ci]),
+    'cffm_profile_collect': (ci, [vp, vp]),
     'cffm_transpose': (ci, [vp, vp, ci, ci, ci, cl, cl, vp]),
     'cffm_pool_matrix': (ci, [P4, vp, vp]),
     'cffm_pool_matrix_bwd': (ci, [vp, P4, vp]),

@@ -36,6 +36,69 @@ static Geo to_geo(const cffm_geom* g) {
     return G;
 }
 
+
+// ------------------------------------------------------------------------------------------- stage timing
+// Optional per-stage HIP-event timing on the caller's stream (bench.py's live `roofline` numbers):
+// when enabled every stage-level entry point brackets its launches with two events.
+enum { ST_TRANSPOSE, ST_POOLMAT, ST_LN_POOL_FWD, ST_LN_POOL_BWD, ST_BIAS_ASM, ST_BIAS_SCT, ST_ATTN_FWD, ST_ATTN_BWD,
+       ST_GEMM, ST_COLSUM, ST_RES_LN, ST_LN_BWD, ST_GELU, ST_GELU_BWD, ST_RES_OUT, ST_GTC_FWD, ST_GTC_BWD, ST_LN, ST_COUNT };
+static const char* const k_stage_names[ST_COUNT] = {"transpose", "pool_matrix", "ln_pool_fwd", "ln_pool_bwd", "bias_assemble",
+    "bias_scatter", "cfm_attn_fwd", "cfm_attn_bwd", "gemm_rocblas", "colsum", "residual_ln", "ln_bwd", "bias_gelu", "gelu_bwd",
+    "residual_out", "gtc_attn_fwd", "gtc_attn_bwd", "layernorm"};
+#ifndef CFFM_EMU
+#include <vector>
+struct ProfRec { int stage; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t prof_event() {
+    hipEvent_t e;
+    if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    int stage; hipStream_t st; hipEvent_t e0; bool on;
+    ProfScope(int s, void* stream) : stage(s), st((hipStream_t)stream), on(g_prof_on) {
+        if (on) { e0 = prof_event(); (void)hipEventRecord(e0, st); }
+    }
+    ~ProfScope() {
+        if (on) { hipEvent_t e1 = prof_event(); (void)hipEventRecord(e1, st); g_prof_recs.push_back({stage, e0, e1}); }
+    }
+};
+#define PROF(stage) ProfScope prof_scope_(stage, stream)
+#else
+#define PROF(stage) (void)0
+#endif
+
+extern "C" {
+int cffm_profile_enable(int on) {
+#ifndef CFFM_EMU
+    g_prof_on = on != 0;
+#endif
+    return 0;
+}
+int cffm_profile_stage_count(void) { return ST_COUNT; }
+const char* cffm_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? k_stage_names[i] : ""; }
+// sums the recorded intervals per stage (ms) and launch counts, then clears the records; synchronises.
+int cffm_profile_collect(float* ms /*[count]*/, int* calls /*[count]*/) {
+    for (int i = 0; i < ST_COUNT; ++i) { ms[i] = 0.f; calls[i] = 0; }
+#ifndef CFFM_EMU
+    for (auto& r : g_prof_recs) {
+        float t = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        (void)hipEventElapsedTime(&t, r.e0, r.e1);
+        ms[r.stage] += t;
+        calls[r.stage] += 1;
+        g_prof_pool.push_back(r.e0);
+        g_prof_pool.push_back(r.e1);
+    }
+    g_prof_recs.clear();
+#endif
+    return 0;
+}
+}
+
 extern "C" {
 
 int cffm_abi_version(void) { return CFFM_ABI_VERSION; }
@@ -106,6 +169,7 @@ long cffm_layer_scratch_floats(const cffm_geom* g) { return scratch_layout(g).to
 
 // ------------------------------------------------------------------------------------------- stages
 int cffm_transpose(const float* src, float* dst, int batch, int rows, int cols, long src_bs, long dst_bs, void* stream) {
+    PROF(ST_TRANSPOSE);
     REQUIRE(src && dst && batch > 0 && rows > 0 && cols > 0, "transpose: bad arguments");
     CFFM_LAUNCH(k_transpose, ((cols + 63) / 64, (rows + 63) / 64, batch), (256), 0, (hipStream_t)stream, src, dst, rows, cols,
                 src_bs, dst_bs);
@@ -114,6 +178,7 @@ int cffm_transpose(const float* src, float* dst, int batch, int rows, int cols, 
 }
 
 int cffm_pool_matrix(const float* const pool_w[4], float* M, void* stream) {
+    PROF(ST_POOLMAT);
     PoolW pw;
     for (int i = 0; i < 4; ++i) { REQUIRE(pool_w[i], "pool_matrix: null weight %d", i); pw.w[i] = pool_w[i]; }
     CFFM_LAUNCH(k_pool_matrix, (1), (256), 0, (hipStream_t)stream, pw, M);
@@ -122,6 +187,7 @@ int cffm_pool_matrix(const float* const pool_w[4], float* M, void* stream) {
 }
 
 int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream) {
+    PROF(ST_POOLMAT);
     PoolWG gw;
     for (int i = 0; i < 4; ++i) gw.w[i] = dpool_w[i];
     CFFM_LAUNCH(k_pool_matrix_bwd, (1), (128), 0, (hipStream_t)stream, dM, gw);
@@ -132,6 +198,7 @@ int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream)
 int cffm_ln_pool_fwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
                      const float* gamma, const float* beta, const float* M, const float* const pool_b[4],
                      float* zall, float* mean, float* rstd, void* stream) {
+    PROF(ST_LN_POOL_FWD);
     REQUIRE(g && x_ref && x_tgt && zall, "ln_pool_fwd: null");
     PoolB pb;
     for (int i = 0; i < 4; ++i) pb.b[i] = pool_b[i];
@@ -146,6 +213,7 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
                      const float* dzall, const float* dres, float* dx_ref, long dref_bs, int accum_ref,
                      float* dx_tgt, long dtgt_bs, float* dgamma, float* dbeta, float* dM, float* const dpool_b[4],
                      void* stream) {
+    PROF(ST_LN_POOL_BWD);
     hipStream_t st = (hipStream_t)stream;
     PoolBG pb;
     for (int i = 0; i < 4; ++i) { pb.b[i] = dpool_b[i]; hipMemsetAsync(dpool_b[i], 0, sizeof(float), st); }
@@ -159,6 +227,7 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
 }
 
 int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias, float* biasT, void* stream) {
+    PROF(ST_BIAS_ASM);
     BiasTables t;
     t.own = own; t.ring = ring;
     for (int i = 0; i < 4; ++i) t.pool[i] = pool[i];
@@ -169,6 +238,7 @@ int cffm_bias_assemble(const float* own, const float* ring, const float* const p
 }
 
 int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* const dpool[4], void* stream) {
+    PROF(ST_BIAS_SCT);
     hipStream_t st = (hipStream_t)stream;
     BiasTablesG t;
     t.own = down; t.ring = dring;
@@ -183,6 +253,7 @@ int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* con
 
 int cffm_attn_fwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
                   const float* bias, float* ao, float* lse, void* stream) {
+    PROF(ST_ATTN_FWD);
     REQUIRE(g && qkv && key_src && q_dst && bias && ao && lse, "attn_fwd: null");
     CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), qkv, qkv_b,
                 key_src, q_dst, bias, ao, lse);
@@ -200,6 +271,7 @@ static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
 int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
                   const float* bias, const float* biasT, const float* ao, const float* dao, const float* lse,
                   float* dqkv, float* dbiasT, void* stream) {
+    PROF(ST_ATTN_BWD);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(g && qkv && biasT && dao && dqkv && dbiasT, "attn_bwd: null");
     hipMemsetAsync(dqkv, 0, (size_t)g->B * g->RC * 768 * sizeof(float), st);
@@ -213,16 +285,20 @@ int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, cons
 }
 
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream) {
+    PROF(ST_GEMM);
     return gemm_nt(x, w, y, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_fwd: gemm failed") : 0;
 }
 int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream) {
+    PROF(ST_GEMM);
     return gemm_nn(dy, w, dx, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_input: gemm failed") : 0;
 }
 int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream) {
+    PROF(ST_GEMM);
     return gemm_tn(dy, x, dw, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_weight: gemm failed") : 0;
 }
 
 int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
+    PROF(ST_COLSUM);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(cols % 256 == 0, "colsum: cols must be a multiple of 256");
     hipMemsetAsync(out, 0, cols * sizeof(float), st);
@@ -236,6 +312,7 @@ int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
 int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
                      const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,
                      long nrows, void* stream) {
+    PROF(ST_RES_LN);
     CFFM_LAUNCH(k_residual_ln, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, xt, xt_bs, rows_per_batch, yraw, bproj,
                 gamma, beta, x1, z2, mean, rstd, nrows);
     CHECK_LAUNCH("residual_ln");
@@ -244,6 +321,7 @@ int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const floa
 
 int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, const float* gamma, const float* dz2,
                          const float* dres, float* dx1, float* dgamma, float* dbeta, long nrows, int zero_grads, void* stream) {
+    PROF(ST_LN_BWD);
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads) {
         hipMemsetAsync(dgamma, 0, CFFM_C * sizeof(float), st);
@@ -262,6 +340,7 @@ static unsigned ew_grid(long n4) {
 }
 
 int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, int cols, void* stream) {
+    PROF(ST_GELU);
     REQUIRE(cols % 4 == 0, "bias_gelu: cols %% 4");
     const long n4 = rows * cols / 4;
     CFFM_LAUNCH(k_bias_gelu, (ew_grid(n4)), (256), 0, (hipStream_t)stream, hraw, b1, act, n4, cols / 4);
@@ -269,12 +348,14 @@ int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, in
     return 0;
 }
 int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, int cols, void* stream) {
+    PROF(ST_GELU_BWD);
     const long n4 = rows * cols / 4;
     CFFM_LAUNCH(k_gelu_bwd, (ew_grid(n4)), (256), 0, (hipStream_t)stream, hraw, b1, dact, n4, cols / 4);
     CHECK_LAUNCH("gelu_bwd");
     return 0;
 }
 int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float* out, long rows, void* stream) {
+    PROF(ST_RES_OUT);
     const long n4 = rows * CFFM_C / 4;
     CFFM_LAUNCH(k_residual_out, (ew_grid(n4)), (256), 0, (hipStream_t)stream, x1, oraw, b2, out, n4);
     CHECK_LAUNCH("residual_out");
@@ -285,6 +366,7 @@ int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float
 // ------------------------------------------------------------------------------------------- CFFM++ (GTC) stages
 int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
                        long nrows, void* stream) {
+    PROF(ST_LN);
     CFFM_LAUNCH(k_layernorm, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, x, gamma, beta, z, mean, rstd, nrows);
     CHECK_LAUNCH("layernorm_fwd");
     return 0;
@@ -292,6 +374,7 @@ int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 
 int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, float* o, float* lse,
                       int B, int T, int K, void* stream) {
+    PROF(ST_GTC_FWD);
     REQUIRE(K >= 1 && K <= 512, "gtc_attn_fwd: K=%d outside 1..512", K);
     CFFM_LAUNCH(k_gtc_attn_fwd, ((T + GTC_TOK - 1) / GTC_TOK, CFFM_HEADS, B), (256), (size_t)2 * K * CFFM_HD * sizeof(float),
                 (hipStream_t)stream, q_raw, q_b, kv_raw, kv_b, o, lse, T, K);
@@ -301,6 +384,7 @@ int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw,
 
 int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, const float* o,
                       const float* dout, const float* lse, float* dq_raw, float* dkv, int B, int T, int K, void* stream) {
+    PROF(ST_GTC_BWD);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(K >= 1 && K <= 256, "gtc_attn_bwd: K=%d outside 1..256", K);
     hipMemsetAsync(dkv, 0, (size_t)B * K * 512 * sizeof(float), st);

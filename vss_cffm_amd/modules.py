@@ -1,0 +1,187 @@
+"""nn.Module mirror of the reference's hot-path modules, backed by libcffm_hip.so.
+
+Same class names, constructor kwargs and state_dict keys as the reference so its checkpoints load
+unchanged:
+
+* ``BasicLayer3d3``            <- cffm_module/cffm_transformer.py:859-927
+* ``CffmTransformerBlock3d3``  <- :629-832   (parameter container; the arithmetic is in the library)
+* ``WindowAttention3d3``       <- :221-606   (parameter container + the reference's index buffers)
+* ``Mlp``                      <- :10-26
+* ``BasicLayer_cluster`` / ``SwinTransformerBlock_cluster`` / ``WindowAttention_cluster``
+                               <- pvt/swin_transformer_2d.py:1039-1148, :563-665, :157-262
+
+Only the configuration the CFFM heads instantiate (cffm_head.py:74-95, :369-382) is implemented;
+anything else raises NotImplementedError instead of silently computing something different.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_CFFM_FIXED = dict(num_heads=8, window_size=7, expand_size=3, focal_level=2, focal_window=5, pool_method='fc',
+                   mlp_ratio=4., qkv_bias=True)
+
+
+def _index_own(ws=7):
+    c = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing='ij')).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0) + (ws - 1)
+    return rel[..., 0] * (2 * ws - 1) + rel[..., 1]
+
+
+def _index_to(kk, ws=7):
+    q = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing='ij')).flatten(1)
+    k = torch.stack(torch.meshgrid(torch.arange(kk), torch.arange(kk), indexing='ij')).flatten(1)
+    rel = (q[:, :, None] - k[:, None, :]).permute(1, 2, 0) + (kk - 1)
+    return rel[..., 0] * (ws + kk - 1) + rel[..., 1]
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        if drop != 0. or act_layer is not nn.GELU:
+            raise NotImplementedError('CFFM uses Mlp(drop=0, act=GELU) (cffm_head.py:81)')
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+
+class WindowAttention3d3(nn.Module):
+    """Holds the CFM parameters / buffers under the reference's names.  The forward lives in
+    ``cffm_attn_fwd`` (vss_cffm_amd/csrc/cfm_attn_kernels.h)."""
+
+    def __init__(self, dim, expand_size, window_size, focal_window, focal_level, num_heads, qkv_bias=True,
+                 qk_scale=None, attn_drop=0., proj_drop=0., pool_method='none', focal_l_clips=(1, 2, 3),
+                 focal_kernel_clips=(7, 5, 3)):
+        super().__init__()
+        ws = window_size[0] if isinstance(window_size, (tuple, list)) else window_size
+        if (dim, num_heads, ws, expand_size, focal_level, focal_window, pool_method) != (256, 8, 7, 3, 2, 5, 'fc') \
+                or list(focal_l_clips) != [1, 2, 3] or list(focal_kernel_clips) != [7, 5, 3] or qk_scale is not None \
+                or attn_drop != 0. or proj_drop != 0. or not qkv_bias:
+            raise NotImplementedError('libcffm_hip implements the configuration of cffm_head.py:74-95 only')
+        tn = lambda *s: nn.Parameter(nn.init.trunc_normal_(torch.zeros(*s), std=.02))
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(169, num_heads))       # zero-init (:253)
+        self.register_buffer('relative_position_index', _index_own())
+        self.relative_position_bias_table_to_neighbors = tn(1, num_heads, 49, 132)
+        e = expand_size
+        m = torch.ones(4, 7, 7)
+        m[0, :-e, :-e] = 0; m[1, :-e, e:] = 0; m[2, e:, :-e] = 0; m[3, e:, e:] = 0
+        self.register_buffer('valid_ind_rolled', m.flatten().nonzero().view(-1))
+        self.relative_position_bias_table_to_windows = nn.ParameterList([tn(num_heads, 121)])
+        self.register_buffer('relative_position_index_0', _index_to(5))
+        self.relative_position_bias_table_to_windows_clips = nn.ParameterList(
+            [tn(num_heads, (6 + kk) ** 2) for kk in focal_kernel_clips])
+        for i, kk in enumerate(focal_kernel_clips):
+            self.register_buffer('relative_position_index_clips_%d' % i, _index_to(kk))
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class CffmTransformerBlock3d3(nn.Module):
+    def __init__(self, dim, num_heads, window_size=7, expand_size=0, shift_size=0, mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 pool_method='none', focal_level=1, focal_window=1, focal_l_clips=(1, 2, 3), focal_kernel_clips=(7, 5, 3)):
+        super().__init__()
+        if shift_size != 0 or drop != 0. or drop_path != 0. or mlp_ratio != 4. or norm_layer is not nn.LayerNorm:
+            raise NotImplementedError('libcffm_hip implements the configuration of cffm_head.py:74-95 only')
+        self.dim, self.num_heads, self.window_size = dim, num_heads, window_size
+        self.focal_l_clips, self.focal_kernel_clips = list(focal_l_clips), list(focal_kernel_clips)
+        mk = lambda n: self._pool(n)
+        self.pool_layers = nn.ModuleList([mk(49)])
+        self.pool_layers_clips = nn.ModuleList([mk((window_size // s) ** 2) for s in focal_l_clips])
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention3d3(dim, expand_size=expand_size, window_size=(window_size, window_size),
+                                       focal_window=focal_window, focal_level=focal_level, num_heads=num_heads,
+                                       qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop,
+                                       pool_method=pool_method, focal_l_clips=focal_l_clips,
+                                       focal_kernel_clips=focal_kernel_clips)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.register_buffer('attn_mask', None)
+
+    @staticmethod
+    def _pool(n):
+        lin = nn.Linear(n, 1)                      # initialised to the mean (cffm_transformer.py:678-680)
+        lin.weight.data.fill_(1. / n)
+        lin.bias.data.fill_(0)
+        return lin
+
+    def param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k, _, _ in ops.BLOCK_PARAM_KEYS]
+
+
+class BasicLayer3d3(nn.Module):
+    """x [B, T=4, 256, H, W] -> same shape; only the last (target) frame changes."""
+
+    def __init__(self, dim, depth, num_heads, window_size, expand_size, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop=0., attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, pool_method='none', focal_level=1,
+                 focal_window=1, use_conv_embed=False, use_shift=False, use_pre_norm=False, downsample=None,
+                 use_checkpoint=False, focal_l_clips=(1, 2, 3), focal_kernel_clips=(7, 5, 3)):
+        super().__init__()
+        if use_shift or use_conv_embed or use_pre_norm or downsample is not None or use_checkpoint:
+            raise NotImplementedError('libcffm_hip implements the configuration of cffm_head.py:74-95 only')
+        self.dim, self.depth = dim, depth
+        self.blocks = nn.ModuleList([
+            CffmTransformerBlock3d3(dim=dim, num_heads=num_heads, window_size=window_size, shift_size=0,
+                                    expand_size=expand_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                    drop=drop, attn_drop=attn_drop,
+                                    drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                    norm_layer=norm_layer, pool_method=pool_method, focal_level=focal_level,
+                                    focal_window=focal_window, focal_l_clips=focal_l_clips,
+                                    focal_kernel_clips=focal_kernel_clips) for i in range(depth)])
+        self.downsample = None
+
+    def forward(self, x, batch_size=None, num_clips=None):
+        params = [p for blk in self.blocks for p in blk.param_list()]
+        return ops.cffm_layer(x, self.depth, params)
+
+
+# ------------------------------------------------------------------------------------------- CFFM++
+class WindowAttention_cluster(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if (dim, num_heads) != (256, 8) or qk_scale is not None or attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError('libcffm_hip implements the configuration of cffm_head.py:369-382 only')
+        # parameters the reference registers but never uses on this path (no gradient)
+        self.relative_position_bias_table = nn.Parameter(nn.init.trunc_normal_(torch.zeros(169, num_heads), std=.02))
+        self.register_buffer('relative_position_index', _index_own())
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.qkv_cluster = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj_cluster = nn.Linear(dim, dim)
+
+
+class SwinTransformerBlock_cluster(nn.Module):
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if shift_size != 0 or drop != 0. or drop_path != 0. or mlp_ratio != 4.:
+            raise NotImplementedError('only the shift-free depth-1 block of cffm_head.py:369-382 is implemented')
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention_cluster(dim, (window_size, window_size), num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.H = self.W = None
+
+    def forward(self, x, mask_matrix, cluster_centers):
+        assert x.shape[1] == self.H * self.W, 'input feature has wrong size'
+        sd = dict(self.named_parameters())
+        return ops.gtc_block(x, cluster_centers, [sd[k] for k in ops.GTC_PARAM_KEYS])
+
+
+class BasicLayer_cluster(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0.,
+                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 disable_shift=True):
+        super().__init__()
+        if depth != 1 or downsample is not None or use_checkpoint:
+            raise NotImplementedError('CFFM++ uses BasicLayer_cluster(depth=1) (cffm_head.py:367-382)')
+        self.window_size, self.depth = window_size, depth
+        self.blocks = nn.ModuleList([SwinTransformerBlock_cluster(dim, num_heads, window_size, 0, mlp_ratio, qkv_bias,
+                                                                  qk_scale, drop, attn_drop, drop_path)])
+        self.downsample = None
+
+    def forward(self, x, H, W, cluster_centers):
+        for blk in self.blocks:
+            blk.H, blk.W = H, W
+            x = blk(x, None, cluster_centers)
+        return x, H, W, x, H, W          # the reference's 6-tuple (swin_transformer_2d.py:1148)
