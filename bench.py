@@ -47,8 +47,7 @@ def cpu_baseline(max_seconds=25.0):
     """The oracle (CPU restatement of the reference, kind "port") on the host cores: forward + backward of
     the same hot path on single clips of the same shape."""
     from oracle import cffm_oracle as O, recipe as R
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     st = {k: v.requires_grad_(True) for k, v in R.layer_state(DEPTH, seed=0).items()}
     x = R.synth_input('x', (1, T, 256, GRID, GRID), seed=1).requires_grad_(True)
 
@@ -56,14 +55,26 @@ def cpu_baseline(max_seconds=25.0):
         y = O.layer_forward(x, st, DEPTH)
         y[:, -1].square().mean().backward()
 
-    one()  # warm-up
+    # torch's intra-op pool does not scale to every hardware thread on these small tensors (256 threads is
+    # ~100x slower than 16 on a 2x64-core host), so pick the fastest of a few pool sizes and report it.
+    best = None
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(n)
+        one()
+        t = time.time()
+        one()
+        t = time.time() - t
+        if best is None or t < best[1]:
+            best = (n, t)
+    cores = best[0]
+    torch.set_num_threads(cores)
     t0, n = time.time(), 0
     while n < 3 or (time.time() - t0 < max_seconds and n < 12):
         one()
         n += 1
     dt = (time.time() - t0) / n
     return {'value': round(1.0 / dt, 4), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d x (1 clip [1,4,256,60,60], depth 2, fwd+bwd) after 1 warm-up, torch %d threads' % (n, cores),
+            'sample': '%d x (1 clip [1,4,256,60,60], depth 2, fwd+bwd), torch intra-op threads = %d (fastest of 8/16/32/64 on a %d-thread host)' % (n, cores, ncpu),
             'ms_per_clip': round(dt * 1e3, 1)}
 
 
