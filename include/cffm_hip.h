@@ -105,12 +105,15 @@ int cffm_colsum(const float* a, long rows, int cols, float* out /* overwritten *
 int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
                      const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,
                      long nrows, void* stream);
-/* dx1 = (dres or 0) + LNbwd(dz2); dgamma/dbeta are accumulated (zeroed first when zero_grads != 0) */
+/* dx1 = (dres or 0) + LNbwd(dz2); dgamma/dbeta are overwritten (zero_grads != 0) or accumulated into; the column
+ * sums of dres and of dx1 (the bias gradients of the Linear layers on either side) come for free: pass NULL to skip */
 int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, const float* gamma, const float* dz2,
                          const float* dres /* may be NULL */, float* dx1, float* dgamma, float* dbeta, long nrows,
-                         int zero_grads, void* stream);
+                         int zero_grads, float* dres_colsum /* [256] or NULL */, float* dx1_colsum /* [256] or NULL */,
+                         void* stream);
 int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, int cols, void* stream);
-int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact_inout, long rows, int cols, void* stream);
+int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact_inout, long rows, int cols /* 1024 */,
+                  float* db1 /* [1024] column sums of the result, or NULL */, void* stream);
 int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float* out, long rows, void* stream);
 
 /* ---- CFFM++ global temporal context (WindowAttention_cluster, pvt/swin_transformer_2d.py:208-262) ---- */

@@ -59,10 +59,10 @@ SIGNATURES = {
     'cffm_linear_bwd_weight': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_colsum': (ci, [vp, cl, ci, vp, vp]),
     'cffm_residual_ln': (ci, [vp, cl, ci, vp, vp, vp, vp, vp, vp, vp, vp, cl, vp]),
-    'cffm_ln_bwd_residual': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp]),
+    'cffm_ln_bwd_residual': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp, vp, vp]),
     'cffm_layernorm_fwd': (ci, [vp, vp, vp, vp, vp, vp, cl, vp]),
     'cffm_bias_gelu': (ci, [vp, vp, vp, cl, ci, vp]),
-    'cffm_gelu_bwd': (ci, [vp, vp, vp, cl, ci, vp]),
+    'cffm_gelu_bwd': (ci, [vp, vp, vp, cl, ci, vp, vp]),
     'cffm_residual_out': (ci, [vp, vp, vp, vp, cl, vp]),
     'cffm_block_forward': (ci, [GP, BP, vp, cl, vp, cl, vp, vp, vp, vp, vp]),
     'cffm_block_backward': (ci, [GP, BP, BP, vp, cl, vp, cl, vp, vp, vp, vp, vp, cl, ci, vp, cl, vp, vp]),

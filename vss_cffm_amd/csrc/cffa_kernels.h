@@ -75,27 +75,27 @@ __global__ void __launch_bounds__(256) k_pool_matrix(PoolW pw, float* __restrict
     }
 }
 
-// dW_pool[grp][k] = sum_{g in grp, i} dM[g][i] * dM[g][i]/dw
-__global__ void __launch_bounds__(128) k_pool_matrix_bwd(const float* __restrict__ dM, PoolWG gw) {
-    const int t = threadIdx.x;
+// dW_pool[grp][k] = sum_{g in grp, i} dM[g][i] * dM[g][i]/dw.  One wave per weight (111 weights): lanes over
+// the 49 pixels, loop over the group's cells, wave reduction.
+__global__ void __launch_bounds__(64) k_pool_matrix_bwd(const float* __restrict__ dM, PoolWG gw) {
+    const int t = blockIdx.x, i = threadIdx.x;
     int grp, k;
     if (t < 49) { grp = 0; k = t; }
     else if (t < 98) { grp = 1; k = t - 49; }
     else if (t < 107) { grp = 2; k = t - 98; }
-    else if (t < 111) { grp = 3; k = t - 107; }
-    else return;
+    else { grp = 3; k = t - 107; }
     float acc = 0.f;
     if (grp < 2) {
-        acc = dM[grp * CFFM_WA + k];
-    } else {
+        if (i == k) acc = dM[grp * CFFM_WA + k];
+    } else if (i < CFFM_WA) {
         const int wsg = grp == 2 ? 3 : 2, ncell = grp == 2 ? 2 : 3, g0 = grp == 2 ? 2 : 6;
         const int a = k / wsg, b = k % wsg;
         for (int u = 0; u < ncell; ++u)
             for (int v = 0; v < ncell; ++v)
-                for (int i = 0; i < CFFM_WA; ++i)
-                    acc += dM[(g0 + u * ncell + v) * CFFM_WA + i] * bil_tap(wsg * u + a, i / 7) * bil_tap(wsg * v + b, i % 7);
+                acc += dM[(g0 + u * ncell + v) * CFFM_WA + i] * bil_tap(wsg * u + a, i / 7) * bil_tap(wsg * v + b, i % 7);
     }
-    gw.w[grp][k] = acc;
+    acc = wave_sum(acc);
+    if (i == 0) gw.w[grp][k] = acc;
 }
 
 // --------------------------------------------------------------------------- geometry helpers
@@ -184,9 +184,11 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
 }
 
 // --------------------------------------------------------------------------- LN1 + pad + pool (backward)
-// Inputs: dzall (gradient of every token row: target tokens + pooled cells).  Outputs: dx for the
-// frame (NHWC; `accum` adds to what is there), dgamma/dbeta (atomics), dM [15,49] (atomics),
-// dpool_bias (atomics).
+// Inputs: dzall (gradient of every token row: target tokens + pooled cells), dres (residual-path gradient
+// of the target frame, may be NULL).  Outputs: dx of the frame (NHWC; `accum_ref` adds to what is there) and
+// one partial record per workgroup, part[blk][LNP_REC] = dgamma[256] | dbeta[256] | dM[15*49] | dpool_bias[4]
+// (zeros outside this frame's cells); k_reduce_partials sums the records -- no contended atomics.
+#define LNP_REC (2 * CFFM_C + CFFM_NCELL * CFFM_WA + 4)
 __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
                                                       const float* __restrict__ x_tgt, long tgt_bs,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -194,18 +196,18 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
                                                       const float* __restrict__ rstd_in, const float* __restrict__ dzall,
                                                       const float* __restrict__ dres,
                                                       float* __restrict__ dx_ref, long dref_bs, int accum_ref,
-                                                      float* __restrict__ dx_tgt, long dtgt_bs,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      float* __restrict__ dM, PoolBG dpb) {
+                                                      float* __restrict__ dx_tgt, long dtgt_bs, float* __restrict__ part) {
     __shared__ float sM[9 * CFFM_WA];
     __shared__ float sdP[9][CFFM_C];
+    __shared__ float sdM[9 * CFFM_WA];
     __shared__ float red[4][2][CFFM_C];
+    __shared__ float sbs[4];
     const int w = blockIdx.x, frame = blockIdx.y, b = blockIdx.z;
     const int wy = w / G.gx, wx = w % G.gx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int g0, ncell;
     frame_cells(frame, g0, ncell);
-    for (int e = threadIdx.x; e < ncell * CFFM_WA; e += 256) sM[e] = M[g0 * CFFM_WA + e];
+    for (int e = threadIdx.x; e < ncell * CFFM_WA; e += 256) { sM[e] = M[g0 * CFFM_WA + e]; sdM[e] = 0.f; }
     float bsum = 0.f;
     for (int c = 0; c < ncell; ++c) {
         const float v = dzall[((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + threadIdx.x];
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
         bsum += v;
     }
     bsum = wave_sum(bsum);
-    if (lane == 0) atomicAdd(dpb.b[frame_group(frame)], bsum);
+    if (lane == 0) sbs[wave] = bsum;
     __syncthreads();
     const float* xf = (frame == 3) ? x_tgt + (long)b * tgt_bs : x_ref + (long)b * ref_bs + (long)frame * G.HW * CFFM_C;
     float* dxf = (frame == 3) ? dx_tgt + (long)b * dtgt_bs : dx_ref + (long)b * dref_bs + (long)frame * G.HW * CFFM_C;
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
             const f32x4 dp = *(const f32x4*)(&sdP[c][4 * lane]);
             dz += sM[c * CFFM_WA + i] * dp;
             const float dm = wave_sum(dp[0] * z[0] + dp[1] * z[1] + dp[2] * z[2] + dp[3] * z[3]);
-            if (lane == 0) atomicAdd(dM + (g0 + c) * CFFM_WA + i, dm);
+            if (lane == 0) sdM[c * CFFM_WA + i] = dm;  // pixel i belongs to exactly one wave: no conflict
         }
         ag += dz * xh;
         ab += dz;
@@ -251,7 +253,30 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
     *(f32x4*)(&red[wave][0][4 * lane]) = ag;
     *(f32x4*)(&red[wave][1][4 * lane]) = ab;
     __syncthreads();
+    float* rec = part + ((long)(b * 4 + frame) * G.nW + w) * LNP_REC;
     const int ch = threadIdx.x;
-    atomicAdd(dgamma + ch, red[0][0][ch] + red[1][0][ch] + red[2][0][ch] + red[3][0][ch]);
-    atomicAdd(dbeta + ch, red[0][1][ch] + red[1][1][ch] + red[2][1][ch] + red[3][1][ch]);
+    rec[ch] = red[0][0][ch] + red[1][0][ch] + red[2][0][ch] + red[3][0][ch];
+    rec[CFFM_C + ch] = red[0][1][ch] + red[1][1][ch] + red[2][1][ch] + red[3][1][ch];
+    for (int e = threadIdx.x; e < CFFM_NCELL * CFFM_WA + 4; e += 256) {
+        float v = 0.f;
+        if (e < CFFM_NCELL * CFFM_WA) {
+            if (e >= g0 * CFFM_WA && e < (g0 + ncell) * CFFM_WA) v = sdM[e - g0 * CFFM_WA];
+        } else if (e - CFFM_NCELL * CFFM_WA == frame_group(frame)) {
+            v = sbs[0] + sbs[1] + sbs[2] + sbs[3];
+        }
+        rec[2 * CFFM_C + e] = v;
+    }
+}
+
+// last stage of the ln_pool_bwd reduction: tmp[nsl][LNP_REC] -> dgamma, dbeta, dM and the 4 pool-bias gradients
+__global__ void __launch_bounds__(256) k_lnp_finish(const float* __restrict__ tmp, int nsl, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ dM, PoolBG dpb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= LNP_REC) return;
+    float s = 0.f;
+    for (int b = 0; b < nsl; ++b) s += tmp[(long)b * LNP_REC + c];
+    if (c < CFFM_C) dgamma[c] = s;
+    else if (c < 2 * CFFM_C) dbeta[c - CFFM_C] = s;
+    else if (c < 2 * CFFM_C + CFFM_NCELL * CFFM_WA) dM[c - 2 * CFFM_C] = s;
+    else dpb.b[c - 2 * CFFM_C - CFFM_NCELL * CFFM_WA][0] = s;
 }

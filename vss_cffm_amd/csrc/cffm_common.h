@@ -120,6 +120,25 @@ __device__ __forceinline__ f16x8 cat_f16x4(f16x4 lo, f16x4 hi) {
     return r;
 }
 
+// ordering point between LDS writes and reads of *other lanes of the same wave* (wave-private LDS
+// scratch; LDS operations of one wave execute in order, this only pins the compiler / the emulator)
+__device__ __forceinline__ void wave_lds_sync() {
+#ifdef CFFM_EMU
+    emu::wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+__device__ __forceinline__ float fast_exp(float x) {
+#ifdef CFFM_EMU
+    return expf(x);
+#else
+    return __expf(x);
+#endif
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));

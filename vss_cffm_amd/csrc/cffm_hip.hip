@@ -167,6 +167,37 @@ static Scratch scratch_layout(const cffm_geom* g) {
 }
 long cffm_layer_scratch_floats(const cffm_geom* g) { return scratch_layout(g).total; }
 
+
+// ------------------------------------------------------------------------------------------- internal scratch
+// Small library-owned device buffer for the block-partial records of the two-stage reductions
+// (grows on demand; stream-ordered reuse, one stream at a time as the ABI's threading rule says).
+static float* g_scr = nullptr;
+static size_t g_scr_floats = 0;
+static float* lib_scratch(size_t nfloats) {
+    if (nfloats <= g_scr_floats) return g_scr;
+#ifdef CFFM_EMU
+    free(g_scr);
+    g_scr = (float*)malloc(nfloats * sizeof(float));
+#else
+    if (g_scr) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr); }
+    if (hipMalloc((void**)&g_scr, nfloats * sizeof(float)) != hipSuccess) g_scr = nullptr;
+#endif
+    g_scr_floats = g_scr ? nfloats : 0;
+    return g_scr;
+}
+#define RED_SLICES 32
+// out[width] (+)= sum over nblk records of `part` (record stride `stride`); tmp: RED_SLICES*width floats
+static int reduce_records(const float* part, int nblk, int width, int stride, float* out, int accumulate, float* tmp, hipStream_t st) {
+    const unsigned gx = (width + 255) / 256;
+    if (nblk <= 2 * RED_SLICES) {
+        CFFM_LAUNCH(k_reduce_partials, (gx, 1), (256), 0, st, part, nblk, width, stride, out, accumulate);
+    } else {
+        CFFM_LAUNCH(k_reduce_partials, (gx, RED_SLICES), (256), 0, st, part, nblk, width, stride, tmp, 0);
+        CFFM_LAUNCH(k_reduce_partials, (gx, 1), (256), 0, st, (const float*)tmp, RED_SLICES, width, width, out, accumulate);
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- stages
 int cffm_transpose(const float* src, float* dst, int batch, int rows, int cols, long src_bs, long dst_bs, void* stream) {
     PROF(ST_TRANSPOSE);
@@ -190,7 +221,7 @@ int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream)
     PROF(ST_POOLMAT);
     PoolWG gw;
     for (int i = 0; i < 4; ++i) gw.w[i] = dpool_w[i];
-    CFFM_LAUNCH(k_pool_matrix_bwd, (1), (128), 0, (hipStream_t)stream, dM, gw);
+    CFFM_LAUNCH(k_pool_matrix_bwd, (111), (64), 0, (hipStream_t)stream, dM, gw);
     CHECK_LAUNCH("pool_matrix_bwd");
     return 0;
 }
@@ -216,12 +247,22 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
     PROF(ST_LN_POOL_BWD);
     hipStream_t st = (hipStream_t)stream;
     PoolBG pb;
-    for (int i = 0; i < 4; ++i) { pb.b[i] = dpool_b[i]; hipMemsetAsync(dpool_b[i], 0, sizeof(float), st); }
-    hipMemsetAsync(dgamma, 0, CFFM_C * sizeof(float), st);
-    hipMemsetAsync(dbeta, 0, CFFM_C * sizeof(float), st);
-    hipMemsetAsync(dM, 0, CFFM_NCELL * CFFM_WA * sizeof(float), st);
+    for (int i = 0; i < 4; ++i) pb.b[i] = dpool_b[i];
+    const int nblk = g->nW * 4 * g->B;
+    float* part = lib_scratch((size_t)(nblk + RED_SLICES) * LNP_REC);
+    REQUIRE(part, "ln_pool_bwd: scratch allocation failed");
+    float* tmp = part + (size_t)nblk * LNP_REC;
     CFFM_LAUNCH(k_ln_pool_bwd, (g->nW, 4, g->B), (256), 0, st, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma, beta, M, mean, rstd,
-                dzall, dres, dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, dgamma, dbeta, dM, pb);
+                dzall, dres, dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, part);
+    int nsl = nblk < RED_SLICES ? 1 : RED_SLICES;
+    const float* last = part;
+    int nlast = nblk;
+    if (nblk > RED_SLICES) {
+        CFFM_LAUNCH(k_reduce_partials, ((LNP_REC + 255) / 256, nsl), (256), 0, st, (const float*)part, nblk, LNP_REC, LNP_REC, tmp, 0);
+        last = tmp;
+        nlast = nsl;
+    }
+    CFFM_LAUNCH(k_lnp_finish, ((LNP_REC + 255) / 256), (256), 0, st, last, nlast, dgamma, dbeta, dM, pb);
     CHECK_LAUNCH("ln_pool_bwd");
     return 0;
 }
@@ -239,14 +280,10 @@ int cffm_bias_assemble(const float* own, const float* ring, const float* const p
 
 int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* const dpool[4], void* stream) {
     PROF(ST_BIAS_SCT);
-    hipStream_t st = (hipStream_t)stream;
     BiasTablesG t;
     t.own = down; t.ring = dring;
-    static const int pool_n[4] = {8 * 121, 8 * 169, 8 * 121, 8 * 81};
-    hipMemsetAsync(down, 0, 169 * 8 * sizeof(float), st);
-    for (int i = 0; i < 4; ++i) { t.pool[i] = dpool[i]; hipMemsetAsync(dpool[i], 0, pool_n[i] * sizeof(float), st); }
-    const int n = CFFM_HEADS * CFFM_NKEY * CFFM_WA;
-    CFFM_LAUNCH(k_bias_scatter, ((n + 255) / 256), (256), 0, st, dbiasT, t);
+    for (int i = 0; i < 4; ++i) t.pool[i] = dpool[i];
+    CFFM_LAUNCH(k_bias_scatter, ((BIAS_SCATTER_THREADS + 255) / 256), (256), 0, (hipStream_t)stream, dbiasT, t);
     CHECK_LAUNCH("bias_scatter");
     return 0;
 }
@@ -301,10 +338,12 @@ int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
     PROF(ST_COLSUM);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(cols % 256 == 0, "colsum: cols must be a multiple of 256");
-    hipMemsetAsync(out, 0, cols * sizeof(float), st);
-    int slices = (int)((rows + 63) / 64);
-    if (slices > 128) slices = 128;
-    CFFM_LAUNCH(k_colsum, (cols / 256, slices), (256), 0, st, a, rows, cols, out);
+    int slices = (int)((rows + 31) / 32);
+    if (slices > 256) slices = 256;
+    float* part = lib_scratch((size_t)(slices + RED_SLICES) * cols);
+    REQUIRE(part, "colsum: scratch allocation failed");
+    CFFM_LAUNCH(k_colsum_partial, (cols / 256, slices), (256), 0, st, a, rows, cols, part);
+    reduce_records(part, slices, cols, cols, out, 0, part + (size_t)slices * cols, st);
     CHECK_LAUNCH("colsum");
     return 0;
 }
@@ -320,16 +359,20 @@ int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const floa
 }
 
 int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, const float* gamma, const float* dz2,
-                         const float* dres, float* dx1, float* dgamma, float* dbeta, long nrows, int zero_grads, void* stream) {
+                         const float* dres, float* dx1, float* dgamma, float* dbeta, long nrows, int zero_grads,
+                         float* dres_colsum, float* dx1_colsum, void* stream) {
     PROF(ST_LN_BWD);
     hipStream_t st = (hipStream_t)stream;
-    if (zero_grads) {
-        hipMemsetAsync(dgamma, 0, CFFM_C * sizeof(float), st);
-        hipMemsetAsync(dbeta, 0, CFFM_C * sizeof(float), st);
-    }
     const int rpb = 32;
-    CFFM_LAUNCH(k_ln_bwd_residual, ((unsigned)((nrows + rpb - 1) / rpb)), (256), 0, st, x1, mean, rstd, gamma, dz2, dres, dx1,
-                dgamma, dbeta, nrows, rpb);
+    const int nblk = (int)((nrows + rpb - 1) / rpb);
+    float* part = lib_scratch((size_t)(nblk + RED_SLICES) * 1024);
+    REQUIRE(part, "ln_bwd_residual: scratch allocation failed");
+    float* tmp = part + (size_t)nblk * 1024;
+    CFFM_LAUNCH(k_ln_bwd_residual, (nblk), (256), 0, st, x1, mean, rstd, gamma, dz2, dres, dx1, part, nrows, rpb);
+    reduce_records(part, nblk, CFFM_C, 1024, dgamma, !zero_grads, tmp, st);
+    reduce_records(part + CFFM_C, nblk, CFFM_C, 1024, dbeta, !zero_grads, tmp + RED_SLICES * CFFM_C, st);
+    if (dres_colsum) reduce_records(part + 2 * CFFM_C, nblk, CFFM_C, 1024, dres_colsum, 0, tmp + 2 * RED_SLICES * CFFM_C, st);
+    if (dx1_colsum) reduce_records(part + 3 * CFFM_C, nblk, CFFM_C, 1024, dx1_colsum, 0, tmp + 3 * RED_SLICES * CFFM_C, st);
     CHECK_LAUNCH("ln_bwd_residual");
     return 0;
 }
@@ -347,10 +390,19 @@ int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, in
     CHECK_LAUNCH("bias_gelu");
     return 0;
 }
-int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, int cols, void* stream) {
+int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, int cols, float* db1, void* stream) {
     PROF(ST_GELU_BWD);
-    const long n4 = rows * cols / 4;
-    CFFM_LAUNCH(k_gelu_bwd, (ew_grid(n4)), (256), 0, (hipStream_t)stream, hraw, b1, dact, n4, cols / 4);
+    hipStream_t st = (hipStream_t)stream;
+    REQUIRE(cols == CFFM_HID, "gelu_bwd: cols must be %d", CFFM_HID);
+    const int rpb = 16;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    float* part = nullptr;
+    if (db1) {
+        part = lib_scratch((size_t)(nblk + RED_SLICES) * CFFM_HID);
+        REQUIRE(part, "gelu_bwd: scratch allocation failed");
+    }
+    CFFM_LAUNCH(k_gelu_bwd, (nblk), (256), 0, st, hraw, b1, dact, part, rows, rpb);
+    if (db1) reduce_records(part, nblk, CFFM_HID, CFFM_HID, db1, 0, part + (size_t)nblk * CFFM_HID, st);
     CHECK_LAUNCH("gelu_bwd");
     return 0;
 }
@@ -437,18 +489,16 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     float* dM = scratch + S.dM;
     float* dbiasT = scratch + S.dbiasT;
     // x2 = x1 + act W2^T + b2
-    TRY(cffm_colsum(dout, NP, CFFM_C, gr->fc2_b, stream));
     TRY(cffm_linear_bwd_weight(dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID, stream));
     TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
     // act = gelu(hraw + b1); hraw = z2 W1^T
-    TRY(cffm_gelu_bwd(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, stream));
-    TRY(cffm_colsum(dact, NP, CFFM_HID, gr->fc1_b, stream));
+    TRY(cffm_gelu_bwd(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, stream));
     TRY(cffm_linear_bwd_weight(dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dact, p->fc1_w, dz2, NP, CFFM_HID, CFFM_C, stream));
     // z2 = LN2(x1); x1 also feeds the residual
-    TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1, stream));
+    TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1,
+                             gr->fc2_b /* = colsum(dout) */, gr->proj_b /* = colsum(dx1) */, stream));
     // x1 = xt + ao Wp^T + bp
-    TRY(cffm_colsum(dx1, NP, CFFM_C, gr->proj_b, stream));
     TRY(cffm_linear_bwd_weight(dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dx1, p->proj_w, dao, NP, CFFM_C, CFFM_C, stream));
     // attention

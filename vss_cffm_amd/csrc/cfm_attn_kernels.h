@@ -34,7 +34,7 @@
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads = 4 waves x 16 queries.
-__global__ void __launch_bounds__(256) k_cfm_attn_fwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
+__global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
                                                        const float* __restrict__ bias, float* __restrict__ ao,
                                                        float* __restrict__ lse_out) {
@@ -51,48 +51,73 @@ __global__ void __launch_bounds__(256) k_cfm_attn_fwd(Geo G, const float* __rest
     const float scale = 0.17677669529663687f;  // 32^-0.5 (cffm_transformer.py:248,528)
 
     // ---- stage: key validity, K rows, V transposed, Q rows (bias of the qkv Linear added here) ----
+    // Global loads are issued in three batches, each complete before anything waits on it: the key-table entries of
+    // this thread's 5 row pairs, then the 20 gathered K/V row segments + the Q segment, then (below) the wave's 19
+    // bias tiles -- the kernel pays the L2/HBM latency about three times instead of ~30 times.
+    const int qcol = 16 * wave + (lane & 15), g = lane >> 4;
+    const int ch = lane >> 3;
+    int src0[5], src1[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int pr = (it * 4 + wave) * 8 + (lane & 7);
+        const bool ok = pr < CFFM_NKEY_PAD / 2;
+        src0[it] = ok ? ksrc[2 * pr] : -1;
+        src1[it] = ok ? ksrc[2 * pr + 1] : -1;
+    }
+    const f32x4 bk = ld4(bqkv + 256 + h * CFFM_HD + 4 * ch), bv = ld4(bqkv + 512 + h * CFFM_HD + 4 * ch);
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 k0[5], k1[5], v0[5], v1[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        k0[it] = k1[it] = v0[it] = v1[it] = z4;
+        if (src0[it] >= 0) { k0[it] = ld4(base + (long)src0[it] * 768 + 256 + 4 * ch); v0[it] = ld4(base + (long)src0[it] * 768 + 512 + 4 * ch); }
+        if (src1[it] >= 0) { k1[it] = ld4(base + (long)src1[it] * 768 + 256 + 4 * ch); v1[it] = ld4(base + (long)src1[it] * 768 + 512 + 4 * ch); }
+    }
+    f32x4 qv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + 256 * u, i = it >> 3, c = it & 7;
+        qv[u] = z4;
+        if (i < CFFM_WA) qv[u] = ld4(base + (long)(w * CFFM_WA + i) * 768 + 4 * c) + ld4(bqkv + h * CFFM_HD + 4 * c);
+    }
     for (int n = tid; n < CFFM_NKEY_PAD; n += 256) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
     for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 256)
         Vt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
-    {
-        const int ch = lane >> 3;
-        const f32x4 bk = ld4(bqkv + 256 + h * CFFM_HD + 4 * ch), bv = ld4(bqkv + 512 + h * CFFM_HD + 4 * ch);
-        for (int it = 0; it < 5; ++it) {
-            const int pr = (it * 4 + wave) * 8 + (lane & 7);
-            if (pr < CFFM_NKEY_PAD / 2) {
-                const int n0 = 2 * pr, s0 = ksrc[n0], s1 = ksrc[n0 + 1];
-                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                f32x4 k0 = z, k1 = z, v0 = z, v1 = z;
-                if (s0 >= 0) { k0 = ld4(base + (long)s0 * 768 + 256 + 4 * ch) + bk; v0 = ld4(base + (long)s0 * 768 + 512 + 4 * ch) + bv; }
-                if (s1 >= 0) { k1 = ld4(base + (long)s1 * 768 + 256 + 4 * ch) + bk; v1 = ld4(base + (long)s1 * 768 + 512 + 4 * ch) + bv; }
-                *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0);
-                *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1);
-                for (int e = 0; e < 4; ++e) {
-                    f16x2 pv; pv[0] = (f16)v0[e]; pv[1] = (f16)v1[e];
-                    *(f16x2*)(Vt + (4 * ch + e) * ATT_VT_STRIDE + n0) = pv;
-                }
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int pr = (it * 4 + wave) * 8 + (lane & 7);
+        if (pr < CFFM_NKEY_PAD / 2) {
+            const int n0 = 2 * pr;
+            if (src0[it] >= 0) { k0[it] += bk; v0[it] += bv; }
+            if (src1[it] >= 0) { k1[it] += bk; v1[it] += bv; }
+            *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0[it]);
+            *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1[it]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f16x2 pv; pv[0] = (f16)v0[it][e]; pv[1] = (f16)v1[it][e];
+                *(f16x2*)(Vt + (4 * ch + e) * ATT_VT_STRIDE + n0) = pv;
             }
         }
-        for (int it = tid; it < 64 * 8; it += 256) {
-            const int i = it >> 3, c = it & 7;
-            f32x4 q = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (i < CFFM_WA) q = (ld4(base + (long)(w * CFFM_WA + i) * 768 + 4 * c) + ld4(bqkv + h * CFFM_HD + 4 * c)) * scale;
-            *(f16x4*)(Qs + i * ATT_KS_STRIDE + 4 * c) = to_f16x4(q);
-        }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + 256 * u, i = it >> 3, c = it & 7;
+        *(f16x4*)(Qs + i * ATT_KS_STRIDE + 4 * c) = to_f16x4(qv[u] * scale);
+    }
+    // the wave's 19 bias tiles (L2-resident table) fly across the barrier and land in the MFMA C operands
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
+    f32x4 s[19];
+#pragma unroll
+    for (int t = 0; t < 19; ++t) s[t] = ld4(brow + 16 * t);
     __syncthreads();
 
     // ---- S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column -----------------
-    const int qcol = 16 * wave + (lane & 15), g = lane >> 4;
     const f16x8 qfrag = *(const f16x8*)(Qs + qcol * ATT_KS_STRIDE + 8 * g);
-    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
-    f32x4 s[19];
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 19; ++t) {
         const f16x8 kf = *(const f16x8*)(Ks + (16 * t + (lane & 15)) * ATT_KS_STRIDE + 8 * g);
-        f32x4 acc = mfma16x16x32_f16(kf, qfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
-        acc += ld4(brow + 16 * t) + *(const f32x4*)(vflag + 16 * t + 4 * g);
+        const f32x4 acc = mfma16x16x32_f16(kf, qfrag, s[t] + *(const f32x4*)(vflag + 16 * t + 4 * g));   // C-in = bias + mask
         s[t] = acc;
         m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
     }
@@ -102,7 +127,7 @@ __global__ void __launch_bounds__(256) k_cfm_attn_fwd(Geo G, const float* __rest
 #pragma unroll
     for (int t = 0; t < 19; ++t) {
         f32x4 p;
-        p[0] = expf(s[t][0] - m); p[1] = expf(s[t][1] - m); p[2] = expf(s[t][2] - m); p[3] = expf(s[t][3] - m);
+        p[0] = fast_exp(s[t][0] - m); p[1] = fast_exp(s[t][1] - m); p[2] = fast_exp(s[t][2] - m); p[3] = fast_exp(s[t][3] - m);
         s[t] = p;
         l += (p[0] + p[1]) + (p[2] + p[3]);
     }
@@ -147,7 +172,8 @@ __global__ void __launch_bounds__(256) k_cfm_attn_fwd(Geo G, const float* __rest
 // gradients of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
 // =====================================================================================================
 #define ATT_BWD_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
-                     CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
+                     CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4 + 4 * 2 * 16 * ATT_T_STRIDE * 4)
+#define ATT_T_STRIDE 36  // floats per key row of the per-wave dK/dV transposition scratch
 
 __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
@@ -167,6 +193,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
     float* slse = vflag + CFFM_NKEY_PAD;
     float* sD = slse + 64;
     float* smax = sD + 64;
+    float* tscr = smax + 16;  // [4 key-owner waves][2][16 keys][ATT_T_STRIDE]
 
     const int h = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,7 +311,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                         const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});
                         sv += ld4(brow + 16 * t) + *(const f32x4*)(vflag + 16 * t + 4 * g);
                         f32x4 ds;
-                        for (int r = 0; r < 4; ++r) ds[r] = expf(sv[r] - lq) * (dp[r] - Dq);
+                        for (int r = 0; r < 4; ++r) ds[r] = fast_exp(sv[r] - lq) * (dp[r] - Dq);
                         dB[t < 19 ? t : 0] += ds * isc;
                         dsh[u] = to_f16x4(ds);
                     } else {
@@ -322,7 +349,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                     sv += ld4(btrow + 16 * mt) + vf;
                     const f32x4 lq = *(const f32x4*)(slse + 16 * mt + 4 * g), Dq = *(const f32x4*)(sD + 16 * mt + 4 * g);
                     f32x4 p, ds;
-                    for (int r = 0; r < 4; ++r) { p[r] = expf(sv[r] - lq[r]); ds[r] = p[r] * (dp[r] - Dq[r]); }
+                    for (int r = 0; r < 4; ++r) { p[r] = fast_exp(sv[r] - lq[r]); ds[r] = p[r] * (dp[r] - Dq[r]); }
                     ph[mt] = to_f16x4(p);
                     dsh[mt] = to_f16x4(ds);
                 }
@@ -340,14 +367,26 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                         dk[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)qrow, *(const f16x4*)(qrow + 16)), sf, dk[dt]);
                     }
                 }
-                const int src = ksrc[key];
-                if (src >= 0) {
-                    float* drow = dqkv + ((long)b * G.RC + src) * 768 + h * CFFM_HD + 4 * g;
-                    for (int dt = 0; dt < 2; ++dt)
-                        for (int r = 0; r < 4; ++r) {
-                            atomicAdd(drow + 256 + 16 * dt + r, dk[dt][r] * isc);
-                            atomicAdd(drow + 512 + 16 * dt + r, dv[dt][r] * isc);
-                        }
+                // dK^T/dV^T tiles sit as [d][key] across the wave; go through a wave-private LDS tile so each atomic
+                // instruction adds two whole 128-B (token, head) rows instead of 64 scattered dwords.
+                float* Tk = tscr + (wave - 4) * 2 * 16 * ATT_T_STRIDE;
+                float* Tv = Tk + 16 * ATT_T_STRIDE;
+                wave_lds_sync();
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    *(f32x4*)(Tk + l15 * ATT_T_STRIDE + 16 * dt + 4 * g) = dk[dt] * isc;
+                    *(f32x4*)(Tv + l15 * ATT_T_STRIDE + 16 * dt + 4 * g) = dv[dt] * isc;
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int pss = 0; pss < 8; ++pss) {
+                    const int kl = 2 * pss + (lane >> 5), d = lane & 31;
+                    const int src = ksrc[16 * t + kl];
+                    if (src >= 0) {
+                        float* drow = dqkv + ((long)b * G.RC + src) * 768 + h * CFFM_HD + d;
+                        atomicAdd(drow + 256, Tk[kl * ATT_T_STRIDE + d]);
+                        atomicAdd(drow + 512, Tv[kl * ATT_T_STRIDE + d]);
+                    }
                 }
             }
         }

@@ -59,17 +59,46 @@ __global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __re
     if (biasT) biasT[((long)h * CFFM_NKEY_PAD + n) * CFFM_NQ_PAD + q] = v;
 }
 
-// dbiasT [8][304][64] (key-major, as the attention backward accumulates it) -> the six tables
+// dbiasT [8][304][64] (key-major, as the attention backward accumulates it) -> the six tables.
+// Gather form (no atomics): one thread per table entry sums the <= 49 (query, key) pairs that index it.
 __global__ void __launch_bounds__(256) k_bias_scatter(const float* __restrict__ dbiasT, BiasTablesG g) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= CFFM_HEADS * CFFM_NKEY * CFFM_WA) return;
-    const int q = e % CFFM_WA, n = (e / CFFM_WA) % CFFM_NKEY, h = e / (CFFM_WA * CFFM_NKEY);
-    const float v = dbiasT[((long)h * CFFM_NKEY_PAD + n) * CFFM_NQ_PAD + q];
-    int off;
-    const int id = bias_locate(h, q, n, off);
-    if (id == 1) g.ring[off] = v;  // the dense ring table is one-to-one
-    else atomicAdd((id == 0 ? g.own : g.pool[id - 2]) + off, v);
+    const int n_own = 169 * CFFM_HEADS, n_ring = CFFM_HEADS * 49 * 132;
+    if (e < n_ring) {  // dense ring table [1,8,49,132]: one-to-one
+        const int n = e % 132, q = (e / 132) % 49, h = e / (132 * 49);
+        g.ring[e] = dbiasT[((long)h * CFFM_NKEY_PAD + 49 + n) * CFFM_NQ_PAD + q];
+        return;
+    }
+    int r = e - n_ring;
+    if (r < n_own) {  // own table [169,8]: idx = (qi-ki+6)*13 + (qj-kj+6)
+        const int h = r % CFFM_HEADS, idx = r / CFFM_HEADS, di = idx / 13 - 6, dj = idx % 13 - 6;
+        float acc = 0.f;
+        for (int q = 0; q < 49; ++q) {
+            const int ki = q / 7 - di, kj = q % 7 - dj;
+            if (ki >= 0 && ki < 7 && kj >= 0 && kj < 7) acc += dbiasT[((long)h * CFFM_NKEY_PAD + ki * 7 + kj) * CFFM_NQ_PAD + q];
+        }
+        g.own[r] = acc;
+        return;
+    }
+    r -= n_own;
+    const int kks[4] = {5, 7, 5, 3}, bases[4] = {181, 206, 255, 280};
+    for (int t = 0; t < 4; ++t) {
+        const int kk = kks[t], side = 6 + kk, n_t = CFFM_HEADS * side * side;
+        if (r < n_t) {  // pooled tables [8, side*side]: idx = (qi-a+kk-1)*side + (qj-b+kk-1)
+            const int h = r / (side * side), idx = r % (side * side), di = idx / side - (kk - 1), dj = idx % side - (kk - 1);
+            float acc = 0.f;
+            for (int q = 0; q < 49; ++q) {
+                const int a = q / 7 - di, bb = q % 7 - dj;
+                if (a >= 0 && a < kk && bb >= 0 && bb < kk)
+                    acc += dbiasT[((long)h * CFFM_NKEY_PAD + bases[t] + a * kk + bb) * CFFM_NQ_PAD + q];
+            }
+            g.pool[t][r] = acc;
+            return;
+        }
+        r -= n_t;
+    }
 }
+#define BIAS_SCATTER_THREADS (CFFM_HEADS * 49 * 132 + 169 * CFFM_HEADS + CFFM_HEADS * (121 + 169 + 121 + 81))
 
 // --------------------------------------------------------------------------- x1 = xt + (yraw + bproj); z2 = LN2(x1)
 __global__ void __launch_bounds__(256) k_residual_ln(const float* __restrict__ xt, long xt_bs, int rows_per_batch,
@@ -93,16 +122,19 @@ __global__ void __launch_bounds__(256) k_residual_ln(const float* __restrict__ x
     if (lane == 0) { mean_out[row] = mu; rstd_out[row] = rs; }
 }
 
-// backward of z2 = LN(x1): dx1 = dres + LNbwd(dz2); also dgamma/dbeta partial sums (atomics).
+// backward of z2 = LN(x1): dx1 = dres + LNbwd(dz2).  Every workgroup writes one partial record
+// part[blk][1024] = dgamma | dbeta | colsum(dres) | colsum(dx1) (the last two are the fc2 / proj bias
+// gradients, folded in because this kernel streams those rows anyway); k_reduce_partials sums them.
 __global__ void __launch_bounds__(256) k_ln_bwd_residual(const float* __restrict__ x1, const float* __restrict__ mean_in,
                                                           const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                           const float* __restrict__ dz2, const float* __restrict__ dres,
-                                                          float* __restrict__ dx1, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, long nrows, int rows_per_block) {
-    __shared__ float red[4][2][CFFM_C];
+                                                          float* __restrict__ dx1, float* __restrict__ part, long nrows,
+                                                          int rows_per_block) {
+    __shared__ float red[4][4][CFFM_C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const f32x4 gm = *(const f32x4*)(gamma + 4 * lane);
-    f32x4 ag = (f32x4){0.f, 0.f, 0.f, 0.f}, ab = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ag = z4, ab = z4, ar = z4, ax = z4;
     const long r0 = (long)blockIdx.x * rows_per_block;
     for (long row = r0 + wave; row < r0 + rows_per_block && row < nrows; row += 4) {
         const f32x4 xv = *(const f32x4*)(x1 + row * CFFM_C + 4 * lane);
@@ -115,15 +147,42 @@ __global__ void __launch_bounds__(256) k_ln_bwd_residual(const float* __restrict
         const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
         const float m2 = wave_sum(gz[0] * xh[0] + gz[1] * xh[1] + gz[2] * xh[2] + gz[3] * xh[3]) * (1.f / CFFM_C);
         f32x4 dxv = (gz - m1 - xh * m2) * rs;
-        if (dres) dxv += *(const f32x4*)(dres + row * CFFM_C + 4 * lane);
+        if (dres) {
+            const f32x4 dr = *(const f32x4*)(dres + row * CFFM_C + 4 * lane);
+            ar += dr;
+            dxv += dr;
+        }
+        ax += dxv;
         *(f32x4*)(dx1 + row * CFFM_C + 4 * lane) = dxv;
     }
     *(f32x4*)(&red[wave][0][4 * lane]) = ag;
     *(f32x4*)(&red[wave][1][4 * lane]) = ab;
+    *(f32x4*)(&red[wave][2][4 * lane]) = ar;
+    *(f32x4*)(&red[wave][3][4 * lane]) = ax;
     __syncthreads();
     const int ch = threadIdx.x;
-    atomicAdd(dgamma + ch, red[0][0][ch] + red[1][0][ch] + red[2][0][ch] + red[3][0][ch]);
-    atomicAdd(dbeta + ch, red[0][1][ch] + red[1][1][ch] + red[2][1][ch] + red[3][1][ch]);
+    for (int k = 0; k < 4; ++k)
+        part[(long)blockIdx.x * 1024 + k * CFFM_C + ch] = red[0][k][ch] + red[1][k][ch] + red[2][k][ch] + red[3][k][ch];
+}
+
+// out[y][c] (+)= sum over the y-th slice of blocks of part[b][c]   (later stages of every block-partial
+// reduction; deterministic).  grid (ceil(width/256), nslices); `accumulate` only with one slice.
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, int nblk, int width, int stride,
+                                                          float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= width) return;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+        s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 1) * stride + c];
+        s2 += part[(long)(b + 2) * stride + c]; s3 += part[(long)(b + 3) * stride + c];
+    }
+    for (; b < b1; ++b) s0 += part[(long)b * stride + c];
+    const float sum = (s0 + s1) + (s2 + s3);
+    float* o = out + (long)blockIdx.y * width + c;
+    *o = accumulate ? *o + sum : sum;
 }
 
 // --------------------------------------------------------------------------- act = gelu(hraw + b1)
@@ -136,15 +195,23 @@ __global__ void __launch_bounds__(256) k_bias_gelu(const float* __restrict__ hra
         ((f32x4*)act)[e] = o;
     }
 }
-// dhraw = dact * gelu'(hraw + b1)   (in place on dact)
+// dhraw = dact * gelu'(hraw + b1) (in place on dact); thread t owns columns 4t..4t+3 of the 1024, a workgroup
+// owns `rows_per_block` rows and writes colsum partials part[blk][1024] (fc1 bias gradient) when part != NULL.
 __global__ void __launch_bounds__(256) k_gelu_bwd(const float* __restrict__ hraw, const float* __restrict__ b1,
-                                                   float* __restrict__ dact, long n4, int ncol4) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-        const f32x4 v = ((const f32x4*)hraw)[e] + ((const f32x4*)b1)[e % ncol4];
-        f32x4 d = ((f32x4*)dact)[e];
+                                                   float* __restrict__ dact, float* __restrict__ part, long nrows,
+                                                   int rows_per_block) {
+    const int t = threadIdx.x;
+    const f32x4 bb = ((const f32x4*)b1)[t];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    for (long row = r0; row < r0 + rows_per_block && row < nrows; ++row) {
+        const f32x4 v = ((const f32x4*)(hraw + row * CFFM_HID))[t] + bb;
+        f32x4 d = ((f32x4*)(dact + row * CFFM_HID))[t];
         d[0] *= gelu_erf_grad(v[0]); d[1] *= gelu_erf_grad(v[1]); d[2] *= gelu_erf_grad(v[2]); d[3] *= gelu_erf_grad(v[3]);
-        ((f32x4*)dact)[e] = d;
+        ((f32x4*)(dact + row * CFFM_HID))[t] = d;
+        acc += d;
     }
+    if (part) ((f32x4*)(part + (long)blockIdx.x * CFFM_HID))[t] = acc;
 }
 
 // --------------------------------------------------------------------------- out = x1 + (oraw + b2)
@@ -155,15 +222,17 @@ __global__ void __launch_bounds__(256) k_residual_out(const float* __restrict__ 
 }
 
 // --------------------------------------------------------------------------- column sums (Linear bias grads)
-// out[c] (+)= sum_r a[r][c];  grid (ncol/256, nslices); atomics across row slices (out pre-zeroed).
-__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ a, long nrows, int ncol, float* __restrict__ out) {
+// part[slice][c] = sum over the slice's rows of a[r][c]; grid (ncol/256, nslices); k_reduce_partials finishes.
+__global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict__ a, long nrows, int ncol, float* __restrict__ part) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const long per = (nrows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per, r1 = (r0 + per < nrows) ? r0 + per : nrows;
     if (c >= ncol) return;
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += a[r * ncol + c];
-    atomicAdd(out + c, s);
+    float s0 = 0.f, s1 = 0.f;
+    long r = r0;
+    for (; r + 1 < r1; r += 2) { s0 += a[r * ncol + c]; s1 += a[(r + 1) * ncol + c]; }
+    if (r < r1) s0 += a[r * ncol + c];
+    part[(long)blockIdx.y * ncol + c] = s0 + s1;
 }
 
 // a += b (f32x4)

@@ -203,18 +203,15 @@ class _GtcBlockFn(torch.autograd.Function):
                                                      n2b=n2b, w1=w1, b1=b1, w2=w2, b2=b2).items()}
         gqw = torch.zeros_like(qw)                 # rows 256.. (unused k,v thirds) keep a zero gradient
         gqb = torch.zeros_like(qb)
-        ck(lib.cffm_colsum(_ptr(dout), nt, c, _ptr(g['b2']), st))
         ck(lib.cffm_linear_bwd_weight(_ptr(dout), _ptr(act), _ptr(g['w2']), nt, c, 4 * c, st))
         dact = new(nt, 4 * c)
         ck(lib.cffm_linear_bwd_input(_ptr(dout), _ptr(w2), _ptr(dact), nt, c, 4 * c, st))
-        ck(lib.cffm_gelu_bwd(_ptr(hraw), _ptr(b1), _ptr(dact), nt, 4 * c, st))
-        ck(lib.cffm_colsum(_ptr(dact), nt, 4 * c, _ptr(g['b1']), st))
+        ck(lib.cffm_gelu_bwd(_ptr(hraw), _ptr(b1), _ptr(dact), nt, 4 * c, _ptr(g['b1']), st))
         ck(lib.cffm_linear_bwd_weight(_ptr(dact), _ptr(z2), _ptr(g['w1']), nt, 4 * c, c, st))
         dz2, dx1 = new(nt, c), new(nt, c)
         ck(lib.cffm_linear_bwd_input(_ptr(dact), _ptr(w1), _ptr(dz2), nt, 4 * c, c, st))
         ck(lib.cffm_ln_bwd_residual(_ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2w), _ptr(dz2), _ptr(dout), _ptr(dx1),
-                                    _ptr(g['n2w']), _ptr(g['n2b']), nt, 1, st))
-        ck(lib.cffm_colsum(_ptr(dx1), nt, c, _ptr(g['pb']), st))
+                                    _ptr(g['n2w']), _ptr(g['n2b']), nt, 1, _ptr(g['b2']), _ptr(g['pb']), st))
         ck(lib.cffm_linear_bwd_weight(_ptr(dx1), _ptr(ao), _ptr(g['pw']), nt, c, c, st))
         dao = new(nt, c)
         ck(lib.cffm_linear_bwd_input(_ptr(dx1), _ptr(pw), _ptr(dao), nt, c, c, st))
@@ -230,9 +227,9 @@ class _GtcBlockFn(torch.autograd.Function):
         ck(lib.cffm_linear_bwd_input(_ptr(dkv), _ptr(kvw), _ptr(dcn), nk, 2 * c, c, st))
         dx, dcenters = new(b, t, c), new(b, k, c)
         ck(lib.cffm_ln_bwd_residual(_ptr(x), _ptr(mean1), _ptr(rstd1), _ptr(n1w), _ptr(dz), _ptr(dx1), _ptr(dx),
-                                    _ptr(g['n1w']), _ptr(g['n1b']), nt, 1, st))
+                                    _ptr(g['n1w']), _ptr(g['n1b']), nt, 1, None, None, st))
         ck(lib.cffm_ln_bwd_residual(_ptr(centers), _ptr(cmean), _ptr(crstd), _ptr(n1w), _ptr(dcn), None, _ptr(dcenters),
-                                    _ptr(g['n1w']), _ptr(g['n1b']), nk, 0, st))     # same norm1 (:622): accumulate
+                                    _ptr(g['n1w']), _ptr(g['n1b']), nk, 0, None, None, st))   # same norm1 (:622): accumulate
         return (dx, dcenters, g['n1w'], g['n1b'], gqw, gqb, g['kvw'], g['kvb'], g['pw'], g['pb'], g['n2w'], g['n2b'],
                 g['w1'], g['b1'], g['w2'], g['b2'])
 
