@@ -1,0 +1,146 @@
+"""Drop-in boundary: registry names, constructor contract, state_dict keys, config loading,
+and the whole head against golden logits the reference head produced (hot path through the emulator on CPU)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe as R, ref_import as RI
+from tests import emu, helpers as H
+from vss_cffm_amd import head as Hd
+from vss_cffm_amd.config import Config
+from vss_cffm_amd.registry import HEADS, LOSSES, build_from_cfg, build_head
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B0, B1 = (32, 64, 160, 256), (64, 128, 320, 512)
+KINDS = ('CFFMHead_clips_resize1_8', 'CFFMHead_clips_resize1_8_gene_prototype',
+         'CFFMHead_clips_resize1_8_finetune_w_prototype3')
+
+
+def test_heads_registered_under_reference_names():
+    for k in KINDS:
+        assert k in HEADS
+    assert 'CrossEntropyLoss' in LOSSES
+    with pytest.raises(KeyError):
+        build_head(dict(type='NoSuchHead'))
+    with pytest.raises(KeyError):
+        build_from_cfg(dict(channels=1), HEADS)
+
+
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('size', ['B0', 'B1'])
+def test_state_dict_keys_match_reference(kind, size):
+    want = json.load(open(os.path.join(H.GOLDEN, 'head_state_dict_keys.json')))['%s/%s' % (kind, size)]
+    m = build_head(RI.head_cfg(kind=kind, in_channels=B0 if size == 'B0' else B1, depths=1 if size == 'B0' else 2))
+    got = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    assert got == want
+
+
+def test_own_configs_and_merge_semantics():
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'cffm_b0_64.py'))
+    dh = cfg.model.decode_head
+    assert dh.type == 'CFFMHead_clips_resize1_8' and dh.in_channels == [32, 64, 160, 256]
+    assert dh.decoder_params.depths == 1 and dh.num_classes == 124 and dh.norm_cfg.type == 'SyncBN'
+    pp = Config.fromfile(os.path.join(ROOT, 'configs', 'cffmpp_b1_480.py'))
+    assert pp.model.decode_head.type.endswith('prototype3') and pp.model.decode_head.in_channels == [64, 128, 320, 512]
+    assert pp.optimizer.lr == 2e-4 and 'betas' not in pp.optimizer and '_delete_' not in pp.optimizer
+    pp.merge_from_dict({'model.decode_head.num_classes': 19, 'data.samples_per_gpu': 1})
+    assert pp.model.decode_head.num_classes == 19 and pp.data.samples_per_gpu == 1 and pp.model.decode_head.channels == 128
+    assert pp.get('nope', 7) == 7
+    head = build_head(cfg.model.decode_head)
+    assert isinstance(head, Hd.CFFMHead_clips_resize1_8) and head.num_clips == 4 and head.align_corners is False
+
+
+@pytest.mark.skipif(not RI.available(), reason='/root/reference not present')
+def test_reference_local_configs_load_unchanged():
+    files = sorted(glob.glob(os.path.join(RI.REF_ROOT, 'local_configs', 'cffm', '*', '*.py')))
+    assert len(files) == 12
+    for f in files:
+        cfg = Config.fromfile(f)
+        dh = cfg.model.decode_head
+        assert dh.type in KINDS and dh.num_classes == 124 and dh.decoder_params.embed_dim == 256
+        assert cfg.model.backbone.type.startswith('mit_b') and cfg.data.samples_per_gpu >= 1
+        assert cfg.optimizer.type == 'AdamW' and '_delete_' not in cfg.optimizer
+        assert cfg.find_unused_parameters is True
+        head = build_head(dh)                     # the registry accepts the config's head dict as is
+        assert head.decoder_focal.depth == dh.decoder_params.depths
+
+
+def _my_head(kind, device, seed):
+    m = build_head(RI.head_cfg(kind=kind))
+    res = m.load_state_dict(R.synth_state(m, seed=seed), strict=False)
+    assert not res.unexpected_keys
+    for d in (m.dropout, getattr(m, 'dropout3', None)):
+        if d is not None:
+            d.p = 0.0
+    if device.type == 'cpu':
+        Hd.revert_sync_batchnorm(m)               # as the reference's CPU tests do
+    return m.to(device)
+
+
+def run_head_golden(device):
+    from tests.golden.make_golden_head import feature_maps, labels
+    g = H.load_golden('head_b0_64')
+    tol = 1e-3                                     # the north-star contract on logits
+    head = _my_head('CFFMHead_clips_resize1_8', device, 30)
+    feats = [f.to(device) for f in feature_maps(1, 4, 64)]
+    head.eval()
+    with torch.no_grad():
+        assert H.rel_err(head(feats, 1, 4).cpu(), g['eval_logits']) < tol
+        t2 = head([f.to(device) for f in feature_maps(1, 2, 64, seed=33)], 1, 2)
+        assert H.rel_err(t2.cpu(), g['eval_t2_logits']) < 1e-5          # short-circuit: no hot path involved
+    head.train()
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    out = head(fg, 1, 4)
+    assert H.rel_err(out.detach().cpu(), g['train_logits']) < tol
+    loss = head.losses(out, labels(1, 4, 64).to(device))
+    assert abs(float(loss['loss_seg']) - float(g['loss_seg'])) < 1e-3 * float(g['loss_seg'])
+    assert abs(float(loss['acc_seg']) - float(g['acc_seg'])) < 1e-3
+    loss['loss_seg'].backward()
+    for i, f in enumerate(fg):
+        assert H.rel_err(f.grad.cpu(), g['dfeat%d' % i]) < 5e-3, i
+    assert head.conv_seg.weight.grad is None      # never used: why the reference needs find_unused_parameters
+    # CFFM++
+    import tempfile
+    pp = _my_head('CFFMHead_clips_resize1_8_finetune_w_prototype3', device, 34)
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, 'vid0'))
+        torch.save(R.synth_input('centers', (1, 8, 256), seed=35, scale=1.0), os.path.join(tmp, 'vid0', 'centers.pt'))
+        pp.save_path = tmp + '/'
+        metas = [{'filename': tmp + '/data/vid0/origin/0001.jpg'}]
+        pp.eval()
+        with torch.no_grad():
+            assert H.rel_err(pp(feats, 1, 4, None, metas).cpu(), g['pp_eval_logits']) < tol
+        pp.train()
+        out = pp(feats, 1, 4, None, metas)
+        assert H.rel_err(out.detach().cpu(), g['pp_train_logits']) < tol
+        out.sum().backward()
+        trained = {n.split('.')[0] for n, p in pp.named_parameters() if p.grad is not None}
+        assert trained == {'decoder_swin', 'linear_pred3'}               # SURVEY.md 3.5 [probe]
+
+
+def test_head_against_reference_golden_emulated():
+    with emu.active():
+        run_head_golden(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_head_against_reference_golden_gpu():
+    run_head_golden(torch.device('cuda:0'))
+
+
+def test_cpu_plumbing_config1_needs_no_gpu():
+    """BASELINE config 1: B0 head, 1 clip of 2 x 64x64 frames, CPU forward -- eval short-circuits before CFFM
+    (cffm_head.py:127-129), so it runs without the HIP library; T=4 on CPU raises instead of falling back."""
+    from tests.golden.make_golden_head import feature_maps
+    from vss_cffm_amd import _lib
+    head = Hd.revert_sync_batchnorm(build_head(RI.head_cfg())).eval()
+    with torch.no_grad():
+        y = head(feature_maps(1, 2, 64, seed=33), 1, 2)
+        assert y.shape == (1, 124, 16, 16)
+        if not torch.cuda.is_available():
+            with pytest.raises(_lib.CffmError):
+                head(feature_maps(1, 4, 64), 1, 4)

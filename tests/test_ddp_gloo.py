@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: two processes, gloo backend, the module wrapped in DistributedDataParallel exactly as
+bench.py does on RCCL; kernels run through the emulator library.  Checks that the custom autograd function is
+DDP-safe (every parameter gets its gradient in one backward, buckets all-reduce) and that the averaged
+gradients equal the mean of the per-rank single-process gradients (clips shard with no data-path collective)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _layer():
+    import vss_cffm_amd as V
+    from oracle import recipe as R
+    m = V.BasicLayer3d3(dim=256, depth=1, num_heads=8, window_size=7, expand_size=3, pool_method='fc', focal_level=2,
+                        focal_window=5, focal_l_clips=[1, 2, 3], focal_kernel_clips=[7, 5, 3])
+    m.load_state_dict(R.layer_state(1, seed=40), strict=False)
+    return m
+
+
+def _clip(rank):
+    from oracle import recipe as R
+    return R.synth_input('ddp_x', (1, 4, 256, 8, 8), seed=50 + rank), R.synth_input('ddp_g', (1, 256, 8, 8), seed=60 + rank, scale=1.0)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CFFM_EMU_THREADS='2')
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tests import emu
+    with emu.active():
+        model = torch.nn.parallel.DistributedDataParallel(_layer(), gradient_as_bucket_view=True, broadcast_buffers=False)
+        x, g = _clip(rank)
+        y = model(x)
+        (y[:, -1] * g).sum().backward()
+    grads = {k: p.grad.clone() for k, p in model.module.named_parameters()}
+    assert all(v is not None for v in grads.values())
+    torch.save(grads, os.path.join(out, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_world_size_2_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r)) for r in range(world))
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k            # all-reduced: identical on both ranks
+    # single-process reference: mean of the two ranks' own gradients
+    from tests import emu, helpers as H
+    per_rank = []
+    with emu.active():
+        for r in range(world):
+            m = _layer()
+            x, g = _clip(r)
+            (m(x)[:, -1] * g).sum().backward()
+            per_rank.append({k: p.grad for k, p in m.named_parameters()})
+    for k in g0:
+        want = (per_rank[0][k] + per_rank[1][k]) / world
+        assert H.rel_err(g0[k], want) < 1e-5, k

@@ -66,8 +66,9 @@ def test_full_size_against_oracle_and_properties():
     y2 = m(xg.detach())
     assert torch.equal(y.detach(), y2)                              # forward has no atomics
     y_single = m(xg.detach()[1:2])
-    # clips are independent; rocBLAS may pick another SGEMM kernel for another M, so not bit-exact
-    assert H.rel_err(y_single[0, -1], y.detach()[1, -1]) < 1e-5
+    # clips are independent.  Not bit-exact: rocBLAS picks another SGEMM kernel for another M (1e-7 differences
+    # in q/k/v), and the f16 rounding of the MFMA operands turns some of those into 1-ulp(f16) differences.
+    assert H.rel_err(y_single[0, -1], y.detach()[1, -1]) < FWD_TOL
     (y[:, -1] * gy.to(dev())).sum().backward()
     torch.set_num_threads(max(1, torch.get_num_threads()))
     xo = x.clone().requires_grad_(True)

@@ -3,3 +3,7 @@ cross-frame attention path (CFFA + CFM, and the CFFM++ prototype attention), beh
 reference's own module / registry names.  See DESIGN.md and include/cffm_hip.h."""
 from .modules import (BasicLayer3d3, BasicLayer_cluster, CffmTransformerBlock3d3, Mlp,  # noqa: F401
                       SwinTransformerBlock_cluster, WindowAttention3d3, WindowAttention_cluster)
+from . import head  # noqa: F401,E402  (registers the three CFFM heads and CrossEntropyLoss)
+from .config import Config  # noqa: F401,E402
+from .registry import (BACKBONES, HEADS, LOSSES, NECKS, SEGMENTORS, Registry, build_backbone,  # noqa: F401,E402
+                       build_from_cfg, build_head, build_loss, build_neck, build_segmentor)

@@ -1,0 +1,356 @@
+"""The three CFFM decode heads, registered under the reference's names with the reference's constructor
+contract and state_dict keys, around the MI355X hot path.
+
+* ``CFFMHead_clips_resize1_8``                      <- cffm_head.py:41-157
+* ``CFFMHead_clips_resize1_8_gene_prototype``       <- cffm_head.py:161-300  (k-means prototypes per video)
+* ``CFFMHead_clips_resize1_8_finetune_w_prototype3``<- cffm_head.py:304-535  (CFFM++)
+* ``BaseDecodeHead_clips_flow``                     <- decode_head.py:513-835 (ctor contract, losses)
+* ``CrossEntropyLoss`` / ``accuracy``               <- losses/cross_entropy_loss.py:141, losses/accuracy.py:4
+
+Only ``decoder_focal`` / ``decoder_swin`` run in libcffm_hip.so; the SegFormer MLP decoder, the 1x1
+classifiers, the resizes and the losses around them are stock PyTorch (out of the hot path, SURVEY 8f "next").
+mmcv is absent on both boxes, so ``ConvModule`` / ``resize`` are re-provided with the same parameter names.
+"""
+import glob
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .modules import BasicLayer3d3, BasicLayer_cluster
+from .registry import HEADS, LOSSES, build_loss
+
+
+def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=None):
+    """mmseg.ops.resize: F.interpolate (mmseg/ops/wrappers.py:8-29, minus its warning)."""
+    return F.interpolate(input, size, scale_factor, mode, align_corners)
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> ReLU with mmcv's sub-module names (``conv``, ``bn``, ``activate``)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, norm_cfg=None, act_cfg=dict(type='ReLU'), **kw):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=norm_cfg is None, **kw)
+        self.bn = None
+        if norm_cfg is not None:
+            kinds = {'BN': nn.BatchNorm2d, 'BN2d': nn.BatchNorm2d, 'SyncBN': nn.SyncBatchNorm}
+            if norm_cfg['type'] not in kinds:
+                raise KeyError('unsupported norm type %s' % norm_cfg['type'])
+            self.bn = kinds[norm_cfg['type']](out_channels)
+            for p in self.bn.parameters():
+                p.requires_grad = norm_cfg.get('requires_grad', True)
+        self.activate = nn.ReLU(inplace=True) if act_cfg is not None else None
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+        if self.conv.bias is not None:
+            nn.init.zeros_(self.conv.bias)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return self.activate(x) if self.activate is not None else x
+
+
+def revert_sync_batchnorm(module):
+    """SyncBatchNorm -> BatchNorm2d in place (what the reference's CPU tests do, tests/test_models/test_forward.py:186)."""
+    for name, child in module.named_children():
+        if isinstance(child, nn.SyncBatchNorm):
+            bn = nn.BatchNorm2d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)
+            bn.load_state_dict(child.state_dict())
+            setattr(module, name, bn)
+        else:
+            revert_sync_batchnorm(child)
+    return module
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def accuracy(pred, target, topk=1):
+    """Top-1 pixel accuracy in percent over ALL pixels (ignored ones count as wrong, as in the reference)."""
+    if pred.size(0) == 0:
+        return pred.new_tensor(0.)
+    hit = pred.argmax(dim=1).eq(target)
+    return hit.float().sum().reshape(1) * (100.0 / target.numel())
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0):
+        super().__init__()
+        if use_sigmoid or use_mask:
+            raise NotImplementedError('the CFFM configs use the softmax cross entropy only')
+        self.reduction, self.class_weight, self.loss_weight = reduction, class_weight, loss_weight
+
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, ignore_index=-100):
+        cw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
+        loss = F.cross_entropy(cls_score, label, weight=cw, reduction='none', ignore_index=ignore_index)
+        if weight is not None:
+            loss = loss * weight.float()
+        red = reduction_override or self.reduction
+        if avg_factor is not None:
+            assert red == 'mean'
+            loss = loss.sum() / avg_factor
+        elif red == 'mean':
+            loss = loss.mean()          # over all pixels, ignored ones included (cross_entropy_loss.py:18-30)
+        elif red == 'sum':
+            loss = loss.sum()
+        return self.loss_weight * loss
+
+
+# ------------------------------------------------------------------------------------------------ base class
+class BaseDecodeHead_clips_flow(nn.Module):
+    def __init__(self, in_channels, channels, *, num_classes, dropout_ratio=0.1, conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU'), in_index=-1, input_transform=None,
+                 loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0), decoder_params=None,
+                 ignore_index=255, sampler=None, align_corners=False, num_clips=5):
+        super().__init__()
+        if input_transform is not None:
+            assert input_transform in ('resize_concat', 'multiple_select')
+            assert isinstance(in_channels, (list, tuple)) and isinstance(in_index, (list, tuple))
+            assert len(in_channels) == len(in_index)
+        else:
+            assert isinstance(in_channels, int) and isinstance(in_index, int)
+        if sampler is not None:
+            raise NotImplementedError('pixel samplers are not used by the CFFM configs')
+        self.input_transform, self.in_index = input_transform, in_index
+        self.in_channels = sum(in_channels) if input_transform == 'resize_concat' else in_channels
+        self.channels, self.num_classes, self.dropout_ratio = channels, num_classes, dropout_ratio
+        self.conv_cfg, self.norm_cfg, self.act_cfg = conv_cfg, norm_cfg, act_cfg
+        self.loss_decode = build_loss(loss_decode)
+        self.ignore_index, self.align_corners, self.num_clips = ignore_index, align_corners, num_clips
+        self.sampler = None
+        self.conv_seg = nn.Conv2d(channels, num_classes, kernel_size=1)      # never used by the CFFM forward
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else None
+        self.fp16_enabled = False
+
+    def init_weights(self):
+        nn.init.normal_(self.conv_seg.weight, mean=0, std=0.01)
+        nn.init.constant_(self.conv_seg.bias, 0)
+
+    def _transform_inputs(self, inputs):
+        if self.input_transform == 'multiple_select':
+            return [inputs[i] for i in self.in_index]
+        if self.input_transform == 'resize_concat':
+            picked = [inputs[i] for i in self.in_index]
+            return torch.cat([resize(x, size=picked[0].shape[2:], mode='bilinear', align_corners=self.align_corners)
+                              for x in picked], dim=1)
+        return inputs[self.in_index]
+
+    def forward_train(self, inputs, img_metas, gt_semantic_seg, train_cfg, batch_size, num_clips, img=None):
+        return self.losses(self.forward(inputs, batch_size, num_clips, img), gt_semantic_seg)
+
+    def forward_test(self, inputs, img_metas, test_cfg, batch_size=None, num_clips=None, img=None):
+        return self.forward(inputs, batch_size, num_clips, img)
+
+    def cls_seg(self, feat):
+        return self.conv_seg(self.dropout(feat) if self.dropout is not None else feat)
+
+    def losses(self, seg_logit, seg_label):
+        """0.5 * CE(per-frame logits, all frames) + CE(clip-level logits, last frame)  (decode_head.py:744-835).
+        seg_logit [B, T+e, K, h, w] with e extra clip-level maps, seg_label [B, T, 1, H, W]."""
+        assert seg_logit.dim() == 5 and seg_label.dim() == 5
+        b, t = seg_label.shape[:2]
+        n = seg_logit.shape[1]
+        if n in (t + 1, t + 3):                       # k+1 / k+3: e clip-level maps, all judged on the last frame
+            e, frame_labels = n - t, seg_label
+        elif n in (2 * t, 2 * t + 1):                 # 2k / 2k+1: frame logits twice (minus one), labels repeated
+            e, frame_labels = n - (2 * t - 1), torch.cat([seg_label, seg_label], 1)[:, :-1]
+        else:
+            raise AssertionError('unsupported logit layout %d for %d frames' % (n, t))
+        frame_logits = seg_logit[:, :n - e].flatten(0, 1)
+        clip_logits = seg_logit[:, n - e:].flatten(0, 1)
+        frame_labels = frame_labels.flatten(0, 1).squeeze(1)
+        clip_labels = seg_label[:, -1:].expand(-1, e, -1, -1, -1).flatten(0, 1).squeeze(1)
+        size = seg_label.shape[3:]
+        frame_logits = resize(frame_logits, size=size, mode='bilinear', align_corners=self.align_corners)
+        clip_logits = resize(clip_logits, size=size, mode='bilinear', align_corners=self.align_corners)
+        loss = 0.5 * self.loss_decode(frame_logits, frame_labels, weight=None, ignore_index=self.ignore_index) \
+            + self.loss_decode(clip_logits, clip_labels, weight=None, ignore_index=self.ignore_index)
+        return dict(loss_seg=loss, acc_seg=accuracy(frame_logits, frame_labels))
+
+
+class MLP(nn.Module):
+    """SegFormer linear embedding: [N,C,H,W] -> [N,H*W,embed] (cffm_head.py:26-37)."""
+
+    def __init__(self, input_dim=2048, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Linear(input_dim, embed_dim)
+
+    def forward(self, x):
+        return self.proj(x.flatten(2).transpose(1, 2))
+
+
+def _focal_layer(embed_dim, depths):
+    return BasicLayer3d3(dim=embed_dim, depth=depths, num_heads=8, window_size=7, mlp_ratio=4., qkv_bias=True,
+                         qk_scale=None, drop=0., attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, pool_method='fc',
+                         downsample=None, focal_level=2, focal_window=5, expand_size=3, use_conv_embed=False,
+                         use_shift=False, use_pre_norm=False, use_checkpoint=False, focal_l_clips=[1, 2, 3],
+                         focal_kernel_clips=[7, 5, 3])
+
+
+class _CffmHeadBase(BaseDecodeHead_clips_flow):
+    """What the three heads share: SegFormer MLP decoder, fuse conv, per-frame classifier, hot path."""
+
+    def __init__(self, feature_strides, **kwargs):
+        super().__init__(input_transform='multiple_select', **kwargs)
+        assert len(feature_strides) == len(self.in_channels)
+        assert min(feature_strides) == feature_strides[0]
+        self.feature_strides = feature_strides
+        c1, c2, c3, c4 = self.in_channels
+        dp = kwargs['decoder_params']
+        e = dp['embed_dim']
+        self.linear_c4, self.linear_c3 = MLP(c4, e), MLP(c3, e)
+        self.linear_c2, self.linear_c1 = MLP(c2, e), MLP(c1, e)
+        self.linear_fuse = ConvModule(e * 4, e, kernel_size=1, norm_cfg=dict(type='SyncBN', requires_grad=True))
+        self.linear_pred = nn.Conv2d(e, self.num_classes, kernel_size=1)
+        self.linear_pred2 = nn.Conv2d(e * 2, self.num_classes, kernel_size=1)
+        self.decoder_focal = _focal_layer(e, dp['depths'])
+
+    def _fuse(self, inputs):
+        """cffm_head.py:102-119: 4 x (linear embed -> resize to 1/4) -> concat -> 1x1 conv + BN + ReLU."""
+        c1, c2, c3, c4 = self._transform_inputs(inputs)
+        n, size = c4.shape[0], c1.shape[2:]
+        maps = []
+        for lin, c in ((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2), (self.linear_c1, c1)):
+            m = lin(c).permute(0, 2, 1).reshape(n, -1, c.shape[2], c.shape[3])
+            maps.append(m if c is c1 else resize(m, size=size, mode='bilinear', align_corners=False))
+        return self.linear_fuse(torch.cat(maps, dim=1))
+
+    def _frame_logits(self, fused, batch_size, num_clips):
+        x = self.linear_pred(self.dropout(fused) if self.dropout is not None else fused)
+        return x.reshape(batch_size, num_clips, -1, fused.shape[2], fused.shape[3])
+
+    def _clip_features(self, fused, batch_size, num_clips):
+        """1/4 -> 1/8 resize, then the hot path (cffm_head.py:131-145)."""
+        h, w = fused.shape[2:]
+        small = resize(fused, size=(int(h / 2), int(w / 2)), mode='bilinear', align_corners=False)
+        stack = small.reshape(batch_size, num_clips, -1, int(h / 2), int(w / 2))
+        mined = self.decoder_focal(stack)
+        assert mined.shape == stack.shape
+        return stack, mined
+
+    def _clip_logits(self, stack, mined, size):
+        feat = torch.cat([stack[:, -1], mined[:, -1]], 1)
+        x2 = self.linear_pred2(self.dropout(feat) if self.dropout is not None else feat)
+        return resize(x2, size=size, mode='bilinear', align_corners=False).unsqueeze(1)
+
+
+@HEADS.register_module()
+class CFFMHead_clips_resize1_8(_CffmHeadBase):
+    def forward(self, inputs, batch_size=None, num_clips=None, imgs=None):
+        if self.training:
+            assert self.num_clips == num_clips
+        fused = self._fuse(inputs)
+        x = self._frame_logits(fused, batch_size, num_clips)
+        if not self.training and num_clips != self.num_clips:
+            return x[:, -1]                                   # short-circuit before CFFM (cffm_head.py:127-129)
+        stack, mined = self._clip_features(fused, batch_size, num_clips)
+        x2 = self._clip_logits(stack, mined, fused.shape[2:])
+        if not self.training:
+            return x2.squeeze(1)
+        return torch.cat([x, x2], 1)                          # [B, T+1, classes, h, w]
+
+
+def _kmeans(x, k, iters=10):
+    """Plain euclidean k-means with random initial centroids, like fast_pytorch_kmeans.KMeans(mode='euclidean',
+    max_iter=10) which the reference calls (cffm_head.py:280-282; third-party, version unpinned, random init ->
+    parity unpinned; outside the measured path)."""
+    centers = x[torch.randperm(x.shape[0], device=x.device)[:k]].clone()
+    for _ in range(iters):
+        assign = torch.cdist(x, centers).argmin(dim=1)
+        for j in range(k):
+            sel = assign == j
+            if sel.any():
+                centers[j] = x[sel].mean(dim=0)
+    return centers
+
+
+@HEADS.register_module()
+class CFFMHead_clips_resize1_8_gene_prototype(_CffmHeadBase):
+    def __init__(self, feature_strides, **kwargs):
+        super().__init__(feature_strides, **kwargs)
+        self.n_clusters, self.save_path = 100, './cluster_centers/'
+
+    def forward_test(self, inputs, img_metas, test_cfg, batch_size=None, num_clips=None, img=None):
+        return self.forward(inputs, batch_size, num_clips, img, img_metas)
+
+    def forward(self, inputs, batch_size=None, num_clips=None, imgs=None, img_metas=None):
+        if self.training:
+            assert self.num_clips == num_clips
+        fused = self._fuse(inputs)
+        x = self._frame_logits(fused, batch_size, num_clips)
+        assert batch_size == 1
+        h, w = fused.shape[2:]
+        small = resize(fused, size=(int(h / 2), int(w / 2)), mode='bilinear', align_corners=False)
+        feats = small.reshape(batch_size, num_clips, -1, int(h / 2), int(w / 2)).permute(0, 1, 3, 4, 2)
+        feats = feats.reshape(batch_size, -1, feats.shape[-1])
+        with torch.no_grad():
+            centers = torch.stack([_kmeans(feats[i], self.n_clusters) for i in range(batch_size)], dim=0)
+        video = img_metas[0]['filename'].split('/')[-3]
+        os.makedirs(self.save_path + video, exist_ok=True)
+        torch.save(centers, self.save_path + video + '/centers.pt')
+        if not self.training:
+            return x[:, -1]
+
+
+@HEADS.register_module()
+class CFFMHead_clips_resize1_8_finetune_w_prototype3(_CffmHeadBase):
+    def __init__(self, feature_strides, **kwargs):
+        super().__init__(feature_strides, **kwargs)
+        e = kwargs['decoder_params']['embed_dim']
+        focal = self._modules.pop('decoder_focal')           # keep the reference's registration (state_dict) order
+        self.linear_pred3 = nn.Conv2d(e, self.num_classes, kernel_size=1)
+        self.decoder_focal = focal
+        self.n_clusters, self.save_path = 10, './cluster_centers/'
+        self.dropout3 = nn.Dropout2d(self.dropout_ratio)
+        self.decoder_swin = BasicLayer_cluster(dim=e, depth=1, num_heads=8, window_size=7, mlp_ratio=4., qkv_bias=True,
+                                               qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                                               norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False)
+        self.finetune = True
+
+    def forward_train(self, inputs, img_metas, gt_semantic_seg, train_cfg, batch_size, num_clips, img=None):
+        return self.losses(self.forward(inputs, batch_size, num_clips, img, img_metas), gt_semantic_seg)
+
+    def forward_test(self, inputs, img_metas, test_cfg, batch_size=None, num_clips=None, img=None):
+        return self.forward(inputs, batch_size, num_clips, img, img_metas)
+
+    def _load_centers(self, img_metas, device, keep=0.8):
+        """Per-video prototype tensors [1,K,C] (cffm_head.py:430-455); several files -> random 80 % subset."""
+        out = []
+        for meta in img_metas:
+            video = meta['filename'].split('/')[-3]
+            path = self.save_path + video + '/centers.pt'
+            if os.path.isfile(path):
+                out.append(torch.load(path, map_location='cpu'))
+                continue
+            parts = torch.cat([torch.load(p, map_location='cpu') for p in glob.glob(self.save_path + video + '/*.pt')], dim=1)
+            assert parts.dim() == 3 and parts.shape[0] == 1, parts.shape
+            pick = torch.topk(torch.rand(parts.shape[1]), int(parts.shape[1] * keep))[1].sort()[0]
+            out.append(parts[:, pick])
+        return torch.cat(out, dim=0).to(device)
+
+    def forward(self, inputs, batch_size=None, num_clips=None, imgs=None, img_metas=None):
+        assert batch_size == len(img_metas)
+        centers = self._load_centers(img_metas, inputs[0].device)
+        if self.training:
+            assert self.num_clips == num_clips
+        with torch.no_grad():                                  # the fuse conv is frozen in eval (cffm_head.py:478-480)
+            self.linear_fuse.eval()
+            fused = self._fuse(inputs)
+        x = self._frame_logits(fused, batch_size, num_clips)
+        if not self.training and num_clips != self.num_clips:
+            return x[:, -1]
+        stack, mined = self._clip_features(fused, batch_size, num_clips)
+        x2 = self._clip_logits(stack, mined, fused.shape[2:])
+        if self.finetune:                                      # the CFFM branch is detached (cffm_head.py:514-518)
+            stack, x, x2 = stack.detach(), x.detach(), x2.detach()
+        b, _, c, h2, w2 = stack.shape
+        tokens = stack[:, -1].permute(0, 2, 3, 1).reshape(b, h2 * w2, c)
+        ctx = self.decoder_swin(tokens, h2, w2, centers)[0]
+        ctx = ctx.reshape(b, h2, w2, c).permute(0, 3, 1, 2)
+        x3 = resize(self.linear_pred3(self.dropout3(ctx)), size=fused.shape[2:], mode='bilinear', align_corners=False)
+        x3 = x3.unsqueeze(1)
+        if not self.training:
+            return x2.squeeze(1) + 0.5 * x3.squeeze(1)
+        return torch.cat([x, x3], 1)

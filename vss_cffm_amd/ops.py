@@ -66,8 +66,7 @@ def device_tables(h0, w0, device):
     key = (h0, w0, str(device))
     if key not in _table_cache:
         ks, qd = geometry.tables(h0, w0)
-        _table_cache[key] = (torch.from_numpy(np.ascontiguousarray(ks)).to(device),
-                             torch.from_numpy(np.ascontiguousarray(qd)).to(device))
+        _table_cache[key] = (torch.from_numpy(np.array(ks)).to(device), torch.from_numpy(np.array(qd)).to(device))
     return _table_cache[key]
 
 
