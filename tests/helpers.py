@@ -22,6 +22,18 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+def scalar_grad_err(got, ref, sibling_weight_grad):
+    """The four pool biases are scalars: signed sums over every pooled cell and channel, so their *relative*
+    error is unbounded under cancellation.  Judge them on the scale of the sibling pool-weight gradient (sums of
+    the same terms weighted by O(1) activations) when that is larger than the scalar itself."""
+    ref = abs(float(np.asarray(ref).reshape(-1)[0]))
+    got = abs(float(torch.as_tensor(got).reshape(-1)[0]))
+    scale = ref
+    if sibling_weight_grad is not None:
+        scale = max(scale, float(np.abs(np.asarray(sibling_weight_grad)).max()))
+    return abs(got - ref) / max(scale, 1e-30)
+
+
 def layer_case_inputs(g, dtype=torch.float32):
     b, h, w, depth = [int(v) for v in g['meta']]
     st = R.layer_state(depth, seed=0, dtype=dtype)
@@ -65,10 +77,9 @@ def check_layer_backward(g, dx, param_grads, tol):
             err = rel_err(got.sum(-1), ref)
         else:
             raise KeyError(key)
-        # the four pool biases are scalars: sums of signed contributions of every pooled cell, so the f16
-        # operand noise of the attention backward is amplified by cancellation -> 2.5x the tolerance
-        tol_k = tol * 2.5 if got.numel() == 1 else tol
+        if got.numel() == 1 and kind in ('g', 'gnorm'):
+            err = scalar_grad_err(got, ref, g.get('p/g/' + name.replace('.bias', '.weight')))
         if err > worst[1]:
             worst = (key, err)
-        assert err < tol_k, '%s rel err %.3e >= %.1e' % (key, err, tol)
+        assert err < tol, '%s rel err %.3e >= %.1e' % (key, err, tol)
     return e, worst
