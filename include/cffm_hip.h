@@ -94,9 +94,12 @@ int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* con
 int cffm_attn_fwd(const cffm_geom* g, const float* qkv /*[B*RC,768] raw (no bias)*/, const float* qkv_b,
                   const int* key_src /*[nW,304]*/, const int* q_dst /*[nW,49]*/, const float* bias,
                   float* ao /*[B*HW,256]*/, float* lse /*[B*nW*8,64]*/, void* stream);
+/* inv_ptr [RC+1] / inv_idx: CSR inverse of key_src (token row -> the window*304+slot pairs reading it);
+ * dkv_part: scratch [B*nW*304*512] floats for the per-window dK/dV rows the gather pass sums */
 int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
-                  const float* bias, const float* biasT, const float* ao, const float* dao, const float* lse,
-                  float* dqkv /*[B*RC,768], overwritten*/, float* dbiasT /*[8,304,64], overwritten*/, void* stream);
+                  const int* inv_ptr, const int* inv_idx, const float* bias, const float* biasT, const float* ao,
+                  const float* dao, const float* lse, float* dqkv /*[B*RC,768], overwritten*/,
+                  float* dbiasT /*[8,304,64], overwritten*/, float* dkv_part, void* stream);
 /* y[M,N] = x[M,K] w[N,K]^T ;  dx[M,K] = dy[M,N] w[N,K] ;  dw[N,K] = dy[M,N]^T x[M,K]   (row-major, no bias) */
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream);
 int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream);
@@ -135,7 +138,8 @@ int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const flo
                        float* scratch, void* stream);
 int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                         const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
-                        const int* q_dst, const float* ws, const float* dout /*[B*HW,256]*/,
+                        const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws,
+                        const float* dout /*[B*HW,256]*/,
                         float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs,
                         float* scratch, void* stream);
 /* x [B,4,256,H0,W0] -> y_tgt [B,256,H0,W0] (frames 0..2 of the reference's output equal the input) */
@@ -146,7 +150,7 @@ int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* p
  * frames 0..2 is the caller's torch.cat) and every parameter gradient of every block */
 int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                         const float* dy_tgt_nchw, float* dx_nchw, const int* key_src, const int* q_dst,
-                        const float* saved, float* scratch, void* stream);
+                        const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,3 +37,16 @@ def test_tables_match_oracle_maps(h0, w0):
 def test_row_space_is_64_rows_per_window():
     key_src, _ = G.tables(60, 60)
     assert key_src.max() < 64 * 81
+
+
+@pytest.mark.parametrize('h0,w0', [(8, 8), (13, 30), (60, 60)])
+def test_inverse_tables_are_the_inverse(h0, w0):
+    key_src, _ = G.tables(h0, w0)
+    inv_ptr, inv_idx = G.inverse_tables(h0, w0)
+    nw = key_src.shape[0]
+    assert inv_ptr.shape == (64 * nw + 1,) and inv_ptr[-1] == (key_src >= 0).sum() == inv_idx.size
+    flat = key_src.reshape(-1)
+    for row in (0, 48, 49 * nw, 50 * nw + nw // 2, 64 * nw - 1):
+        got = sorted(inv_idx[inv_ptr[row]:inv_ptr[row + 1]].tolist())
+        assert got == sorted(np.nonzero(flat == row)[0].tolist())
+    assert (np.diff(inv_ptr) >= 1).all()           # every token row is read by at least one window

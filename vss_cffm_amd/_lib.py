@@ -53,7 +53,7 @@ SIGNATURES = {
     'cffm_bias_assemble': (ci, [vp, vp, P4, vp, vp, vp]),
     'cffm_bias_scatter': (ci, [vp, vp, vp, P4, vp]),
     'cffm_attn_fwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp]),
-    'cffm_attn_bwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'cffm_attn_bwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_linear_fwd': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_input': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight': (ci, [vp, vp, vp, cl, ci, ci, vp]),
@@ -65,9 +65,9 @@ SIGNATURES = {
     'cffm_gelu_bwd': (ci, [vp, vp, vp, cl, ci, vp, vp]),
     'cffm_residual_out': (ci, [vp, vp, vp, vp, cl, vp]),
     'cffm_block_forward': (ci, [GP, BP, vp, cl, vp, cl, vp, vp, vp, vp, vp]),
-    'cffm_block_backward': (ci, [GP, BP, BP, vp, cl, vp, cl, vp, vp, vp, vp, vp, cl, ci, vp, cl, vp, vp]),
+    'cffm_block_backward': (ci, [GP, BP, BP, vp, cl, vp, cl, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp, cl, vp, vp]),
     'cffm_layer_forward': (ci, [GP, ci, BP, vp, vp, vp, vp, vp, vp, vp]),
-    'cffm_layer_backward': (ci, [GP, ci, BP, BP, vp, vp, vp, vp, vp, vp, vp]),
+    'cffm_layer_backward': (ci, [GP, ci, BP, BP, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_gtc_attn_fwd': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_gtc_attn_bwd': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
 }

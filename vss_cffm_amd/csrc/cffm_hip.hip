@@ -147,7 +147,7 @@ long cffm_layer_saved_floats(const cffm_geom* g, int depth) {
 }
 
 // scratch carve (floats): fwd uses [0, BHW*C); bwd uses all of it
-struct Scratch { long a, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, total; };
+struct Scratch { long a, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, dkvp, total; };
 static Scratch scratch_layout(const cffm_geom* g) {
     const long B = g->B, HW = g->HW, RC = g->RC;
     Scratch s;
@@ -162,6 +162,7 @@ static Scratch scratch_layout(const cffm_geom* g) {
     s.dM = p; p += up(CFFM_NCELL * CFFM_WA);
     s.dbiasT = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     s.dxs = p; p += up(B * 4 * HW * CFFM_C);
+    s.dkvp = p; p += up(B * g->nW * (long)CFFM_NKEY_PAD * 512);
     s.total = p;
     return s;
 }
@@ -306,17 +307,17 @@ static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
 }
 
 int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
-                  const float* bias, const float* biasT, const float* ao, const float* dao, const float* lse,
-                  float* dqkv, float* dbiasT, void* stream) {
+                  const int* inv_ptr, const int* inv_idx, const float* bias, const float* biasT, const float* ao,
+                  const float* dao, const float* lse, float* dqkv, float* dbiasT, float* dkv_part, void* stream) {
     PROF(ST_ATTN_BWD);
     hipStream_t st = (hipStream_t)stream;
-    REQUIRE(g && qkv && biasT && dao && dqkv && dbiasT, "attn_bwd: null");
-    hipMemsetAsync(dqkv, 0, (size_t)g->B * g->RC * 768 * sizeof(float), st);
+    REQUIRE(g && qkv && biasT && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
     hipMemsetAsync(dbiasT, 0, (size_t)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD * sizeof(float), st);
     int per;
     const int ng = attn_bwd_groups(g, &per);
     CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (512), ATT_BWD_LDS, st, to_geo(g), qkv, qkv_b, key_src, q_dst, bias, biasT, ao,
-                dao, lse, dqkv, dbiasT, per);
+                dao, lse, dqkv, dkv_part, dbiasT, per);
+    CFFM_LAUNCH(k_dkv_gather, ((g->RC + 3) / 4, g->B), (256), 0, st, to_geo(g), inv_ptr, inv_idx, (const float*)dkv_part, dqkv);
     CHECK_LAUNCH("attn_bwd");
     return 0;
 }
@@ -473,8 +474,8 @@ int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const flo
 
 int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                         const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
-                        const int* q_dst, const float* ws, const float* dout, float* dx_ref, long dref_bs,
-                        int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, void* stream) {
+                        const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
+                        float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, void* stream) {
     REQUIRE(g && p && gr && ws && dout && scratch, "block_backward: null");
     cffm_block_ws L;
     cffm_block_ws_layout(g, &L);
@@ -502,8 +503,8 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     TRY(cffm_linear_bwd_weight(dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dx1, p->proj_w, dao, NP, CFFM_C, CFFM_C, stream));
     // attention
-    TRY(cffm_attn_bwd(g, ws + L.qkv, p->qkv_b, key_src, q_dst, ws + L.bias, ws + L.biasT, ws + L.ao, dao, ws + L.lse, dqkv,
-                      dbiasT, stream));
+    TRY(cffm_attn_bwd(g, ws + L.qkv, p->qkv_b, key_src, q_dst, inv_ptr, inv_idx, ws + L.bias, ws + L.biasT, ws + L.ao, dao,
+                      ws + L.lse, dqkv, dbiasT, scratch + S.dkvp, stream));
     TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, stream));
     // qkv = zall Wqkv^T (+ bias inside the attention kernel)
     TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
@@ -539,7 +540,7 @@ int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* p
 
 int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                         const float* dy_tgt_nchw, float* dx_nchw, const int* key_src, const int* q_dst,
-                        const float* saved, float* scratch, void* stream) {
+                        const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream) {
     REQUIRE(g && params && grads && dy_tgt_nchw && dx_nchw && saved && scratch && depth >= 1, "layer_backward: bad arguments");
     cffm_block_ws L;
     cffm_block_ws_layout(g, &L);
@@ -558,7 +559,7 @@ int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* 
         // (block_backward has consumed `dout` by the time ln_pool_bwd writes dx_tgt)
         float* dtgt = (i == 0) ? dxs + 3 * img : dcur;
         const long dtgt_bs = (i == 0) ? 4 * img : img;
-        TRY(cffm_block_backward(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, ws, dcur, dxs, 4 * img,
+        TRY(cffm_block_backward(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dcur, dxs, 4 * img,
                                 i != depth - 1, dtgt, dtgt_bs, scratch, stream));
     }
     TRY(cffm_transpose(dxs, dx_nchw, g->B * 4, (int)HW, CFFM_C, img, img, stream));

@@ -25,6 +25,9 @@
 #pragma once
 #include "cffa_kernels.h"
 
+#ifndef CFFM_ABLATE
+#define CFFM_ABLATE 0  // profiling only: 1 = no dK/dV atomics, 2 = no query-owner role, 4 = no key-owner role
+#endif
 #define ATT_KS_STRIDE 40   // halfs per K/V/Q row in LDS (32 + 8 pad = 80 B)
 #define ATT_VT_STRIDE 328  // halfs per row of a [32][keys] transposed image (164 dwords = 4*41)
 #define ATT_QT_STRIDE 72   // halfs per row of a [32][64 queries] transposed image (36 dwords = 4*9)
@@ -166,21 +169,21 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const float* __r
 // Backward.  grid (8 heads, NG groups), 512 threads; each workgroup walks the windows of its group for
 // one head.  Waves 0-3 ("query owners": 16 queries x all keys, S^T orientation) produce dQ and the
 // position-bias gradient, which stays in registers across the windows of the group; waves 4-7 ("key
-// owners": 16-key tiles x all 64 queries, S orientation) produce dK and dV for their keys and add them
-// to the shared token rows (ring / pooled keys are read by several windows) with f32 atomics.
+// owners": 16-key tiles x all 64 queries, S orientation) produce dK and dV for their keys into per-window
+// partial rows; k_dkv_gather then sums, for every token row, the slots of all windows that read it (ring /
+// pooled keys are shared by up to 49 windows) through a host-built inverse of the key table.
 // dO is rescaled per window by a power of two so every f16 gradient operand sits near 1 (training-size
 // gradients of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
 // =====================================================================================================
 #define ATT_BWD_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
-                     CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4 + 4 * 2 * 16 * ATT_T_STRIDE * 4)
-#define ATT_T_STRIDE 36  // floats per key row of the per-wave dK/dV transposition scratch
+                     CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
 
 __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
                                                        const float* __restrict__ bias, const float* __restrict__ biasT,
                                                        const float* __restrict__ ao, const float* __restrict__ dao,
                                                        const float* __restrict__ lse_in, float* __restrict__ dqkv,
-                                                       float* __restrict__ dbiasT, int per_group) {
+                                                       float* __restrict__ dkv_part, float* __restrict__ dbiasT, int per_group) {
     CFFM_DYN_SMEM(smem);
     f16* Qs = (f16*)smem;
     f16* dOs = Qs + 64 * ATT_KS_STRIDE;
@@ -193,7 +196,6 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
     float* slse = vflag + CFFM_NKEY_PAD;
     float* sD = slse + 64;
     float* smax = sD + 64;
-    float* tscr = smax + 16;  // [4 key-owner waves][2][16 keys][ATT_T_STRIDE]
 
     const int h = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -212,27 +214,58 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
         const float* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;
 
         // ---------------- stage --------------------------------------------------------------------
+        // global loads in two batches (tables, then every gathered row segment), as in the forward
+        const int ch = lane >> 3;
+        int src0[3], src1[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int prk = (it * 8 + wave) * 8 + (lane & 7);
+            const bool ok = prk < CFFM_NKEY_PAD / 2;
+            src0[it] = ok ? ksrc[2 * prk] : -1;
+            src1[it] = ok ? ksrc[2 * prk + 1] : -1;
+        }
+        const int pr = (tid & 255) >> 3, c = tid & 7, i0 = 2 * pr, i1 = i0 + 1;
+        int t0 = -1, t1 = -1;
+        if (tid >= 256) {
+            t0 = (i0 < CFFM_WA) ? q_dst[w * CFFM_WA + i0] : -1;
+            t1 = (i1 < CFFM_WA) ? q_dst[w * CFFM_WA + i1] : -1;
+        }
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 k0[3], k1[3], v0[3], v1[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            k0[it] = k1[it] = v0[it] = v1[it] = z4;
+            if (src0[it] >= 0) { k0[it] = ld4(base + (long)src0[it] * 768 + 256 + 4 * ch); v0[it] = ld4(base + (long)src0[it] * 768 + 512 + 4 * ch); }
+            if (src1[it] >= 0) { k1[it] = ld4(base + (long)src1[it] * 768 + 256 + 4 * ch); v1[it] = ld4(base + (long)src1[it] * 768 + 512 + 4 * ch); }
+        }
+        f32x4 r0 = z4, r1 = z4, o0 = z4, o1 = z4;
+        if (tid < 256) {
+            if (i0 < CFFM_WA) r0 = ld4(base + (long)(w * CFFM_WA + i0) * 768 + 4 * c);
+            if (i1 < CFFM_WA) r1 = ld4(base + (long)(w * CFFM_WA + i1) * 768 + 4 * c);
+        } else {
+            if (t0 >= 0) { const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c; r0 = ld4(dao + off); o0 = ld4(ao + off); }
+            if (t1 >= 0) { const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c; r1 = ld4(dao + off); o1 = ld4(ao + off); }
+        }
         for (int n = tid; n < CFFM_NKEY_PAD; n += 512) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
         for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 512)
             Kt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
         if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid];
         {   // K (row-major + transposed) and V (row-major); lane -> (row pair, 4-channel chunk)
-            const int ch = lane >> 3;
             const f32x4 bk = ld4(bqkv + 256 + h * CFFM_HD + 4 * ch), bv = ld4(bqkv + 512 + h * CFFM_HD + 4 * ch);
+#pragma unroll
             for (int it = 0; it < 3; ++it) {
-                const int pr = (it * 8 + wave) * 8 + (lane & 7);
-                if (pr < CFFM_NKEY_PAD / 2) {
-                    const int n0 = 2 * pr, s0 = ksrc[n0], s1 = ksrc[n0 + 1];
-                    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    f32x4 k0 = z, k1 = z, v0 = z, v1 = z;
-                    if (s0 >= 0) { k0 = ld4(base + (long)s0 * 768 + 256 + 4 * ch) + bk; v0 = ld4(base + (long)s0 * 768 + 512 + 4 * ch) + bv; }
-                    if (s1 >= 0) { k1 = ld4(base + (long)s1 * 768 + 256 + 4 * ch) + bk; v1 = ld4(base + (long)s1 * 768 + 512 + 4 * ch) + bv; }
-                    *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0);
-                    *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1);
-                    *(f16x4*)(Vs + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v0);
-                    *(f16x4*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v1);
+                const int prk = (it * 8 + wave) * 8 + (lane & 7);
+                if (prk < CFFM_NKEY_PAD / 2) {
+                    const int n0 = 2 * prk;
+                    if (src0[it] >= 0) { k0[it] += bk; v0[it] += bv; }
+                    if (src1[it] >= 0) { k1[it] += bk; v1[it] += bv; }
+                    *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0[it]);
+                    *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1[it]);
+                    *(f16x4*)(Vs + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v0[it]);
+                    *(f16x4*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v1[it]);
+#pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        f16x2 pk; pk[0] = (f16)k0[e]; pk[1] = (f16)k1[e];
+                        f16x2 pk; pk[0] = (f16)k0[it][e]; pk[1] = (f16)k1[it][e];
                         *(f16x2*)(Kt + (4 * ch + e) * ATT_VT_STRIDE + n0) = pk;
                     }
                 }
@@ -240,27 +273,14 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
         }
         // Q (threads 0..255) and dO / D (threads 256..511); item = (query pair, chunk); chunk = lane & 7 so
         // the 8 chunks of a query sit in 8 adjacent lanes (D is reduced with xor-shuffles 1,2,4)
-        const int pr = (tid & 255) >> 3, c = tid & 7, i0 = 2 * pr, i1 = i0 + 1;
-        f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
         float d0 = 0.f, d1 = 0.f, amax = 0.f;
         if (tid < 256) {
             const f32x4 bq = ld4(bqkv + h * CFFM_HD + 4 * c);
-            if (i0 < CFFM_WA) r0 = (ld4(base + (long)(w * CFFM_WA + i0) * 768 + 4 * c) + bq) * scale;
-            if (i1 < CFFM_WA) r1 = (ld4(base + (long)(w * CFFM_WA + i1) * 768 + 4 * c) + bq) * scale;
+            if (i0 < CFFM_WA) r0 = (r0 + bq) * scale;
+            if (i1 < CFFM_WA) r1 = (r1 + bq) * scale;
         } else {
-            const int t0 = (i0 < CFFM_WA) ? q_dst[w * CFFM_WA + i0] : -1, t1 = (i1 < CFFM_WA) ? q_dst[w * CFFM_WA + i1] : -1;
-            if (t0 >= 0) {
-                const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c;
-                r0 = ld4(dao + off);
-                const f32x4 ov = ld4(ao + off);
-                d0 = r0[0] * ov[0] + r0[1] * ov[1] + r0[2] * ov[2] + r0[3] * ov[3];
-            }
-            if (t1 >= 0) {
-                const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c;
-                r1 = ld4(dao + off);
-                const f32x4 ov = ld4(ao + off);
-                d1 = r1[0] * ov[0] + r1[1] * ov[1] + r1[2] * ov[2] + r1[3] * ov[3];
-            }
+            d0 = r0[0] * o0[0] + r0[1] * o0[1] + r0[2] * o0[2] + r0[3] * o0[3];
+            d1 = r1[0] * o1[0] + r1[1] * o1[1] + r1[2] * o1[2] + r1[3] * o1[3];
             for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
         }
         d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64); d0 += __shfl_xor(d0, 4, 64);
@@ -290,7 +310,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
         }
         __syncthreads();
 
-        if (wave < 4) {
+        if (wave < 4 && !(CFFM_ABLATE & 2)) {
             // ---------------- role A: query owners -> dQ, dBias ----------------------------------------
             const int qcol = 16 * wave + l15;
             const f16x8 qfrag = *(const f16x8*)(Qs + qcol * ATT_KS_STRIDE + 8 * g);
@@ -298,9 +318,15 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
             const float lq = slse[qcol], Dq = sD[qcol];
             const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
             f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            f32x4 bcur[2] = {ld4(brow), ld4(brow + 16)};   // bias tiles are fetched one key-tile pair ahead
 #pragma unroll
             for (int kt = 0; kt < 10; ++kt) {
                 f16x4 dsh[2];
+                f32x4 bnxt[2] = {bcur[0], bcur[1]};
+                if (kt < 9) {
+                    bnxt[0] = ld4(brow + 16 * (2 * kt + 2));
+                    if (2 * kt + 3 < 19) bnxt[1] = ld4(brow + 16 * (2 * kt + 3));
+                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int t = 2 * kt + u;
@@ -309,7 +335,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                         const f16x8 vf = *(const f16x8*)(Vs + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
                         f32x4 sv = mfma16x16x32_f16(kf, qfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
                         const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});
-                        sv += ld4(brow + 16 * t) + *(const f32x4*)(vflag + 16 * t + 4 * g);
+                        sv += bcur[u] + *(const f32x4*)(vflag + 16 * t + 4 * g);
                         f32x4 ds;
                         for (int r = 0; r < 4; ++r) ds[r] = fast_exp(sv[r] - lq) * (dp[r] - Dq);
                         dB[t < 19 ? t : 0] += ds * isc;
@@ -325,20 +351,31 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                     const f16x8 ka = cat_f16x4(*(const f16x4*)kr, *(const f16x4*)(kr + 16));
                     dq[mt] = mfma16x16x32_f16(ka, dsf, dq[mt]);
                 }
+                bcur[0] = bnxt[0];
+                bcur[1] = bnxt[1];
             }
             if (qcol < CFFM_WA) {
                 float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
                 *(f32x4*)(drow) = dq[0] * (scale * isc);
                 *(f32x4*)(drow + 16) = dq[1] * (scale * isc);
             }
-        } else {
+        } else if (wave >= 4 && !(CFFM_ABLATE & 4)) {
             // ---------------- role B: key owners -> dK, dV ---------------------------------------------
+            f32x4 bt[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) bt[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + 16 * (wave - 4) + l15) * CFFM_NQ_PAD + 4 * g + 16 * mt);
             for (int t = wave - 4; t < 19; t += 4) {
                 const int key = 16 * t + l15;
+                f32x4 bn[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) bn[mt] = bt[mt];
+                if (t + 4 < 19) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) bn[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + key + 64) * CFFM_NQ_PAD + 4 * g + 16 * mt);
+                }
                 const f16x8 kfrag = *(const f16x8*)(Ks + key * ATT_KS_STRIDE + 8 * g);
                 const f16x8 vfrag = *(const f16x8*)(Vs + key * ATT_KS_STRIDE + 8 * g);
                 const float vf = vflag[key];
-                const float* btrow = biasT + ((long)h * CFFM_NKEY_PAD + key) * CFFM_NQ_PAD + 4 * g;
                 f16x4 ph[4], dsh[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
@@ -346,7 +383,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                     const f16x8 da = *(const f16x8*)(dOs + (16 * mt + l15) * ATT_KS_STRIDE + 8 * g);
                     f32x4 sv = mfma16x16x32_f16(qa, kfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
                     const f32x4 dp = mfma16x16x32_f16(da, vfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    sv += ld4(btrow + 16 * mt) + vf;
+                    sv += bt[mt] + vf;
                     const f32x4 lq = *(const f32x4*)(slse + 16 * mt + 4 * g), Dq = *(const f32x4*)(sD + 16 * mt + 4 * g);
                     f32x4 p, ds;
                     for (int r = 0; r < 4; ++r) { p[r] = fast_exp(sv[r] - lq[r]); ds[r] = p[r] * (dp[r] - Dq[r]); }
@@ -367,25 +404,17 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                         dk[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)qrow, *(const f16x4*)(qrow + 16)), sf, dk[dt]);
                     }
                 }
-                // dK^T/dV^T tiles sit as [d][key] across the wave; go through a wave-private LDS tile so each atomic
-                // instruction adds two whole 128-B (token, head) rows instead of 64 scattered dwords.
-                float* Tk = tscr + (wave - 4) * 2 * 16 * ATT_T_STRIDE;
-                float* Tv = Tk + 16 * ATT_T_STRIDE;
-                wave_lds_sync();
+                // dK^T/dV^T tiles sit as [d = 16dt+4g+r][key = l15]: every lane owns 16 contiguous bytes of a key row.
+                // They go to this window's slot of the partial buffer (plain stores); k_dkv_gather sums, per token
+                // row, the slots of every window that reads it -- deterministic, no atomics on shared rows.
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    *(f32x4*)(Tk + l15 * ATT_T_STRIDE + 16 * dt + 4 * g) = dk[dt] * isc;
-                    *(f32x4*)(Tv + l15 * ATT_T_STRIDE + 16 * dt + 4 * g) = dv[dt] * isc;
-                }
-                wave_lds_sync();
+                for (int mt = 0; mt < 4; ++mt) bt[mt] = bn[mt];
+                if (ksrc[key] >= 0) {
+                    float* prow = dkv_part + ((long)wb * CFFM_NKEY_PAD + key) * 512 + h * CFFM_HD + 4 * g;
 #pragma unroll
-                for (int pss = 0; pss < 8; ++pss) {
-                    const int kl = 2 * pss + (lane >> 5), d = lane & 31;
-                    const int src = ksrc[16 * t + kl];
-                    if (src >= 0) {
-                        float* drow = dqkv + ((long)b * G.RC + src) * 768 + h * CFFM_HD + d;
-                        atomicAdd(drow + 256, Tk[kl * ATT_T_STRIDE + d]);
-                        atomicAdd(drow + 512, Tv[kl * ATT_T_STRIDE + d]);
+                    for (int dt = 0; dt < 2; ++dt) {
+                        *(f32x4*)(prow + 16 * dt) = dk[dt] * isc;
+                        *(f32x4*)(prow + 256 + 16 * dt) = dv[dt] * isc;
                     }
                 }
             }
@@ -404,4 +433,25 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                 }
         }
     }
+}
+
+// dqkv[b][row][256..767] = sum over the (window, key slot) pairs that read `row` of dkv_part[b*nW + window][slot][512];
+// inv_ptr [RC+1], inv_idx [nnz] = CSR inverse of key_src (per clip).  One wave per token row; pooled rows also get
+// their (unused) q third zeroed so the qkv weight/bias gradient GEMMs see zeros there.  grid (ceil(RC/4), B).
+__global__ void __launch_bounds__(256) k_dkv_gather(Geo G, const int* __restrict__ inv_ptr, const int* __restrict__ inv_idx,
+                                                     const float* __restrict__ dkv_part, float* __restrict__ dqkv) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (row >= G.RC) return;
+    const int e0 = inv_ptr[row], e1 = inv_ptr[row + 1];
+    const float* part = dkv_part + (long)b * G.nW * CFFM_NKEY_PAD * 512 + 8 * lane;
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    for (int e = e0; e < e1; ++e) {
+        const float* p = part + (long)inv_idx[e] * 512;
+        a0 += ld4(p);
+        a1 += ld4(p + 4);
+    }
+    float* drow = dqkv + ((long)b * G.RC + row) * 768;
+    *(f32x4*)(drow + 256 + 8 * lane) = a0;
+    *(f32x4*)(drow + 256 + 8 * lane + 4) = a1;
+    if (row >= CFFM_WA * G.nW) *(f32x4*)(drow + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }

@@ -64,3 +64,21 @@ def tables(h0, w0):
     key_src.setflags(write=False)
     q_dst.setflags(write=False)
     return key_src, q_dst
+
+
+@functools.lru_cache(maxsize=32)
+def inverse_tables(h0, w0):
+    """CSR inverse of ``key_src``: for every token row of a clip, the ``window * 304 + slot`` pairs whose key is
+    that row (ring / pooled keys are read by up to 49 windows; 12 ring positions twice by the same window).
+    -> (inv_ptr int32 [64 nW + 1], inv_idx int32 [nnz]); the dK/dV gather pass of the backward walks it."""
+    key_src, _ = tables(h0, w0)
+    nw = key_src.shape[0]
+    flat = key_src.reshape(-1)
+    slots = np.nonzero(flat >= 0)[0].astype(np.int32)
+    rows = flat[slots]
+    order = np.argsort(rows, kind='stable')
+    inv_idx = np.ascontiguousarray(slots[order])
+    counts = np.bincount(rows, minlength=64 * nw)
+    inv_ptr = np.zeros(64 * nw + 1, dtype=np.int32)
+    inv_ptr[1:] = np.cumsum(counts)
+    return inv_ptr, inv_idx

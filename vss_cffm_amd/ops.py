@@ -66,7 +66,8 @@ def device_tables(h0, w0, device):
     key = (h0, w0, str(device))
     if key not in _table_cache:
         ks, qd = geometry.tables(h0, w0)
-        _table_cache[key] = (torch.from_numpy(np.array(ks)).to(device), torch.from_numpy(np.array(qd)).to(device))
+        ip, ii = geometry.inverse_tables(h0, w0)
+        _table_cache[key] = tuple(torch.from_numpy(np.array(a)).to(device) for a in (ks, qd, ip, ii))
     return _table_cache[key]
 
 
@@ -105,7 +106,7 @@ class _LayerFn(torch.autograd.Function):
         x = x.contiguous()
         params = [p.detach().contiguous() for p in params]
         g = make_geom(lib, b, h0, w0)
-        key_src, q_dst = device_tables(h0, w0, x.device)
+        key_src, q_dst, inv_ptr, inv_idx = device_tables(h0, w0, x.device)
         saved = torch.empty(lib.cffm_layer_saved_floats(C.byref(g), depth), dtype=torch.float32, device=x.device)
         scratch = torch.empty(lib.cffm_layer_scratch_floats(C.byref(g)), dtype=torch.float32, device=x.device)
         y = torch.empty(b, 256, h0, w0, dtype=torch.float32, device=x.device)
@@ -113,14 +114,14 @@ class _LayerFn(torch.autograd.Function):
         _lib.check(lib.cffm_layer_forward(C.byref(g), depth, pstructs, _ptr(x), _ptr(y), _ptr(key_src), _ptr(q_dst),
                                           _ptr(saved), _ptr(scratch), _stream(x)), lib)
         ctx.depth, ctx.geom_args = depth, (b, h0, w0)
-        ctx.save_for_backward(saved, key_src, q_dst, *params)
+        ctx.save_for_backward(saved, key_src, q_dst, inv_ptr, inv_idx, *params)
         ctx.scratch = scratch
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.get()
-        saved, key_src, q_dst, *params = ctx.saved_tensors
+        saved, key_src, q_dst, inv_ptr, inv_idx, *params = ctx.saved_tensors
         depth = ctx.depth
         b, h0, w0 = ctx.geom_args
         g = make_geom(lib, b, h0, w0)
@@ -130,7 +131,8 @@ class _LayerFn(torch.autograd.Function):
         pstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(params[i * NPB:(i + 1) * NPB]) for i in range(depth)])
         gstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(grads[i * NPB:(i + 1) * NPB]) for i in range(depth)])
         _lib.check(lib.cffm_layer_backward(C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src),
-                                           _ptr(q_dst), _ptr(saved), _ptr(ctx.scratch), _stream(dy)), lib)
+                                           _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch),
+                                           _stream(dy)), lib)
         return (dx, None) + tuple(grads)
 
 
