@@ -17,8 +17,8 @@ def load_golden(name):
 
 def rel_err(a, b):
     """max|a-b| / max|b| -- the 'relative fp32 tolerance' of BASELINE.json's north_star."""
-    a = torch.as_tensor(a).double()
-    b = torch.as_tensor(b).double()
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 

@@ -49,4 +49,6 @@ def test_inverse_tables_are_the_inverse(h0, w0):
     for row in (0, 48, 49 * nw, 50 * nw + nw // 2, 64 * nw - 1):
         got = sorted(inv_idx[inv_ptr[row]:inv_ptr[row + 1]].tolist())
         assert got == sorted(np.nonzero(flat == row)[0].tolist())
-    assert (np.diff(inv_ptr) >= 1).all()           # every token row is read by at least one window
+    # some pooled cells are read by nobody (e.g. the last row of the stride-3 grid, off-centre unfold): their
+    # gradient is zero, the gather pass writes zeros for them
+    assert (np.diff(inv_ptr) >= 0).all() and (np.diff(inv_ptr)[:49 * nw] >= 1).all()

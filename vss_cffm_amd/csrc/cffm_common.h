@@ -131,6 +131,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
+// keeps the instruction scheduler from interleaving across this point (bounds register pressure of unrolled loops)
+__device__ __forceinline__ void sched_fence() {
+#ifndef CFFM_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 __device__ __forceinline__ float fast_exp(float x) {
 #ifdef CFFM_EMU
     return expf(x);

@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
                 }
                 bcur[0] = bnxt[0];
                 bcur[1] = bnxt[1];
+                sched_fence();
             }
             if (qcol < CFFM_WA) {
                 float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
