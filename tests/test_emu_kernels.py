@@ -138,8 +138,9 @@ def run_gtc_case(case, device):
     gg = R.synth_input('gg', (b, h * w, 256), seed=6, scale=1.0).to(device)
     y = m(x, h, w, c)[0]
     (y * gg).sum().backward()
-    assert H.rel_err(y.detach(), g['y']) < 1e-5            # fp32 VALU path: tight tolerance
-    assert H.rel_err(x.grad, g['dx']) < 2e-5 and H.rel_err(c.grad, g['dc']) < 2e-5
+    # fp32 VALU attention + split-bf16 GEMMs (2^-17 per product): an order tighter than the CFM path
+    assert H.rel_err(y.detach(), g['y']) < 5e-5
+    assert H.rel_err(x.grad, g['dx']) < 1e-4 and H.rel_err(c.grad, g['dc']) < 1e-4
     no_grad = set(str(s) for s in g['no_grad_keys'])
     pg = {}
     for kk, prm in m.named_parameters():
@@ -149,8 +150,8 @@ def run_gtc_case(case, device):
             pg[kk] = prm.grad
     for key, ref in g.items():
         if key.startswith('p/g/'):
-            assert H.rel_err(pg[key[4:]], ref) < 2e-5, key
+            assert H.rel_err(pg[key[4:]], ref) < 1e-4, key
         elif key.startswith('p/gsum0/'):
-            assert H.rel_err(pg[key[8:]].sum(0), ref) < 2e-5, key
+            assert H.rel_err(pg[key[8:]].sum(0), ref) < 1e-4, key
         elif key.startswith('p/gsum1/'):
-            assert H.rel_err(pg[key[8:]].sum(1), ref) < 2e-5, key
+            assert H.rel_err(pg[key[8:]].sum(1), ref) < 1e-4, key

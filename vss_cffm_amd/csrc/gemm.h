@@ -3,11 +3,48 @@
 // library are the CFFA / CFM path around them.  Row-major operands are mapped onto rocBLAS'
 // column-major interface by swapping operand roles (C^T = B^T A^T), never by copying.
 #pragma once
-#include "cffm_common.h"
+#include "gemm_kernels.h"
+
+// ---- hand-written split-bf16 MFMA path (default) -------------------------------------------------------------
+template <bool A_T, bool B_T>
+static int gemm_split_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int ksplit,
+                             hipStream_t st) {
+    int klen = ((K + ksplit - 1) / ksplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    ksplit = (K + klen - 1) / klen;
+    const int atomic_out = ksplit > 1;
+    if (atomic_out) (void)hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), st);
+    const unsigned gx = (N + GEMM_BN - 1) / GEMM_BN;
+    // 128-row tiles when they already fill the chip, 64-row tiles otherwise
+    if ((long)gx * ((M + 127) / 128) * ksplit >= 384) {
+        CFFM_LAUNCH((k_gemm_split<128, A_T, B_T>), (gx, (M + 127) / 128, ksplit), (256), GEMM_LDS(128), st, A, B, C, M, N, K, lda, ldb,
+                    ldc, klen, atomic_out, (const float*)nullptr);
+    } else {
+        CFFM_LAUNCH((k_gemm_split<64, A_T, B_T>), (gx, (M + 63) / 64, ksplit), (256), GEMM_LDS(64), st, A, B, C, M, N, K, lda, ldb, ldc,
+                    klen, atomic_out, (const float*)nullptr);
+    }
+    return 0;
+}
+// y[M,N] = x[M,K] w[N,K]^T
+static int gemm_nt_split(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, false>(x, w, y, (int)M, N, K, K, K, N, 1, st);
+}
+// dx[M,K] = dy[M,N] w[N,K]: output cols = K, contraction = N
+static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, true>(dy, w, dx, (int)M, K, N, N, K, K, 1, st);
+}
+// dw[N,K] = dy[M,N]^T x[M,K]: output N x K, contraction = M (long) split over workgroups
+static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
+    const int tiles = ((N + 127) / 128) * ((K + GEMM_BN - 1) / GEMM_BN);
+    int ksplit = (512 + tiles - 1) / tiles;
+    const int maxsplit = (int)((M + 4 * GEMM_BK - 1) / (4 * GEMM_BK));   // at least 4 K-tiles per split
+    if (ksplit > maxsplit) ksplit = maxsplit;
+    if (ksplit < 1) ksplit = 1;
+    return gemm_split_launch<true, true>(dy, x, dw, N, K, (int)M, N, K, K, ksplit, st);
+}
 
 #ifdef CFFM_EMU
 // TEST INFRASTRUCTURE (emulator build only): naive host loops standing in for rocBLAS.
-static int gemm_nt(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t) {
+static int gemm_nt_lib(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t) {
     for (long m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {
             double acc = 0;
@@ -16,7 +53,7 @@ static int gemm_nt(const float* x, const float* w, float* y, long M, int N, int 
         }
     return 0;
 }
-static int gemm_nn(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t) {
+static int gemm_nn_lib(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t) {
     for (long m = 0; m < M; ++m)
         for (int k = 0; k < K; ++k) {
             double acc = 0;
@@ -25,7 +62,7 @@ static int gemm_nn(const float* dy, const float* w, float* dx, long M, int N, in
         }
     return 0;
 }
-static int gemm_tn(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t) {
+static int gemm_tn_lib(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t) {
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) {
             double acc = 0;
@@ -45,24 +82,41 @@ static int gemm_ready(hipStream_t st) {
     return rocblas_set_stream(g_rocblas, st) == rocblas_status_success ? 0 : -1;
 }
 // y[M,N] = x[M,K] w[N,K]^T      (col-major: y^T[N,M] = w_cm^T[N,K] x_cm[K,M])
-static int gemm_nt(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
+static int gemm_nt_lib(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
     if (gemm_ready(st)) return -1;
     const float one = 1.f, zero = 0.f;
     return rocblas_sgemm(g_rocblas, rocblas_operation_transpose, rocblas_operation_none, N, (int)M, K, &one, w, K, x, K, &zero, y, N) ==
                    rocblas_status_success ? 0 : -1;
 }
 // dx[M,K] = dy[M,N] w[N,K]      (col-major: dx^T[K,M] = w_cm[K,N] dy_cm[N,M])
-static int gemm_nn(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
+static int gemm_nn_lib(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
     if (gemm_ready(st)) return -1;
     const float one = 1.f, zero = 0.f;
     return rocblas_sgemm(g_rocblas, rocblas_operation_none, rocblas_operation_none, K, (int)M, N, &one, w, K, dy, N, &zero, dx, K) ==
                    rocblas_status_success ? 0 : -1;
 }
 // dw[N,K] = dy[M,N]^T x[M,K]    (col-major: dw^T[K,N] = x_cm[K,M] dy_cm^T[M,N])
-static int gemm_tn(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
+static int gemm_tn_lib(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
     if (gemm_ready(st)) return -1;
     const float one = 1.f, zero = 0.f;
     return rocblas_sgemm(g_rocblas, rocblas_operation_none, rocblas_operation_transpose, K, N, (int)M, &one, x, K, dy, N, &zero, dw, K) ==
                    rocblas_status_success ? 0 : -1;
 }
 #endif
+
+// ---- dispatch: CFFM_GEMM=lib selects the exact-fp32 library path (rocBLAS SGEMM; host loops in the emulator build) --------
+#include <stdlib.h>
+static int gemm_use_lib() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFFM_GEMM"); v = (e && e[0] == 'l') ? 1 : 0; }
+    return v;
+}
+static int gemm_nt(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
+    return gemm_use_lib() ? gemm_nt_lib(x, w, y, M, N, K, st) : gemm_nt_split(x, w, y, M, N, K, st);
+}
+static int gemm_nn(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
+    return gemm_use_lib() ? gemm_nn_lib(dy, w, dx, M, N, K, st) : gemm_nn_split(dy, w, dx, M, N, K, st);
+}
+static int gemm_tn(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
+    return gemm_use_lib() ? gemm_tn_lib(dy, x, dw, M, N, K, st) : gemm_tn_split(dy, x, dw, M, N, K, st);
+}
