@@ -446,10 +446,25 @@ __global__ void __launch_bounds__(256) k_dkv_gather(Geo G, const int* __restrict
     const int e0 = inv_ptr[row], e1 = inv_ptr[row + 1];
     const float* part = dkv_part + (long)b * G.nW * CFFM_NKEY_PAD * 512 + 8 * lane;
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    for (int e = e0; e < e1; ++e) {
-        const float* p = part + (long)inv_idx[e] * 512;
-        a0 += ld4(p);
-        a1 += ld4(p + 4);
+    for (int eb = e0; eb < e1; eb += 64) {          // a row has at most 49 readers; the loop is for generality
+        const int n = (e1 - eb < 64) ? e1 - eb : 64;
+        const int mine = (lane < n) ? inv_idx[eb + lane] : 0;   // the whole reader list in one load
+        int e = 0;
+        for (; e + 3 < n; e += 4) {                 // 8 independent 16-B loads in flight per lane
+            const float* p0 = part + (long)__shfl(mine, e, 64) * 512;
+            const float* p1 = part + (long)__shfl(mine, e + 1, 64) * 512;
+            const float* p2 = part + (long)__shfl(mine, e + 2, 64) * 512;
+            const float* p3 = part + (long)__shfl(mine, e + 3, 64) * 512;
+            const f32x4 x0 = ld4(p0), y0 = ld4(p0 + 4), x1 = ld4(p1), y1 = ld4(p1 + 4);
+            const f32x4 x2 = ld4(p2), y2 = ld4(p2 + 4), x3 = ld4(p3), y3 = ld4(p3 + 4);
+            a0 += (x0 + x1) + (x2 + x3);
+            a1 += (y0 + y1) + (y2 + y3);
+        }
+        for (; e < n; ++e) {
+            const float* p = part + (long)__shfl(mine, e, 64) * 512;
+            a0 += ld4(p);
+            a1 += ld4(p + 4);
+        }
     }
     float* drow = dqkv + ((long)b * G.RC + row) * 768;
     *(f32x4*)(drow + 256 + 8 * lane) = a0;

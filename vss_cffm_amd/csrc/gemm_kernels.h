@@ -60,56 +60,97 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
 #define GEMM_BK 32
 #define GEMM_LD 40  // bf16 per LDS row (32 + 8 pad)
 
-// items of one operand tile per thread: ROWS*8 f32x4 chunks / 256 threads
-template <int ROWS, bool TR>
+// LDS image of an operand tile (ROWS x 32 k), hi and lo parts:
+//   k-contiguous operand (TR = false): [ROWS][GEMM_LD] bf16, fragment = one ds_read_b128 of 8 consecutive k;
+//   row-contiguous operand (TR = true): k-PAIR interleaved dwords [16 k-pairs][ROWS + 4]: a thread that loaded the same
+//     4 rows at k and k+1 (two coalesced 16-B loads) packs (k, k+1) per row into one dword and writes 16 B at once;
+//     a fragment is 4 x ds_read_b32 (k = 8g + 2jj + {0,1}), 16 lanes reading 16 consecutive dwords (conflict-free,
+//     the +4 pad puts the two lane groups of a half-wave on disjoint banks).
+#define GEMM_TS(ROWS) ((ROWS) + 4)
+template <int ROWS>
 struct TileRegs { f32x4 v[ROWS / 32]; };
 
-// global -> registers.  Non-transposed: chunk = 4 consecutive k of one row.  Transposed: chunk = 4 consecutive rows of one k.
+// global -> registers
 template <int ROWS, bool TR>
-__device__ __forceinline__ void tile_load(TileRegs<ROWS, TR>& r, const float* __restrict__ P, int ld, int row0, int nrows,
+__device__ __forceinline__ void tile_load(TileRegs<ROWS>& r, const float* __restrict__ P, int ld, int row0, int nrows,
                                           int k0, int kend, int tid) {
     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!TR) {
 #pragma unroll
-    for (int it = 0; it < ROWS / 32; ++it) {
-        const int item = tid + 256 * it;
-        if (!TR) {
+        for (int it = 0; it < ROWS / 32; ++it) {
+            const int item = tid + 256 * it;
             const int row = row0 + (item >> 3), k = k0 + 4 * (item & 7);
             r.v[it] = (row < nrows && k < kend) ? *(const f32x4*)(P + (long)row * ld + k) : z;   // kend, k multiples of 4
-        } else {
-            const int k = k0 + item / (ROWS / 4), row = row0 + 4 * (item % (ROWS / 4));
-            f32x4 v = z;
-            if (k < kend) {
-                if (row + 3 < nrows) v = *(const f32x4*)(P + (long)k * ld + row);
-                else
-                    for (int e = 0; e < 4; ++e)
-                        if (row + e < nrows) v[e] = P[(long)k * ld + row + e];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ROWS / 64; ++it) {
+            const int item = tid + 256 * it;
+            const int kp = item / (ROWS / 4), row = row0 + 4 * (item % (ROWS / 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + 2 * kp + h;
+                f32x4 v = z;
+                if (k < kend) {
+                    if (row + 3 < nrows) v = *(const f32x4*)(P + (long)k * ld + row);
+                    else
+                        for (int e = 0; e < 4; ++e)
+                            if (row + e < nrows) v[e] = P[(long)k * ld + row + e];
+                }
+                r.v[2 * it + h] = v;
             }
-            r.v[it] = v;
         }
     }
 }
 
-// registers -> LDS (split into hi / lo bf16 images [ROWS][GEMM_LD])
+__device__ __forceinline__ uint32_t pack_bf16(bf16 a, bf16 b) {
+    unsigned short ua, ub;
+    __builtin_memcpy(&ua, &a, 2);
+    __builtin_memcpy(&ub, &b, 2);
+    return (uint32_t)ua | ((uint32_t)ub << 16);
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// registers -> LDS (split into hi / lo bf16 images)
 template <int ROWS, bool TR>
-__device__ __forceinline__ void tile_store(const TileRegs<ROWS, TR>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid) {
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid) {
+    if (!TR) {
 #pragma unroll
-    for (int it = 0; it < ROWS / 32; ++it) {
-        const int item = tid + 256 * it;
-        bf16x4 h, l;
-        split4(r.v[it], h, l);
-        if (!TR) {
+        for (int it = 0; it < ROWS / 32; ++it) {
+            const int item = tid + 256 * it;
+            bf16x4 h, l;
+            split4(r.v[it], h, l);
             const int row = item >> 3, kc = 4 * (item & 7);
             *(bf16x4*)(hi + row * GEMM_LD + kc) = h;
             *(bf16x4*)(lo + row * GEMM_LD + kc) = l;
-        } else {
-            const int k = item / (ROWS / 4), row = 4 * (item % (ROWS / 4));
+        }
+    } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[(row + e) * GEMM_LD + k] = h[e];
-                lo[(row + e) * GEMM_LD + k] = l[e];
-            }
+        for (int it = 0; it < ROWS / 64; ++it) {
+            const int item = tid + 256 * it;
+            const int kp = item / (ROWS / 4), row = 4 * (item % (ROWS / 4));
+            bf16x4 h0, l0, h1, l1;
+            split4(r.v[2 * it], h0, l0);
+            split4(r.v[2 * it + 1], h1, l1);
+            u32x4 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ph[e] = pack_bf16(h0[e], h1[e]); pl[e] = pack_bf16(l0[e], l1[e]); }
+            *(u32x4*)((uint32_t*)hi + kp * GEMM_TS(ROWS) + row) = ph;
+            *(u32x4*)((uint32_t*)lo + kp * GEMM_TS(ROWS) + row) = pl;
         }
     }
+}
+
+// one MFMA operand fragment (8 k-slots of row `row`) out of an LDS image
+template <int ROWS, bool TR>
+__device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int row, int g) {
+    if (!TR) return *(const bf16x8*)(img + row * GEMM_LD + 8 * g);
+    u32x4 d;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) d[jj] = ((const uint32_t*)img)[(4 * g + jj) * GEMM_TS(ROWS) + row];
+    bf16x8 f;
+    __builtin_memcpy(&f, &d, 16);
+    return f;
 }
 
 #define GEMM_LDS(BM) ((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2)
@@ -135,8 +176,8 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    TileRegs<BM, A_T> ra;
-    TileRegs<GEMM_BN, B_T> rb;
+    TileRegs<BM> ra;
+    TileRegs<GEMM_BN> rb;
     tile_load<BM, A_T>(ra, A, lda, m0, M, kbeg, kend, tid);
     tile_load<GEMM_BN, B_T>(rb, B, ldb, n0, N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
@@ -150,13 +191,13 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
         bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bh[j] = *(const bf16x8*)(Bh + (wc + 16 * j + l15) * GEMM_LD + 8 * g);
-            bl[j] = *(const bf16x8*)(Bl + (wc + 16 * j + l15) * GEMM_LD + 8 * g);
+            bh[j] = frag_read<GEMM_BN, B_T>(Bh, wc + 16 * j + l15, g);
+            bl[j] = frag_read<GEMM_BN, B_T>(Bl, wc + 16 * j + l15, g);
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const bf16x8 ah = *(const bf16x8*)(Ah + (wr + 16 * i + l15) * GEMM_LD + 8 * g);
-            const bf16x8 al = *(const bf16x8*)(Al + (wr + 16 * i + l15) * GEMM_LD + 8 * g);
+            const bf16x8 ah = frag_read<BM, A_T>(Ah, wr + 16 * i + l15, g);
+            const bf16x8 al = frag_read<BM, A_T>(Al, wr + 16 * i + l15, g);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
