@@ -174,7 +174,7 @@ long cffm_layer_scratch_floats(const cffm_geom* g) { return scratch_layout(g).to
 // (grows on demand; stream-ordered reuse, one stream at a time as the ABI's threading rule says).
 static float* g_scr = nullptr;
 static size_t g_scr_floats = 0;
-static float* lib_scratch(size_t nfloats) {
+extern "C++" __attribute__((visibility("hidden"))) float* lib_scratch(size_t nfloats) {
     if (nfloats <= g_scr_floats) return g_scr;
 #ifdef CFFM_EMU
     free(g_scr);

@@ -6,21 +6,32 @@
 #include "gemm_kernels.h"
 
 // ---- hand-written split-bf16 MFMA path (default) -------------------------------------------------------------
+float* lib_scratch(size_t nfloats);   // cffm_hip.hip: library-owned device scratch (grows on demand)
+__global__ void k_sum_splits(const float* __restrict__ part, int nsplit, long n, float* __restrict__ out);
+
 template <bool A_T, bool B_T>
 static int gemm_split_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int ksplit,
                              hipStream_t st) {
     int klen = ((K + ksplit - 1) / ksplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
     ksplit = (K + klen - 1) / klen;
-    const int atomic_out = ksplit > 1;
-    if (atomic_out) (void)hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), st);
+    float* out = C;
+    const long split_stride = (long)M * ldc;
+    if (ksplit > 1) {
+        out = lib_scratch((size_t)ksplit * split_stride);
+        if (!out) return -1;
+    }
     const unsigned gx = (N + GEMM_BN - 1) / GEMM_BN;
     // 128-row tiles when they already fill the chip, 64-row tiles otherwise
     if ((long)gx * ((M + 127) / 128) * ksplit >= 384) {
-        CFFM_LAUNCH((k_gemm_split<128, A_T, B_T>), (gx, (M + 127) / 128, ksplit), (256), GEMM_LDS(128), st, A, B, C, M, N, K, lda, ldb,
-                    ldc, klen, atomic_out, (const float*)nullptr);
+        CFFM_LAUNCH((k_gemm_split<128, A_T, B_T>), (gx, (M + 127) / 128, ksplit), (256), GEMM_LDS(128), st, A, B, out, M, N, K, lda, ldb,
+                    ldc, klen, split_stride, (const float*)nullptr);
     } else {
-        CFFM_LAUNCH((k_gemm_split<64, A_T, B_T>), (gx, (M + 63) / 64, ksplit), (256), GEMM_LDS(64), st, A, B, C, M, N, K, lda, ldb, ldc,
-                    klen, atomic_out, (const float*)nullptr);
+        CFFM_LAUNCH((k_gemm_split<64, A_T, B_T>), (gx, (M + 63) / 64, ksplit), (256), GEMM_LDS(64), st, A, B, out, M, N, K, lda, ldb, ldc,
+                    klen, split_stride, (const float*)nullptr);
+    }
+    if (ksplit > 1) {
+        const long n4 = split_stride / 4;
+        CFFM_LAUNCH(k_sum_splits, ((unsigned)((n4 + 255) / 256)), (256), 0, st, (const float*)out, ksplit, split_stride, C);
     }
     return 0;
 }
@@ -35,7 +46,7 @@ static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int
 // dw[N,K] = dy[M,N]^T x[M,K]: output N x K, contraction = M (long) split over workgroups
 static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
     const int tiles = ((N + 127) / 128) * ((K + GEMM_BN - 1) / GEMM_BN);
-    int ksplit = (512 + tiles - 1) / tiles;
+    int ksplit = (384 + tiles - 1) / tiles;
     const int maxsplit = (int)((M + 4 * GEMM_BK - 1) / (4 * GEMM_BK));   // at least 4 K-tiles per split
     if (ksplit > maxsplit) ksplit = maxsplit;
     if (ksplit < 1) ksplit = 1;

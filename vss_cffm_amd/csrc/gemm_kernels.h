@@ -16,7 +16,8 @@
 // Tiles: BM x 128 x 32 per 256-thread workgroup (2x2 waves, each (BM/2) x 64 as 16x16x32 MFMA tiles), LDS rows
 // padded to 80 B (conflict-free ds_read_b128 fragments), next K-tile prefetched into registers while the
 // current one is multiplied.  The weight-gradient form splits its long contraction (M ~ 10^4) over
-// gridDim.z and accumulates with fp32 atomics into the zeroed output.
+// gridDim.z: every split writes its own partial output (plain coalesced stores) and a second tiny kernel sums
+// them -- deterministic, and row-coalesced fp32 atomics measured 3-4x slower than this on gfx950.
 #pragma once
 #include "cffm_common.h"
 
@@ -56,9 +57,13 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
     }
 }
 
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0  // profiling only: 1 = no MFMA, 2 = no global loads in the loop, 4 = no LDS staging in the loop
+#endif
 #define GEMM_BN 128
 #define GEMM_BK 32
 #define GEMM_LD 40  // bf16 per LDS row (32 + 8 pad)
+#define GEMM_TLD 68 // floats per row of the epilogue transposition tile (64 + 4 pad)
 
 // LDS image of an operand tile (ROWS x 32 k), hi and lo parts:
 //   k-contiguous operand (TR = false): [ROWS][GEMM_LD] bf16, fragment = one ds_read_b128 of 8 consecutive k;
@@ -153,12 +158,12 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
     return f;
 }
 
-#define GEMM_LDS(BM) ((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2)
+#define GEMM_LDS(BM) (((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2) : (4 * 32 * GEMM_TLD * 4))
 
 // grid (ceil(N/128), ceil(M/BM), ksplit).  K range of split z: [z*klen, min(K, (z+1)*klen)), klen multiple of 32.
 template <int BM, bool A_T, bool B_T>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                     int M, int N, int K, int lda, int ldb, int ldc, int klen, int atomic_out,
+                                                     int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                                      const float* __restrict__ bias) {
     CFFM_DYN_SMEM(smem);
     bf16* Ah = (bf16*)smem;
@@ -181,10 +186,12 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
     tile_load<BM, A_T>(ra, A, lda, m0, M, kbeg, kend, tid);
     tile_load<GEMM_BN, B_T>(rb, B, ldb, n0, N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-        tile_store<BM, A_T>(ra, Ah, Al, tid);
-        tile_store<GEMM_BN, B_T>(rb, Bh, Bl, tid);
+        if (!(GEMM_ABLATE & 4) || k0 == kbeg) {
+            tile_store<BM, A_T>(ra, Ah, Al, tid);
+            tile_store<GEMM_BN, B_T>(rb, Bh, Bl, tid);
+        }
         __syncthreads();
-        if (k0 + GEMM_BK < kend) {  // next K-tile flies while this one is multiplied
+        if (k0 + GEMM_BK < kend && !(GEMM_ABLATE & 2)) {  // next K-tile flies while this one is multiplied
             tile_load<BM, A_T>(ra, A, lda, m0, M, k0 + GEMM_BK, kend, tid);
             tile_load<GEMM_BN, B_T>(rb, B, ldb, n0, N, k0 + GEMM_BK, kend, tid);
         }
@@ -200,6 +207,7 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
             const bf16x8 al = frag_read<BM, A_T>(Al, wr + 16 * i + l15, g);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (GEMM_ABLATE & 1) { acc[i][j][0] += (float)ah[0] + (float)bl[j][0] + (float)al[1] + (float)bh[j][1]; continue; }
                 acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
                 acc[i][j] = mfma16x16x32_bf16(al, bh[j], acc[i][j]);
                 acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
@@ -207,21 +215,37 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
         }
         __syncthreads();
     }
-    // epilogue: acc[i][j][r] = C[m0 + wr + 16i + 4g + r][n0 + wc + 16j + l15]
+    // epilogue: acc[i][j][r] = C[m0 + wr + 16i + 4g + r][n0 + wc + 16j + l15].  Stored straight from the MFMA layout a
+    // store instruction would touch 4 rows x 64 B; instead each wave transposes 32 rows x 64 columns at a time through
+    // its own LDS slice (the K-loop's operand images are dead) and writes whole 256-byte row segments as 16-B stores
+    float* T = (float*)smem + wave * (32 * GEMM_TLD);
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int half = 0; half < MT / 2; ++half) {
+        wave_lds_sync();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wc + 16 * j + l15;
-            if (col >= N) continue;
-            const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wr + 16 * i + 4 * g + r;
-                if (row >= M) continue;
-                float* dst = C + (long)row * ldc + col;
-                if (atomic_out) atomicAdd(dst, acc[i][j][r] + bv);
-                else *dst = acc[i][j][r] + bv;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[(16 * ii + 4 * g + r) * GEMM_TLD + 16 * j + l15] = acc[2 * half + ii][j][r];
+        wave_lds_sync();
+        const int c4 = 4 * (lane & 15), col = n0 + wc + c4;
+        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias && blockIdx.z == 0 && col + 3 < N) bv = *(const f32x4*)(bias + col);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = (lane >> 4) + 4 * it, row = m0 + wr + 32 * half + rl;
+            if (row >= M) continue;
+            const f32x4 v = *(const f32x4*)(T + rl * GEMM_TLD + c4) + bv;
+            float* dst = C + (long)blockIdx.z * split_stride + (long)row * ldc + col;
+            if (col + 3 < N) {
+                *(f32x4*)dst = v;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) {
+                        dst[e] = v[e] + ((bias && blockIdx.z == 0 && col + 3 >= N) ? bias[col + e] : 0.f);
+                    }
             }
         }
+    }
 }

@@ -240,3 +240,14 @@ __global__ void __launch_bounds__(256) k_add_inplace(float* __restrict__ a, cons
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256)
         ((f32x4*)a)[e] += ((const f32x4*)b)[e];
 }
+
+// out[i] = sum_s part[s*n + i] (f32x4; n multiple of 4): combines the split-K partial outputs of the weight-gradient GEMMs
+__global__ void __launch_bounds__(256) k_sum_splits(const float* __restrict__ part, int nsplit, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i * 4 >= n) return;
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
+    int s = 0;
+    for (; s + 1 < nsplit; s += 2) { a += ((const f32x4*)(part + (long)s * n))[i]; b += ((const f32x4*)(part + (long)(s + 1) * n))[i]; }
+    if (s < nsplit) a += ((const f32x4*)(part + (long)s * n))[i];
+    ((f32x4*)out)[i] = a + b;
+}
