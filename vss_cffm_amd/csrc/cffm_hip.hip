@@ -43,7 +43,7 @@ static Geo to_geo(const cffm_geom* g) {
 enum { ST_TRANSPOSE, ST_POOLMAT, ST_LN_POOL_FWD, ST_LN_POOL_BWD, ST_BIAS_ASM, ST_BIAS_SCT, ST_ATTN_FWD, ST_ATTN_BWD,
        ST_GEMM, ST_COLSUM, ST_RES_LN, ST_LN_BWD, ST_GELU, ST_GELU_BWD, ST_RES_OUT, ST_GTC_FWD, ST_GTC_BWD, ST_LN, ST_COUNT };
 static const char* const k_stage_names[ST_COUNT] = {"transpose", "pool_matrix", "ln_pool_fwd", "ln_pool_bwd", "bias_assemble",
-    "bias_scatter", "cfm_attn_fwd", "cfm_attn_bwd", "gemm_rocblas", "colsum", "residual_ln", "ln_bwd", "bias_gelu", "gelu_bwd",
+    "bias_scatter", "cfm_attn_fwd", "cfm_attn_bwd", "linear_gemm", "colsum", "residual_ln", "ln_bwd", "bias_gelu", "gelu_bwd",
     "residual_out", "gtc_attn_fwd", "gtc_attn_bwd", "layernorm"};
 #ifndef CFFM_EMU
 #include <vector>
