@@ -104,6 +104,11 @@ int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, cons
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream);
 int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream);
 int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream);
+/* fused Mlp halves: hraw = x w^T (raw, kept for backward), act = gelu(hraw + b)  |  out = res + x w^T + b */
+int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K,
+                         void* stream);
+int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, const float* res, float* out, long M, int N,
+                             int K, void* stream);
 int cffm_colsum(const float* a, long rows, int cols, float* out /* overwritten */, void* stream);
 int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
                      const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,

@@ -57,6 +57,8 @@ SIGNATURES = {
     'cffm_linear_fwd': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_input': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_gelu_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_residual_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_colsum': (ci, [vp, cl, ci, vp, vp]),
     'cffm_residual_ln': (ci, [vp, cl, ci, vp, vp, vp, vp, vp, vp, vp, vp, cl, vp]),
     'cffm_ln_bwd_residual': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp, vp, vp]),

@@ -147,13 +147,25 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
     f32x4 acc[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int i = wave; i < CFFM_WA; i += 4) {
+    // the wave's 12-13 pixel rows (1 KiB each) are all requested before the first is consumed
+    f32x4 xr[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const int i = wave + 4 * k;
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        xr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < CFFM_WA && y < G.H0 && x < G.W0) xr[k] = *(const f32x4*)(xf + ((long)y * G.W0 + x) * CFFM_C + 4 * lane);
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const int i = wave + 4 * k;
+        if (i >= CFFM_WA) break;
         const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
         const bool valid = (y < G.H0) && (x < G.W0);  // wave-uniform
         f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (valid) {
             const long pix = (long)y * G.W0 + x;
-            const f32x4 xv = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
+            const f32x4 xv = xr[k];
             const float mu = wave_sum(xv[0] + xv[1] + xv[2] + xv[3]) * (1.f / CFFM_C);
             const f32x4 d = xv - mu;
             const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / CFFM_C);
@@ -222,17 +234,36 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
     const bool accum = (frame == 3) ? false : (accum_ref != 0);
     const f32x4 gm = *(const f32x4*)(gamma + 4 * lane), bt = *(const f32x4*)(beta + 4 * lane);
     f32x4 ag = (f32x4){0.f, 0.f, 0.f, 0.f}, ab = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int i = wave; i < CFFM_WA; i += 4) {
+    // all global reads of the wave's 12-13 pixels (x rows, LN statistics, target-token gradients) are requested first
+    f32x4 xr[13], dzr[13];
+    float mur[13], rsr[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const int i = wave + 4 * k;
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        xr[k] = dzr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mur[k] = rsr[k] = 0.f;
+        if (i < CFFM_WA && y < G.H0 && x < G.W0) {
+            const long pix = (long)y * G.W0 + x;
+            xr[k] = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
+            mur[k] = mean_in[((long)b * 4 + frame) * G.HW + pix];
+            rsr[k] = rstd_in[((long)b * 4 + frame) * G.HW + pix];
+            if (frame == 3) {
+                dzr[k] = *(const f32x4*)(dzall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const int i = wave + 4 * k;
+        if (i >= CFFM_WA) break;
         const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
         if (!((y < G.H0) && (x < G.W0))) continue;  // padded pixel: z is the constant 0
         const long pix = (long)y * G.W0 + x;
-        const f32x4 xv = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
-        const float mu = mean_in[((long)b * 4 + frame) * G.HW + pix];
-        const float rs = rstd_in[((long)b * 4 + frame) * G.HW + pix];
-        const f32x4 xh = (xv - mu) * rs;
+        const float rs = rsr[k];
+        const f32x4 xh = (xr[k] - mur[k]) * rs;
         const f32x4 z = xh * gm + bt;
-        f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (frame == 3) dz = *(const f32x4*)(dzall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane);
+        f32x4 dz = dzr[k];
         for (int c = 0; c < ncell; ++c) {
             const f32x4 dp = *(const f32x4*)(&sdP[c][4 * lane]);
             dz += sM[c * CFFM_WA + i] * dp;
@@ -268,15 +299,3 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
     }
 }
 
-// last stage of the ln_pool_bwd reduction: tmp[nsl][LNP_REC] -> dgamma, dbeta, dM and the 4 pool-bias gradients
-__global__ void __launch_bounds__(256) k_lnp_finish(const float* __restrict__ tmp, int nsl, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ dM, PoolBG dpb) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= LNP_REC) return;
-    float s = 0.f;
-    for (int b = 0; b < nsl; ++b) s += tmp[(long)b * LNP_REC + c];
-    if (c < CFFM_C) dgamma[c] = s;
-    else if (c < 2 * CFFM_C) dbeta[c - CFFM_C] = s;
-    else if (c < 2 * CFFM_C + CFFM_NCELL * CFFM_WA) dM[c - 2 * CFFM_C] = s;
-    else dpb.b[c - 2 * CFFM_C - CFFM_NCELL * CFFM_WA][0] = s;
-}

@@ -131,6 +131,22 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
+// streaming (non-temporal) 16-byte store / load: data written once and read once by a later kernel must not
+// push the L2-resident gather working set (one head's q/k/v slice per XCD) out of the 4 MiB L2
+__device__ __forceinline__ void st4_stream(float* p, f32x4 v) {
+#ifdef CFFM_EMU
+    *(f32x4*)p = v;
+#else
+    __builtin_nontemporal_store(v, (f32x4*)p);
+#endif
+}
+__device__ __forceinline__ f32x4 ld4_stream(const float* p) {
+#ifdef CFFM_EMU
+    return *(const f32x4*)p;
+#else
+    return __builtin_nontemporal_load((const f32x4*)p);
+#endif
+}
 // keeps the instruction scheduler from interleaving across this point (bounds register pressure of unrolled loops)
 __device__ __forceinline__ void sched_fence() {
 #ifndef CFFM_EMU

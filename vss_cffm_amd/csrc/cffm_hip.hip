@@ -186,17 +186,13 @@ extern "C++" __attribute__((visibility("hidden"))) float* lib_scratch(size_t nfl
     g_scr_floats = g_scr ? nfloats : 0;
     return g_scr;
 }
-#define RED_SLICES 32
-// out[width] (+)= sum over nblk records of `part` (record stride `stride`); tmp: RED_SLICES*width floats
-static int reduce_records(const float* part, int nblk, int width, int stride, float* out, int accumulate, float* tmp, hipStream_t st) {
-    const unsigned gx = (width + 255) / 256;
-    if (nblk <= 2 * RED_SLICES) {
-        CFFM_LAUNCH(k_reduce_partials, (gx, 1), (256), 0, st, part, nblk, width, stride, out, accumulate);
-    } else {
-        CFFM_LAUNCH(k_reduce_partials, (gx, RED_SLICES), (256), 0, st, part, nblk, width, stride, tmp, 0);
-        CFFM_LAUNCH(k_reduce_partials, (gx, 1), (256), 0, st, (const float*)tmp, RED_SLICES, width, width, out, accumulate);
-    }
-    return 0;
+static void seg_add(RedSegs& r, int off, int width, float* out, int accumulate) {
+    if (!out) return;
+    const int k = r.nseg++;
+    r.off[k] = off; r.width[k] = width; r.out[k] = out; r.accumulate[k] = accumulate;
+}
+static void reduce_records(const float* part, int nblk, int stride, int total, const RedSegs& segs, hipStream_t st) {
+    CFFM_LAUNCH(k_reduce_records, ((total + 63) / 64), (256), 0, st, part, nblk, stride, total, segs);
 }
 
 // ------------------------------------------------------------------------------------------- stages
@@ -250,20 +246,17 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
     PoolBG pb;
     for (int i = 0; i < 4; ++i) pb.b[i] = dpool_b[i];
     const int nblk = g->nW * 4 * g->B;
-    float* part = lib_scratch((size_t)(nblk + RED_SLICES) * LNP_REC);
+    float* part = lib_scratch((size_t)nblk * LNP_REC);
     REQUIRE(part, "ln_pool_bwd: scratch allocation failed");
-    float* tmp = part + (size_t)nblk * LNP_REC;
     CFFM_LAUNCH(k_ln_pool_bwd, (g->nW, 4, g->B), (256), 0, st, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma, beta, M, mean, rstd,
                 dzall, dres, dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, part);
-    int nsl = nblk < RED_SLICES ? 1 : RED_SLICES;
-    const float* last = part;
-    int nlast = nblk;
-    if (nblk > RED_SLICES) {
-        CFFM_LAUNCH(k_reduce_partials, ((LNP_REC + 255) / 256, nsl), (256), 0, st, (const float*)part, nblk, LNP_REC, LNP_REC, tmp, 0);
-        last = tmp;
-        nlast = nsl;
-    }
-    CFFM_LAUNCH(k_lnp_finish, ((LNP_REC + 255) / 256), (256), 0, st, last, nlast, dgamma, dbeta, dM, pb);
+    RedSegs segs;
+    segs.nseg = 0;
+    seg_add(segs, 0, CFFM_C, dgamma, 0);
+    seg_add(segs, CFFM_C, CFFM_C, dbeta, 0);
+    seg_add(segs, 2 * CFFM_C, CFFM_NCELL * CFFM_WA, dM, 0);
+    for (int i = 0; i < 4; ++i) seg_add(segs, 2 * CFFM_C + CFFM_NCELL * CFFM_WA + i, 1, pb.b[i], 0);
+    reduce_records(part, nblk, LNP_REC, LNP_REC, segs, st);
     CHECK_LAUNCH("ln_pool_bwd");
     return 0;
 }
@@ -335,16 +328,42 @@ int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, i
     return gemm_tn(dy, x, dw, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_weight: gemm failed") : 0;
 }
 
+// fused Mlp halves (one launch each on the hand-written GEMM; the exact-fp32 library path sequences the unfused stages)
+int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K, void* stream) {
+    if (gemm_use_lib()) {
+        TRY(cffm_linear_fwd(x, w, hraw, M, N, K, stream));
+        return cffm_bias_gelu(hraw, b, act, M, N, stream);
+    }
+    PROF(ST_GEMM);
+    REQUIRE(N % 4 == 0, "linear_gelu_fwd: N %% 4");
+    return gemm_nt_gelu_split(x, w, b, hraw, act, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_gelu_fwd: gemm failed") : 0;
+}
+int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, const float* res, float* out, long M, int N, int K,
+                             void* stream) {
+    if (gemm_use_lib()) {
+        float* tmp = lib_scratch((size_t)M * N);
+        REQUIRE(tmp && N == CFFM_C, "linear_residual_fwd: library path needs N == 256");
+        TRY(cffm_linear_fwd(x, w, tmp, M, N, K, stream));
+        return cffm_residual_out(res, tmp, b, out, M, stream);
+    }
+    PROF(ST_GEMM);
+    REQUIRE(N % 4 == 0, "linear_residual_fwd: N %% 4");
+    return gemm_nt_residual_split(x, w, b, res, out, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_residual_fwd: gemm failed") : 0;
+}
+
 int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
     PROF(ST_COLSUM);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(cols % 256 == 0, "colsum: cols must be a multiple of 256");
     int slices = (int)((rows + 31) / 32);
     if (slices > 256) slices = 256;
-    float* part = lib_scratch((size_t)(slices + RED_SLICES) * cols);
+    float* part = lib_scratch((size_t)slices * cols);
     REQUIRE(part, "colsum: scratch allocation failed");
     CFFM_LAUNCH(k_colsum_partial, (cols / 256, slices), (256), 0, st, a, rows, cols, part);
-    reduce_records(part, slices, cols, cols, out, 0, part + (size_t)slices * cols, st);
+    RedSegs segs;
+    segs.nseg = 0;
+    seg_add(segs, 0, cols, out, 0);
+    reduce_records(part, slices, cols, cols, segs, st);
     CHECK_LAUNCH("colsum");
     return 0;
 }
@@ -366,14 +385,16 @@ int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, 
     hipStream_t st = (hipStream_t)stream;
     const int rpb = 32;
     const int nblk = (int)((nrows + rpb - 1) / rpb);
-    float* part = lib_scratch((size_t)(nblk + RED_SLICES) * 1024);
+    float* part = lib_scratch((size_t)nblk * 1024);
     REQUIRE(part, "ln_bwd_residual: scratch allocation failed");
-    float* tmp = part + (size_t)nblk * 1024;
     CFFM_LAUNCH(k_ln_bwd_residual, (nblk), (256), 0, st, x1, mean, rstd, gamma, dz2, dres, dx1, part, nrows, rpb);
-    reduce_records(part, nblk, CFFM_C, 1024, dgamma, !zero_grads, tmp, st);
-    reduce_records(part + CFFM_C, nblk, CFFM_C, 1024, dbeta, !zero_grads, tmp + RED_SLICES * CFFM_C, st);
-    if (dres_colsum) reduce_records(part + 2 * CFFM_C, nblk, CFFM_C, 1024, dres_colsum, 0, tmp + 2 * RED_SLICES * CFFM_C, st);
-    if (dx1_colsum) reduce_records(part + 3 * CFFM_C, nblk, CFFM_C, 1024, dx1_colsum, 0, tmp + 3 * RED_SLICES * CFFM_C, st);
+    RedSegs segs;
+    segs.nseg = 0;
+    seg_add(segs, 0, CFFM_C, dgamma, !zero_grads);
+    seg_add(segs, CFFM_C, CFFM_C, dbeta, !zero_grads);
+    seg_add(segs, 2 * CFFM_C, CFFM_C, dres_colsum, 0);
+    seg_add(segs, 3 * CFFM_C, CFFM_C, dx1_colsum, 0);
+    reduce_records(part, nblk, 1024, 1024, segs, st);
     CHECK_LAUNCH("ln_bwd_residual");
     return 0;
 }
@@ -399,11 +420,16 @@ int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, in
     const int nblk = (int)((rows + rpb - 1) / rpb);
     float* part = nullptr;
     if (db1) {
-        part = lib_scratch((size_t)(nblk + RED_SLICES) * CFFM_HID);
+        part = lib_scratch((size_t)nblk * CFFM_HID);
         REQUIRE(part, "gelu_bwd: scratch allocation failed");
     }
     CFFM_LAUNCH(k_gelu_bwd, (nblk), (256), 0, st, hraw, b1, dact, part, rows, rpb);
-    if (db1) reduce_records(part, nblk, CFFM_HID, CFFM_HID, db1, 0, part + (size_t)nblk * CFFM_HID, st);
+    if (db1) {
+        RedSegs segs;
+        segs.nseg = 0;
+        seg_add(segs, 0, CFFM_HID, db1, 0);
+        reduce_records(part, nblk, CFFM_HID, CFFM_HID, segs, st);
+    }
     CHECK_LAUNCH("gelu_bwd");
     return 0;
 }
@@ -465,10 +491,8 @@ int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const flo
     TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_residual_ln(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
                          ws + L.mean2, ws + L.rstd2, NP, stream));
-    TRY(cffm_linear_fwd(ws + L.z2, p->fc1_w, ws + L.hraw, NP, CFFM_HID, CFFM_C, stream));
-    TRY(cffm_bias_gelu(ws + L.hraw, p->fc1_b, ws + L.act, NP, CFFM_HID, stream));
-    TRY(cffm_linear_fwd(ws + L.act, p->fc2_w, yraw, NP, CFFM_C, CFFM_HID, stream));
-    TRY(cffm_residual_out(ws + L.x1, yraw, p->fc2_b, ws + L.x2, NP, stream));
+    TRY(cffm_linear_gelu_fwd(ws + L.z2, p->fc1_w, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, stream));
+    TRY(cffm_linear_residual_fwd(ws + L.act, p->fc2_w, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, stream));
     return 0;
 }
 

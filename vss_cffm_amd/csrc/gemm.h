@@ -9,9 +9,9 @@
 float* lib_scratch(size_t nfloats);   // cffm_hip.hip: library-owned device scratch (grows on demand)
 __global__ void k_sum_splits(const float* __restrict__ part, int nsplit, long n, float* __restrict__ out);
 
-template <bool A_T, bool B_T>
+template <bool A_T, bool B_T, int EPI = 0>
 static int gemm_split_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int ksplit,
-                             hipStream_t st) {
+                             hipStream_t st, const float* bias = nullptr, float* aux = nullptr) {
     int klen = ((K + ksplit - 1) / ksplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
     ksplit = (K + klen - 1) / klen;
     float* out = C;
@@ -23,11 +23,11 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
     const unsigned gx = (N + GEMM_BN - 1) / GEMM_BN;
     // 128-row tiles when they already fill the chip, 64-row tiles otherwise
     if ((long)gx * ((M + 127) / 128) * ksplit >= 384) {
-        CFFM_LAUNCH((k_gemm_split<128, A_T, B_T>), (gx, (M + 127) / 128, ksplit), (256), GEMM_LDS(128), st, A, B, out, M, N, K, lda, ldb,
-                    ldc, klen, split_stride, (const float*)nullptr);
+        CFFM_LAUNCH((k_gemm_split<128, A_T, B_T, EPI>), (gx, (M + 127) / 128, ksplit), (256), GEMM_LDS(128), st, A, B, out, M, N, K, lda,
+                    ldb, ldc, klen, split_stride, bias, aux);
     } else {
-        CFFM_LAUNCH((k_gemm_split<64, A_T, B_T>), (gx, (M + 63) / 64, ksplit), (256), GEMM_LDS(64), st, A, B, out, M, N, K, lda, ldb, ldc,
-                    klen, split_stride, (const float*)nullptr);
+        CFFM_LAUNCH((k_gemm_split<64, A_T, B_T, EPI>), (gx, (M + 63) / 64, ksplit), (256), GEMM_LDS(64), st, A, B, out, M, N, K, lda, ldb,
+                    ldc, klen, split_stride, bias, aux);
     }
     if (ksplit > 1) {
         const long n4 = split_stride / 4;
@@ -38,6 +38,15 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
 // y[M,N] = x[M,K] w[N,K]^T
 static int gemm_nt_split(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
     return gemm_split_launch<false, false>(x, w, y, (int)M, N, K, K, K, N, 1, st);
+}
+// hraw[M,N] = x w^T (raw, kept for backward), act = gelu(hraw + b)      (fc1 of the Mlp, cffm_transformer.py:21-22)
+static int gemm_nt_gelu_split(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, false, 1>(x, w, hraw, (int)M, N, K, K, K, N, 1, st, b, act);
+}
+// out[M,N] = res + x w^T + b                                             (fc2 + residual, cffm_transformer.py:824)
+static int gemm_nt_residual_split(const float* x, const float* w, const float* b, const float* res, float* out, long M, int N, int K,
+                                  hipStream_t st) {
+    return gemm_split_launch<false, false, 2>(x, w, out, (int)M, N, K, K, K, N, 1, st, b, const_cast<float*>(res));
 }
 // dx[M,K] = dy[M,N] w[N,K]: output cols = K, contraction = N
 static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {

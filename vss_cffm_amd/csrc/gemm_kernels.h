@@ -161,10 +161,11 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
 #define GEMM_LDS(BM) (((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2) : (4 * 32 * GEMM_TLD * 4))
 
 // grid (ceil(N/128), ceil(M/BM), ksplit).  K range of split z: [z*klen, min(K, (z+1)*klen)), klen multiple of 32.
-template <int BM, bool A_T, bool B_T>
+// EPI: 0 plain (+bias) | 1 GELU: C = raw product (saved for backward), aux = gelu(raw + bias) | 2 residual: C = aux + raw + bias
+template <int BM, bool A_T, bool B_T, int EPI>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
-                                                     const float* __restrict__ bias) {
+                                                     const float* __restrict__ bias, float* __restrict__ aux) {
     CFFM_DYN_SMEM(smem);
     bf16* Ah = (bf16*)smem;
     bf16* Al = Ah + BM * GEMM_LD;
@@ -236,8 +237,20 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
         for (int it = 0; it < 8; ++it) {
             const int rl = (lane >> 4) + 4 * it, row = m0 + wr + 32 * half + rl;
             if (row >= M) continue;
-            const f32x4 v = *(const f32x4*)(T + rl * GEMM_TLD + c4) + bv;
+            f32x4 v = *(const f32x4*)(T + rl * GEMM_TLD + c4);
             float* dst = C + (long)blockIdx.z * split_stride + (long)row * ldc + col;
+            if (EPI == 1 && col + 3 < N) {          // N % 4 == 0 for every fused use
+                *(f32x4*)dst = v;
+                f32x4 a;
+                for (int e = 0; e < 4; ++e) a[e] = gelu_erf(v[e] + bv[e]);
+                *(f32x4*)(aux + (long)row * ldc + col) = a;
+                continue;
+            }
+            if (EPI == 2 && col + 3 < N) {
+                *(f32x4*)dst = *(const f32x4*)(aux + (long)row * ldc + col) + v + bv;
+                continue;
+            }
+            v += bv;
             if (col + 3 < N) {
                 *(f32x4*)dst = v;
             } else {

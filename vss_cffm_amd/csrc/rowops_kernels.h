@@ -165,24 +165,37 @@ __global__ void __launch_bounds__(256) k_ln_bwd_residual(const float* __restrict
         part[(long)blockIdx.x * 1024 + k * CFFM_C + ch] = red[0][k][ch] + red[1][k][ch] + red[2][k][ch] + red[3][k][ch];
 }
 
-// out[y][c] (+)= sum over the y-th slice of blocks of part[b][c]   (later stages of every block-partial
-// reduction; deterministic).  grid (ceil(width/256), nslices); `accumulate` only with one slice.
-__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, int nblk, int width, int stride,
-                                                          float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= width) return;
-    const int per = (nblk + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = b0;
-    for (; b + 3 < b1; b += 4) {
-        s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 1) * stride + c];
-        s2 += part[(long)(b + 2) * stride + c]; s3 += part[(long)(b + 3) * stride + c];
+// Second stage of every block-partial reduction, ONE launch per record set: column c of the records
+// part[b][stride] (b < nblk) is summed and written (or accumulated) into the output segment that owns it.
+// A workgroup owns 64 columns; its 4 waves each sum a quarter of the records, LDS combines.  Deterministic.
+#define RED_MAXSEG 8
+struct RedSegs {
+    int nseg;
+    int off[RED_MAXSEG];     // first record column of the segment
+    int width[RED_MAXSEG];
+    int accumulate[RED_MAXSEG];
+    float* out[RED_MAXSEG];
+};
+__global__ void __launch_bounds__(256) k_reduce_records(const float* __restrict__ part, int nblk, int stride, int total, RedSegs segs) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < total) {
+        int b = ry;
+        for (; b + 4 < nblk; b += 8) { s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 4) * stride + c]; }
+        if (b < nblk) s0 += part[(long)b * stride + c];
     }
-    for (; b < b1; ++b) s0 += part[(long)b * stride + c];
-    const float sum = (s0 + s1) + (s2 + s3);
-    float* o = out + (long)blockIdx.y * width + c;
-    *o = accumulate ? *o + sum : sum;
+    red[ry][cx] = s0 + s1;
+    __syncthreads();
+    if (ry == 0 && c < total) {
+        const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        for (int k = 0; k < segs.nseg; ++k)
+            if (c >= segs.off[k] && c < segs.off[k] + segs.width[k]) {
+                float* o = segs.out[k] + (c - segs.off[k]);
+                *o = segs.accumulate[k] ? *o + v : v;
+            }
+    }
 }
 
 // --------------------------------------------------------------------------- act = gelu(hraw + b1)

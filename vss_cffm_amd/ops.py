@@ -179,12 +179,9 @@ class _GtcBlockFn(torch.autograd.Function):
         x1, z2, mean2, rstd2 = new(nt, c), new(nt, c), new(nt), new(nt)
         ck(lib.cffm_residual_ln(_ptr(x), nt * c, nt, _ptr(yraw), _ptr(pb), _ptr(n2w), _ptr(n2b), _ptr(x1), _ptr(z2),
                                 _ptr(mean2), _ptr(rstd2), nt, st))
-        hraw, act = new(nt, 4 * c), new(nt, 4 * c)
-        ck(lib.cffm_linear_fwd(_ptr(z2), _ptr(w1), _ptr(hraw), nt, 4 * c, c, st))
-        ck(lib.cffm_bias_gelu(_ptr(hraw), _ptr(b1), _ptr(act), nt, 4 * c, st))
-        ck(lib.cffm_linear_fwd(_ptr(act), _ptr(w2), _ptr(yraw), nt, c, 4 * c, st))
-        out = new(b, t, c)
-        ck(lib.cffm_residual_out(_ptr(x1), _ptr(yraw), _ptr(b2), _ptr(out), nt, st))
+        hraw, act, out = new(nt, 4 * c), new(nt, 4 * c), new(b, t, c)
+        ck(lib.cffm_linear_gelu_fwd(_ptr(z2), _ptr(w1), _ptr(b1), _ptr(hraw), _ptr(act), nt, 4 * c, c, st))
+        ck(lib.cffm_linear_residual_fwd(_ptr(act), _ptr(w2), _ptr(b2), _ptr(x1), _ptr(out), nt, c, 4 * c, st))
         ctx.save_for_backward(x, centers, z, mean1, rstd1, cn, cmean, crstd, qraw, kvraw, ao, lse, x1, z2, mean2, rstd2,
                               hraw, act, n1w, n1b, qw, qb, kvw, kvb, pw, pb, n2w, n2b, w1, b1, w2, b2)
         return out
