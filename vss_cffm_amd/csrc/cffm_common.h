@@ -42,15 +42,42 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 #endif
 
 // ---- wave (64 lanes) reductions ------------------------------------------------------------------
+// Result in every lane.  On the GPU: 4 DPP steps inside each 16-lane row (quad swaps, half-mirror, mirror -- every
+// lane ends up with its row's total), then the 4 row totals are read with v_readlane and added: ~12 cheap VALU/SALU
+// instructions.  (The portable __shfl_xor butterfly lowers to 6 dependent ds_bpermute round trips through the LDS
+// crossbar -- it made the LayerNorm / pooling kernels latency-bound.)
+#ifndef CFFM_EMU
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
+#ifdef CFFM_EMU
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
+#else
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);   // row_half_mirror
+    v += dpp_f32<0x140>(v);   // row_mirror
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
+#ifdef CFFM_EMU
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
+#else
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+#endif
 }
 
 // ---- MFMA wrappers (CDNA4). Fragment maps used throughout (cdna_hip_programming.md section 3):

@@ -192,7 +192,7 @@ static void seg_add(RedSegs& r, int off, int width, float* out, int accumulate) 
     r.off[k] = off; r.width[k] = width; r.out[k] = out; r.accumulate[k] = accumulate;
 }
 static void reduce_records(const float* part, int nblk, int stride, int total, const RedSegs& segs, hipStream_t st) {
-    CFFM_LAUNCH(k_reduce_records, ((total + 63) / 64), (256), 0, st, part, nblk, stride, total, segs);
+    CFFM_LAUNCH(k_reduce_records, ((total + 63) / 64), (1024), 0, st, part, nblk, stride, total, segs);
 }
 
 // ------------------------------------------------------------------------------------------- stages

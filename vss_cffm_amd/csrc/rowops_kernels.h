@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd_residual(const float* __restrict
 
 // Second stage of every block-partial reduction, ONE launch per record set: column c of the records
 // part[b][stride] (b < nblk) is summed and written (or accumulated) into the output segment that owns it.
-// A workgroup owns 64 columns; its 4 waves each sum a quarter of the records, LDS combines.  Deterministic.
+// A workgroup owns 64 columns; its 16 waves each sum every 16th record, LDS combines.  Deterministic.
 #define RED_MAXSEG 8
 struct RedSegs {
     int nseg;
@@ -176,20 +176,24 @@ struct RedSegs {
     int accumulate[RED_MAXSEG];
     float* out[RED_MAXSEG];
 };
-__global__ void __launch_bounds__(256) k_reduce_records(const float* __restrict__ part, int nblk, int stride, int total, RedSegs segs) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+__global__ void __launch_bounds__(1024) k_reduce_records(const float* __restrict__ part, int nblk, int stride, int total, RedSegs segs) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;   // 16 waves: each sums every 16th record
     const int c = blockIdx.x * 64 + cx;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < total) {
         int b = ry;
-        for (; b + 4 < nblk; b += 8) { s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 4) * stride + c]; }
-        if (b < nblk) s0 += part[(long)b * stride + c];
+        for (; b + 48 < nblk; b += 64) {
+            s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 16) * stride + c];
+            s2 += part[(long)(b + 32) * stride + c]; s3 += part[(long)(b + 48) * stride + c];
+        }
+        for (; b < nblk; b += 16) s0 += part[(long)b * stride + c];
     }
-    red[ry][cx] = s0 + s1;
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ry == 0 && c < total) {
-        const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        float v = 0.f;
+        for (int k = 0; k < 16; ++k) v += red[k][cx];
         for (int k = 0; k < segs.nseg; ++k)
             if (c >= segs.off[k] && c < segs.off[k] + segs.width[k]) {
                 float* o = segs.out[k] + (c - segs.off[k]);
