@@ -91,14 +91,16 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
 int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias /*[8,64,304]*/,
                        float* biasT /*[8,304,64] or NULL*/, void* stream);
 int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* const dpool[4], void* stream);
-int cffm_attn_fwd(const cffm_geom* g, const float* qkv /*[B*RC,768] raw (no bias)*/, const float* qkv_b,
-                  const int* key_src /*[nW,304]*/, const int* q_dst /*[nW,49]*/, const float* bias,
-                  float* ao /*[B*HW,256]*/, float* lse /*[B*nW*8,64]*/, void* stream);
+/* qkv16 [B*RC,768] f16 = zall w^T + b with the q third times 32^-0.5 (cffm_linear_qkv_fwd) */
+int cffm_linear_qkv_fwd(const float* zall, const float* w /*[768,256]*/, const float* b /*[768]*/, void* qkv16, long M,
+                        void* stream);
+int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src /*[nW,304]*/, const int* q_dst /*[nW,49]*/,
+                  const float* bias, float* ao /*[B*HW,256]*/, float* lse /*[B*nW*8,64]*/, void* stream);
 /* inv_ptr [RC+1] / inv_idx: CSR inverse of key_src (token row -> the window*304+slot pairs reading it);
  * dkv_part: scratch [B*nW*304*512] floats for the per-window dK/dV rows the gather pass sums */
-int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
+int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst,
                   const int* inv_ptr, const int* inv_idx, const float* bias, const float* biasT, const float* ao,
-                  const float* dao, const float* lse, float* dqkv /*[B*RC,768], overwritten*/,
+                  const float* dao, const float* lse, float* dqkv /*[B*RC,768] fp32: d(zall w^T), overwritten*/,
                   float* dbiasT /*[8,304,64], overwritten*/, float* dkv_part, void* stream);
 /* y[M,N] = x[M,K] w[N,K]^T ;  dx[M,K] = dy[M,N] w[N,K] ;  dw[N,K] = dy[M,N]^T x[M,K]   (row-major, no bias) */
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream);

@@ -92,12 +92,15 @@ def run_stage_checks(lib, device):
     assert torch.equal(biasT.transpose(1, 2), bias)
     assert float(bias[:, 49:].abs().max()) == 0 and float(bias[:, :, 289:].abs().max()) == 0
     # --- attention on the library's own zall -> qkv
-    qkv = f(b * rc, 768)
-    assert lib.cffm_linear_fwd(P(zall), P(p['attn.qkv.weight']), P(qkv), b * rc, 768, 256, stream) == 0
+    qkv = torch.zeros(b * rc, 768, dtype=torch.float16, device=device)
+    assert lib.cffm_linear_qkv_fwd(P(zall), P(p['attn.qkv.weight']), P(p['attn.qkv.bias']), P(qkv), b * rc, stream) == 0
+    ref_qkv = it['qkv_t'].reshape(b, -1, 768)[:, win.view(-1)].clone()                 # target rows, window-major
+    ref_qkv[..., :256] *= 32 ** -0.5
+    assert H.rel_err(qkv.view(b, rc, 768)[:, :49 * nw].float().cpu(), ref_qkv) < 1e-3    # f16 storage
     ks, qd = geometry.tables(h0, w0)
     ks, qd = torch.from_numpy(np.array(ks)).to(device), torch.from_numpy(np.array(qd)).to(device)
     ao, lse = f(b * hw, 256), f(b * nw * 8, 64)
-    assert lib.cffm_attn_fwd(C.byref(g), P(qkv), P(p['attn.qkv.bias']), P(ks), P(qd), P(bias), P(ao), P(lse), stream) == 0
+    assert lib.cffm_attn_fwd(C.byref(g), P(qkv), P(ks), P(qd), P(bias), P(ao), P(lse), stream) == 0
     ao_ref = torch.zeros(b, hp * wp, 256)
     ao_ref[:, win.view(-1)] = it['ao'].reshape(b, nw * 49, 256)
     ao_ref = ao_ref.view(b, hp, wp, 256)[:, :h0, :w0].reshape(b * hw, 256)

@@ -27,6 +27,8 @@ typedef float f16;  // emulator-only switch: MFMA operands keep fp32, to separat
 #else
 typedef _Float16 f16;
 #endif
+typedef _Float16 h16;                                       // f16 as stored in global memory (q/k/v)
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
@@ -135,6 +137,13 @@ __device__ __forceinline__ f32x4 mfma16x16x4_f32(float a, float b, f32x4 c) {
 #endif
 }
 
+// 8 stored halfs (16 B) -> 8 MFMA-operand elements (a no-op copy unless the emulator's fp32-operand switch is on)
+__device__ __forceinline__ f16x8 ld_h8(const h16* p) {
+    const h16x8 v = *(const h16x8*)p;
+    f16x8 r;
+    for (int e = 0; e < 8; ++e) r[e] = (f16)v[e];
+    return r;
+}
 __device__ __forceinline__ f16x4 to_f16x4(f32x4 v) {
     f16x4 r;
     r[0] = (f16)v[0]; r[1] = (f16)v[1]; r[2] = (f16)v[2]; r[3] = (f16)v[3];

@@ -124,7 +124,7 @@ int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* o) {
     o->rstd1 = p; p += up(B * 4 * HW);
     o->M = p; p += up(CFFM_NCELL * CFFM_WA);
     o->zall = p; p += up(B * RC * CFFM_C);
-    o->qkv = p; p += up(B * RC * 768);
+    o->qkv = p; p += up(B * RC * 768 / 2);   // f16 q|k|v
     o->bias = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     o->biasT = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     o->lse = p; p += up(B * nW * CFFM_HEADS * CFFM_NQ_PAD);
@@ -193,6 +193,11 @@ static void seg_add(RedSegs& r, int off, int width, float* out, int accumulate) 
 }
 static void reduce_records(const float* part, int nblk, int stride, int total, const RedSegs& segs, hipStream_t st) {
     CFFM_LAUNCH(k_reduce_records, ((total + 63) / 64), (1024), 0, st, part, nblk, stride, total, segs);
+}
+
+static unsigned ew_grid(long n4) {
+    long b = (n4 + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
 // ------------------------------------------------------------------------------------------- stages
@@ -282,11 +287,11 @@ int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* con
     return 0;
 }
 
-int cffm_attn_fwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
-                  const float* bias, float* ao, float* lse, void* stream) {
+int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst, const float* bias, float* ao,
+                  float* lse, void* stream) {
     PROF(ST_ATTN_FWD);
-    REQUIRE(g && qkv && key_src && q_dst && bias && ao && lse, "attn_fwd: null");
-    CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), qkv, qkv_b,
+    REQUIRE(g && qkv16 && key_src && q_dst && bias && ao && lse, "attn_fwd: null");
+    CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
                 key_src, q_dst, bias, ao, lse);
     CHECK_LAUNCH("attn_fwd");
     return 0;
@@ -299,16 +304,16 @@ static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
     return (total + *per_group - 1) / *per_group;
 }
 
-int cffm_attn_bwd(const cffm_geom* g, const float* qkv, const float* qkv_b, const int* key_src, const int* q_dst,
+int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst,
                   const int* inv_ptr, const int* inv_idx, const float* bias, const float* biasT, const float* ao,
                   const float* dao, const float* lse, float* dqkv, float* dbiasT, float* dkv_part, void* stream) {
     PROF(ST_ATTN_BWD);
     hipStream_t st = (hipStream_t)stream;
-    REQUIRE(g && qkv && biasT && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
+    REQUIRE(g && qkv16 && biasT && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
     hipMemsetAsync(dbiasT, 0, (size_t)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD * sizeof(float), st);
     int per;
     const int ng = attn_bwd_groups(g, &per);
-    CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (512), ATT_BWD_LDS, st, to_geo(g), qkv, qkv_b, key_src, q_dst, bias, biasT, ao,
+    CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (512), ATT_BWD_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias, biasT, ao,
                 dao, lse, dqkv, dkv_part, dbiasT, per);
     CFFM_LAUNCH(k_dkv_gather, ((g->RC + 3) / 4, g->B), (256), 0, st, to_geo(g), inv_ptr, inv_idx, (const float*)dkv_part, dqkv);
     CHECK_LAUNCH("attn_bwd");
@@ -326,6 +331,22 @@ int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, in
 int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream) {
     PROF(ST_GEMM);
     return gemm_tn(dy, x, dw, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_weight: gemm failed") : 0;
+}
+
+// q|k|v Linear feeding the CFM kernels: qkv16[M,768] (f16) = x w^T + b, q third times 32^-0.5 (cffm_transformer.py:374, :528)
+int cffm_linear_qkv_fwd(const float* x, const float* w, const float* b, void* qkv16, long M, void* stream) {
+    REQUIRE(x && w && b && qkv16, "linear_qkv_fwd: null");
+    if (gemm_use_lib()) {
+        float* tmp = lib_scratch((size_t)M * 768);
+        REQUIRE(tmp, "linear_qkv_fwd: scratch allocation failed");
+        TRY(cffm_linear_fwd(x, w, tmp, M, 768, CFFM_C, stream));
+        const long n4 = M * 768 / 4;
+        CFFM_LAUNCH(k_qkv_to_f16, (ew_grid(n4)), (256), 0, (hipStream_t)stream, (const float*)tmp, b, (h16*)qkv16, n4);
+        CHECK_LAUNCH("qkv_to_f16");
+        return 0;
+    }
+    PROF(ST_GEMM);
+    return gemm_nt_qkv16_split(x, w, b, (h16*)qkv16, M, 768, CFFM_C, (hipStream_t)stream) ? fail(-3, "linear_qkv_fwd: gemm failed") : 0;
 }
 
 // fused Mlp halves (one launch each on the hand-written GEMM; the exact-fp32 library path sequences the unfused stages)
@@ -399,10 +420,6 @@ int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, 
     return 0;
 }
 
-static unsigned ew_grid(long n4) {
-    long b = (n4 + 255) / 256;
-    return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
-}
 
 int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, int cols, void* stream) {
     PROF(ST_GELU);
@@ -485,9 +502,9 @@ int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const flo
     TRY(cffm_pool_matrix(p->pool_w, ws + L.M, stream));
     TRY(cffm_ln_pool_fwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
                          ws + L.mean1, ws + L.rstd1, stream));
-    TRY(cffm_linear_fwd(ws + L.zall, p->qkv_w, ws + L.qkv, NR, 768, CFFM_C, stream));
+    TRY(cffm_linear_qkv_fwd(ws + L.zall, p->qkv_w, p->qkv_b, ws + L.qkv, NR, stream));
     TRY(cffm_bias_assemble(p->rpb_own, p->rpb_ring, p->rpb_pool, ws + L.bias, ws + L.biasT, stream));
-    TRY(cffm_attn_fwd(g, ws + L.qkv, p->qkv_b, key_src, q_dst, ws + L.bias, ws + L.ao, ws + L.lse, stream));
+    TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, ws + L.bias, ws + L.ao, ws + L.lse, stream));
     TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_residual_ln(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
                          ws + L.mean2, ws + L.rstd2, NP, stream));
@@ -527,10 +544,10 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     TRY(cffm_linear_bwd_weight(dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dx1, p->proj_w, dao, NP, CFFM_C, CFFM_C, stream));
     // attention
-    TRY(cffm_attn_bwd(g, ws + L.qkv, p->qkv_b, key_src, q_dst, inv_ptr, inv_idx, ws + L.bias, ws + L.biasT, ws + L.ao, dao,
+    TRY(cffm_attn_bwd(g, ws + L.qkv, key_src, q_dst, inv_ptr, inv_idx, ws + L.bias, ws + L.biasT, ws + L.ao, dao,
                       ws + L.lse, dqkv, dbiasT, scratch + S.dkvp, stream));
     TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, stream));
-    // qkv = zall Wqkv^T (+ bias inside the attention kernel)
+    // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)
     TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
     TRY(cffm_linear_bwd_weight(dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dqkv, p->qkv_w, dzall, NR, 768, CFFM_C, stream));

@@ -37,7 +37,7 @@
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads = 4 waves x 16 queries.
-__global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
+__global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __restrict__ qkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
                                                        const float* __restrict__ bias, float* __restrict__ ao,
                                                        float* __restrict__ lse_out) {
@@ -50,63 +50,53 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const float* __r
     const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* ksrc = key_src + w * CFFM_NKEY_PAD;
-    const float* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;
-    const float scale = 0.17677669529663687f;  // 32^-0.5 (cffm_transformer.py:248,528)
+    const h16* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;   // q|k|v as f16, bias added, q pre-scaled (GEMM epilogue)
 
-    // ---- stage: key validity, K rows, V transposed, Q rows (bias of the qkv Linear added here) ----
+    // ---- stage: key validity, K rows, V transposed, Q rows ----
     // Global loads are issued in three batches, each complete before anything waits on it: the key-table entries of
-    // this thread's 5 row pairs, then the 20 gathered K/V row segments + the Q segment, then (below) the wave's 19
-    // bias tiles -- the kernel pays the L2/HBM latency about three times instead of ~30 times.
+    // this thread's 3 row pairs, then the 12 gathered 16-byte K/V segments + the Q segment, then (below) the wave's 19
+    // bias tiles -- the kernel pays the L2/HBM latency about three times instead of ~30 times.  A (token, head) slice
+    // is 64 B of f16 = four 16-byte chunks c4.
     const int qcol = 16 * wave + (lane & 15), g = lane >> 4;
-    const int ch = lane >> 3;
-    int src0[5], src1[5];
+    const int c4 = lane >> 4;
+    int src0[3], src1[3];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        const int pr = (it * 4 + wave) * 8 + (lane & 7);
+    for (int it = 0; it < 3; ++it) {
+        const int pr = (it * 4 + wave) * 16 + (lane & 15);
         const bool ok = pr < CFFM_NKEY_PAD / 2;
         src0[it] = ok ? ksrc[2 * pr] : -1;
         src1[it] = ok ? ksrc[2 * pr + 1] : -1;
     }
-    const f32x4 bk = ld4(bqkv + 256 + h * CFFM_HD + 4 * ch), bv = ld4(bqkv + 512 + h * CFFM_HD + 4 * ch);
-    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 k0[5], k1[5], v0[5], v1[5];
+    f16x8 z8;
+    for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
+    f16x8 k0[3], k1[3], v0[3], v1[3];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        k0[it] = k1[it] = v0[it] = v1[it] = z4;
-        if (src0[it] >= 0) { k0[it] = ld4(base + (long)src0[it] * 768 + 256 + 4 * ch); v0[it] = ld4(base + (long)src0[it] * 768 + 512 + 4 * ch); }
-        if (src1[it] >= 0) { k1[it] = ld4(base + (long)src1[it] * 768 + 256 + 4 * ch); v1[it] = ld4(base + (long)src1[it] * 768 + 512 + 4 * ch); }
+    for (int it = 0; it < 3; ++it) {
+        k0[it] = k1[it] = v0[it] = v1[it] = z8;
+        if (src0[it] >= 0) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
+        if (src1[it] >= 0) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
     }
-    f32x4 qv[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int it = tid + 256 * u, i = it >> 3, c = it & 7;
-        qv[u] = z4;
-        if (i < CFFM_WA) qv[u] = ld4(base + (long)(w * CFFM_WA + i) * 768 + 4 * c) + ld4(bqkv + h * CFFM_HD + 4 * c);
-    }
+    const int qi = tid >> 2, qc = tid & 3;
+    f16x8 qv = z8;
+    if (qi < CFFM_WA) qv = ld_h8(base + (long)(w * CFFM_WA + qi) * 768 + 8 * qc);
     for (int n = tid; n < CFFM_NKEY_PAD; n += 256) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
     for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 256)
         Vt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        const int pr = (it * 4 + wave) * 8 + (lane & 7);
+    for (int it = 0; it < 3; ++it) {
+        const int pr = (it * 4 + wave) * 16 + (lane & 15);
         if (pr < CFFM_NKEY_PAD / 2) {
             const int n0 = 2 * pr;
-            if (src0[it] >= 0) { k0[it] += bk; v0[it] += bv; }
-            if (src1[it] >= 0) { k1[it] += bk; v1[it] += bv; }
-            *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0[it]);
-            *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1[it]);
+            *(f16x8*)(Ks + n0 * ATT_KS_STRIDE + 8 * c4) = k0[it];
+            *(f16x8*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = k1[it];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f16x2 pv; pv[0] = (f16)v0[it][e]; pv[1] = (f16)v1[it][e];
-                *(f16x2*)(Vt + (4 * ch + e) * ATT_VT_STRIDE + n0) = pv;
+            for (int e = 0; e < 8; ++e) {
+                f16x2 pv; pv[0] = v0[it][e]; pv[1] = v1[it][e];
+                *(f16x2*)(Vt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pv;
             }
         }
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int it = tid + 256 * u, i = it >> 3, c = it & 7;
-        *(f16x4*)(Qs + i * ATT_KS_STRIDE + 4 * c) = to_f16x4(qv[u] * scale);
-    }
+    *(f16x8*)(Qs + qi * ATT_KS_STRIDE + 8 * qc) = qv;
     // the wave's 19 bias tiles (L2-resident table) fly across the barrier and land in the MFMA C operands
     const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
     f32x4 s[19];
@@ -178,7 +168,7 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const float* __r
 #define ATT_BWD_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
                      CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
 
-__global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __restrict__ qkv, const float* __restrict__ bqkv,
+__global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const h16* __restrict__ qkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
                                                        const float* __restrict__ bias, const float* __restrict__ biasT,
                                                        const float* __restrict__ ao, const float* __restrict__ dao,
@@ -211,38 +201,43 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
     for (int wb = wb0; wb < wb1; ++wb) {
         const int w = wb % G.nW, b = wb / G.nW;
         const int* ksrc = key_src + w * CFFM_NKEY_PAD;
-        const float* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;
+        const h16* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;   // f16, bias added, q pre-scaled
 
         // ---------------- stage --------------------------------------------------------------------
-        // global loads in two batches (tables, then every gathered row segment), as in the forward
-        const int ch = lane >> 3;
-        int src0[3], src1[3];
+        // global loads in two batches (tables, then every gathered 16-byte segment), as in the forward
+        const int c4 = lane >> 4;
+        int src0[2], src1[2];
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int prk = (it * 8 + wave) * 8 + (lane & 7);
+        for (int it = 0; it < 2; ++it) {
+            const int prk = (it * 8 + wave) * 16 + (lane & 15);
             const bool ok = prk < CFFM_NKEY_PAD / 2;
             src0[it] = ok ? ksrc[2 * prk] : -1;
             src1[it] = ok ? ksrc[2 * prk + 1] : -1;
         }
+        // Q: threads 0..127 own (query pair, 16-byte chunk); dO / O: threads 256..511 own (query pair, 4-channel chunk)
         const int pr = (tid & 255) >> 3, c = tid & 7, i0 = 2 * pr, i1 = i0 + 1;
+        const int qp = tid >> 2, qc = tid & 3;          // Q item (tid < 128): rows 2qp, 2qp+1, chunk qc
         int t0 = -1, t1 = -1;
         if (tid >= 256) {
             t0 = (i0 < CFFM_WA) ? q_dst[w * CFFM_WA + i0] : -1;
             t1 = (i1 < CFFM_WA) ? q_dst[w * CFFM_WA + i1] : -1;
         }
-        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 k0[3], k1[3], v0[3], v1[3];
+        f16x8 z8;
+        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
+        f16x8 k0[2], k1[2], v0[2], v1[2];
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            k0[it] = k1[it] = v0[it] = v1[it] = z4;
-            if (src0[it] >= 0) { k0[it] = ld4(base + (long)src0[it] * 768 + 256 + 4 * ch); v0[it] = ld4(base + (long)src0[it] * 768 + 512 + 4 * ch); }
-            if (src1[it] >= 0) { k1[it] = ld4(base + (long)src1[it] * 768 + 256 + 4 * ch); v1[it] = ld4(base + (long)src1[it] * 768 + 512 + 4 * ch); }
+        for (int it = 0; it < 2; ++it) {
+            k0[it] = k1[it] = v0[it] = v1[it] = z8;
+            if (src0[it] >= 0) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
+            if (src1[it] >= 0) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
         }
+        f16x8 q0 = z8, q1 = z8;
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 r0 = z4, r1 = z4, o0 = z4, o1 = z4;
-        if (tid < 256) {
-            if (i0 < CFFM_WA) r0 = ld4(base + (long)(w * CFFM_WA + i0) * 768 + 4 * c);
-            if (i1 < CFFM_WA) r1 = ld4(base + (long)(w * CFFM_WA + i1) * 768 + 4 * c);
-        } else {
+        if (tid < 128) {
+            if (2 * qp < CFFM_WA) q0 = ld_h8(base + (long)(w * CFFM_WA + 2 * qp) * 768 + 8 * qc);
+            if (2 * qp + 1 < CFFM_WA) q1 = ld_h8(base + (long)(w * CFFM_WA + 2 * qp + 1) * 768 + 8 * qc);
+        } else if (tid >= 256) {
             if (t0 >= 0) { const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c; r0 = ld4(dao + off); o0 = ld4(ao + off); }
             if (t1 >= 0) { const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c; r1 = ld4(dao + off); o1 = ld4(ao + off); }
         }
@@ -250,35 +245,36 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
         for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 512)
             Kt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
         if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid];
-        {   // K (row-major + transposed) and V (row-major); lane -> (row pair, 4-channel chunk)
-            const f32x4 bk = ld4(bqkv + 256 + h * CFFM_HD + 4 * ch), bv = ld4(bqkv + 512 + h * CFFM_HD + 4 * ch);
+        // K (row-major + transposed) and V (row-major): straight 16-byte copies, the transposed image as packed key pairs
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int prk = (it * 8 + wave) * 8 + (lane & 7);
-                if (prk < CFFM_NKEY_PAD / 2) {
-                    const int n0 = 2 * prk;
-                    if (src0[it] >= 0) { k0[it] += bk; v0[it] += bv; }
-                    if (src1[it] >= 0) { k1[it] += bk; v1[it] += bv; }
-                    *(f16x4*)(Ks + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k0[it]);
-                    *(f16x4*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(k1[it]);
-                    *(f16x4*)(Vs + n0 * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v0[it]);
-                    *(f16x4*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 4 * ch) = to_f16x4(v1[it]);
+        for (int it = 0; it < 2; ++it) {
+            const int prk = (it * 8 + wave) * 16 + (lane & 15);
+            if (prk < CFFM_NKEY_PAD / 2) {
+                const int n0 = 2 * prk;
+                *(f16x8*)(Ks + n0 * ATT_KS_STRIDE + 8 * c4) = k0[it];
+                *(f16x8*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = k1[it];
+                *(f16x8*)(Vs + n0 * ATT_KS_STRIDE + 8 * c4) = v0[it];
+                *(f16x8*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = v1[it];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f16x2 pk; pk[0] = (f16)k0[it][e]; pk[1] = (f16)k1[it][e];
-                        *(f16x2*)(Kt + (4 * ch + e) * ATT_VT_STRIDE + n0) = pk;
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    f16x2 pk; pk[0] = k0[it][e]; pk[1] = k1[it][e];
+                    *(f16x2*)(Kt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pk;
                 }
             }
         }
-        // Q (threads 0..255) and dO / D (threads 256..511); item = (query pair, chunk); chunk = lane & 7 so
-        // the 8 chunks of a query sit in 8 adjacent lanes (D is reduced with xor-shuffles 1,2,4)
+        if (tid < 128) {   // Q rows and the transposed Q image
+            *(f16x8*)(Qs + (2 * qp) * ATT_KS_STRIDE + 8 * qc) = q0;
+            *(f16x8*)(Qs + (2 * qp + 1) * ATT_KS_STRIDE + 8 * qc) = q1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f16x2 pq; pq[0] = q0[e]; pq[1] = q1[e];
+                *(f16x2*)(Qt + (8 * qc + e) * ATT_QT_STRIDE + 2 * qp) = pq;
+            }
+        }
+        // dO / D (threads 256..511); chunk = lane & 7 so the 8 chunks of a query sit in 8 adjacent lanes (D is reduced
+        // with xor-shuffles 1,2,4)
         float d0 = 0.f, d1 = 0.f, amax = 0.f;
-        if (tid < 256) {
-            const f32x4 bq = ld4(bqkv + h * CFFM_HD + 4 * c);
-            if (i0 < CFFM_WA) r0 = (r0 + bq) * scale;
-            if (i1 < CFFM_WA) r1 = (r1 + bq) * scale;
-        } else {
+        if (tid >= 256) {
             d0 = r0[0] * o0[0] + r0[1] * o0[1] + r0[2] * o0[2] + r0[3] * o0[3];
             d1 = r1[0] * o1[0] + r1[1] * o1[1] + r1[2] * o1[2] + r1[3] * o1[3];
             for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
@@ -294,18 +290,14 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
         if (am > 0.f) frexpf(am, &ex);
         const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f;
         const float isc = 1.f / sc;
-        {
-            f16* rowm = (tid < 256) ? Qs : dOs;
-            f16* trn = (tid < 256) ? Qt : dOt;
-            if (tid >= 256) {
-                r0 *= sc; r1 *= sc;
-                if (c == 0) { sD[i0] = d0 * sc; sD[i1] = d1 * sc; }
-            }
-            *(f16x4*)(rowm + i0 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r0);
-            *(f16x4*)(rowm + i1 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r1);
+        if (tid >= 256) {
+            r0 *= sc; r1 *= sc;
+            if (c == 0) { sD[i0] = d0 * sc; sD[i1] = d1 * sc; }
+            *(f16x4*)(dOs + i0 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r0);
+            *(f16x4*)(dOs + i1 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r1);
             for (int e = 0; e < 4; ++e) {
                 f16x2 pq; pq[0] = (f16)r0[e]; pq[1] = (f16)r1[e];
-                *(f16x2*)(trn + (4 * c + e) * ATT_QT_STRIDE + i0) = pq;
+                *(f16x2*)(dOt + (4 * c + e) * ATT_QT_STRIDE + i0) = pq;
             }
         }
         __syncthreads();
@@ -357,7 +349,7 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const float* __rest
             }
             if (qcol < CFFM_WA) {
                 float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
-                *(f32x4*)(drow) = dq[0] * (scale * isc);
+                *(f32x4*)(drow) = dq[0] * (scale * isc);      // d(raw q): the stored q carries the 32^-0.5 factor
                 *(f32x4*)(drow + 16) = dq[1] * (scale * isc);
             }
         } else if (wave >= 4 && !(CFFM_ABLATE & 4)) {

@@ -48,6 +48,10 @@ static int gemm_nt_residual_split(const float* x, const float* w, const float* b
                                   hipStream_t st) {
     return gemm_split_launch<false, false, 2>(x, w, out, (int)M, N, K, K, K, N, 1, st, b, const_cast<float*>(res));
 }
+// qkv16[M,768] (f16) = (x w^T + b) with the q third pre-scaled                (qkv Linear feeding the CFM kernels)
+static int gemm_nt_qkv16_split(const float* x, const float* w, const float* b, h16* qkv16, long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, false, 3>(x, w, nullptr, (int)M, N, K, K, K, N, 1, st, b, (float*)qkv16);
+}
 // dx[M,K] = dy[M,N] w[N,K]: output cols = K, contraction = N
 static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
     return gemm_split_launch<false, true>(dy, w, dx, (int)M, K, N, N, K, K, 1, st);

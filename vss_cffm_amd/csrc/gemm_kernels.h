@@ -162,6 +162,8 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
 
 // grid (ceil(N/128), ceil(M/BM), ksplit).  K range of split z: [z*klen, min(K, (z+1)*klen)), klen multiple of 32.
 // EPI: 0 plain (+bias) | 1 GELU: C = raw product (saved for backward), aux = gelu(raw + bias) | 2 residual: C = aux + raw + bias
+//      3 q|k|v: nothing in C; aux (h16 [M,N]) = f16(raw + bias), the q third (cols < 256) also times 32^-0.5 -- exactly the
+//        values the attention kernels used to form from the fp32 product, stored once at half the bytes
 template <int BM, bool A_T, bool B_T, int EPI>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
@@ -244,6 +246,14 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
                 f32x4 a;
                 for (int e = 0; e < 4; ++e) a[e] = gelu_erf(v[e] + bv[e]);
                 *(f32x4*)(aux + (long)row * ldc + col) = a;
+                continue;
+            }
+            if (EPI == 3 && col + 3 < N) {
+                const float sc = col < CFFM_C ? 0.17677669529663687f : 1.f;
+                typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+                h16x4 o;
+                for (int e = 0; e < 4; ++e) o[e] = (h16)((v[e] + bv[e]) * sc);
+                *(h16x4*)((h16*)aux + (long)row * ldc + col) = o;
                 continue;
             }
             if (EPI == 2 && col + 3 < N) {

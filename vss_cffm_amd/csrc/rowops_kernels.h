@@ -268,3 +268,18 @@ __global__ void __launch_bounds__(256) k_sum_splits(const float* __restrict__ pa
     if (s < nsplit) a += ((const f32x4*)(part + (long)s * n))[i];
     ((f32x4*)out)[i] = a + b;
 }
+
+// q|k|v fp32 product -> f16 with the Linear bias and the q scale folded in (only used by the exact-fp32 library GEMM
+// path; the hand-written GEMM does this in its epilogue)
+__global__ void __launch_bounds__(256) k_qkv_to_f16(const float* __restrict__ raw, const float* __restrict__ bias, h16* __restrict__ out,
+                                                     long n4) {
+    typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const int col = (int)((e * 4) % 768);
+        const f32x4 v = ((const f32x4*)raw)[e] + *(const f32x4*)(bias + col);
+        const float sc = col < CFFM_C ? 0.17677669529663687f : 1.f;
+        h16x4 o;
+        for (int k = 0; k < 4; ++k) o[k] = (h16)(v[k] * sc);
+        ((h16x4*)out)[e] = o;
+    }
+}
