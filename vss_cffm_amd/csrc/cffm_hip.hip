@@ -299,7 +299,7 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
 
 static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
     const int total = g->B * g->nW;
-    int ng = total < 32 ? total : 32;  // 8 heads x 32 groups = one 512-thread workgroup per CU
+    int ng = total < 64 ? total : 64;  // 8 heads x 64 groups = two 256-thread workgroups per CU
     *per_group = (total + ng - 1) / ng;
     return (total + *per_group - 1) / *per_group;
 }
@@ -313,8 +313,10 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     hipMemsetAsync(dbiasT, 0, (size_t)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD * sizeof(float), st);
     int per;
     const int ng = attn_bwd_groups(g, &per);
-    CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (512), ATT_BWD_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias, biasT, ao,
-                dao, lse, dqkv, dkv_part, dbiasT, per);
+    CFFM_LAUNCH(k_cfm_attn_bwd_q, (CFFM_HEADS, ng), (256), ATT_BWQ_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias, ao, dao,
+                lse, dqkv, dbiasT, per);
+    CFFM_LAUNCH(k_cfm_attn_bwd_kv, (g->B * g->nW * CFFM_HEADS), (256), ATT_BWK_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst,
+                biasT, ao, dao, lse, dkv_part);
     CFFM_LAUNCH(k_dkv_gather, ((g->RC + 3) / 4, g->B), (256), 0, st, to_geo(g), inv_ptr, inv_idx, (const float*)dkv_part, dqkv);
     CHECK_LAUNCH("attn_bwd");
     return 0;

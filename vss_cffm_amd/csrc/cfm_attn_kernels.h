@@ -25,9 +25,6 @@
 #pragma once
 #include "cffa_kernels.h"
 
-#ifndef CFFM_ABLATE
-#define CFFM_ABLATE 0  // profiling only: 1 = no dK/dV atomics, 2 = no query-owner role, 4 = no key-owner role
-#endif
 #define ATT_KS_STRIDE 40   // halfs per K/V/Q row in LDS (32 + 8 pad = 80 B)
 #define ATT_VT_STRIDE 328  // halfs per row of a [32][keys] transposed image (164 dwords = 4*41)
 #define ATT_QT_STRIDE 72   // halfs per row of a [32][64 queries] transposed image (36 dwords = 4*9)
@@ -156,43 +153,89 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 }
 
 // =====================================================================================================
-// Backward.  grid (8 heads, NG groups), 512 threads; each workgroup walks the windows of its group for
-// one head.  Waves 0-3 ("query owners": 16 queries x all keys, S^T orientation) produce dQ and the
-// position-bias gradient, which stays in registers across the windows of the group; waves 4-7 ("key
-// owners": 16-key tiles x all 64 queries, S orientation) produce dK and dV for their keys into per-window
-// partial rows; k_dkv_gather then sums, for every token row, the slots of all windows that read it (ring /
-// pooled keys are shared by up to 49 windows) through a host-built inverse of the key table.
-// dO is rescaled per window by a power of two so every f16 gradient operand sits near 1 (training-size
-// gradients of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
+// Backward: two kernels + a gather pass.
+//  k_cfm_attn_bwd_q  ("query owners", S^T orientation as in the forward): grid (8 heads, NG groups), 256 threads = 4 waves x
+//     16 queries; every workgroup walks the windows of its group so the position-bias gradient (19 tiles x 4 regs per lane)
+//     stays in registers and is added to dbiasT once at the end; dQ is written directly (each query row has one owner).
+//     Q / dO fragments come straight from global memory (16 / 32 B per lane); LDS holds K, V and K^T: 70 KB -> 2 workgroups
+//     per CU overlap each other's gather latency.
+//  k_cfm_attn_bwd_kv ("key owners", S orientation): one workgroup per (clip, window, head), 4 waves x 16-key tiles x all 64
+//     queries -> dK^T, dV^T of the window's 289 key slots, written to per-window partial rows; 69 KB LDS -> 2 per CU.
+//  k_dkv_gather sums, for every token row, the slots of all windows that read it (ring / pooled keys are shared by up to 49
+//     windows) through a host-built inverse of the key table -- deterministic, no atomics on shared rows.
+// dO is rescaled by a power of two (per wave / per window) so every f16 gradient operand sits near 1 (training-size gradients
+// of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
 // =====================================================================================================
-#define ATT_BWD_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
+#define ATT_BWQ_LDS ((2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4)
+#define ATT_BWK_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
                      CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
 
-__global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const h16* __restrict__ qkv,
-                                                       const int* __restrict__ key_src, const int* __restrict__ q_dst,
-                                                       const float* __restrict__ bias, const float* __restrict__ biasT,
-                                                       const float* __restrict__ ao, const float* __restrict__ dao,
-                                                       const float* __restrict__ lse_in, float* __restrict__ dqkv,
-                                                       float* __restrict__ dkv_part, float* __restrict__ dbiasT, int per_group) {
+// stage the window's K, V rows (and optionally K^T) from the f16 q|k|v rows: two batches of global loads
+template <int NTHREADS, bool WITH_KT>
+__device__ __forceinline__ void stage_kv(const h16* __restrict__ base, const int* __restrict__ ksrc, f16* Ks, f16* Vs, f16* Kt,
+                                         float* vflag, int tid) {
+    constexpr int NW = NTHREADS / 64, NIT = (CFFM_NKEY_PAD / 2 + NW * 16 - 1) / (NW * 16);
+    const int lane = tid & 63, wave = tid >> 6, c4 = lane >> 4;
+    int src0[NIT], src1[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int prk = (it * NW + wave) * 16 + (lane & 15);
+        const bool ok = prk < CFFM_NKEY_PAD / 2;
+        src0[it] = ok ? ksrc[2 * prk] : -1;
+        src1[it] = ok ? ksrc[2 * prk + 1] : -1;
+    }
+    f16x8 z8;
+    for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
+    f16x8 k0[NIT], k1[NIT], v0[NIT], v1[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        k0[it] = k1[it] = v0[it] = v1[it] = z8;
+        if (src0[it] >= 0) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
+        if (src1[it] >= 0) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
+    }
+    for (int n = tid; n < CFFM_NKEY_PAD; n += NTHREADS) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
+    if (WITH_KT)
+        for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += NTHREADS)
+            Kt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int prk = (it * NW + wave) * 16 + (lane & 15);
+        if (prk < CFFM_NKEY_PAD / 2) {
+            const int n0 = 2 * prk;
+            *(f16x8*)(Ks + n0 * ATT_KS_STRIDE + 8 * c4) = k0[it];
+            *(f16x8*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = k1[it];
+            *(f16x8*)(Vs + n0 * ATT_KS_STRIDE + 8 * c4) = v0[it];
+            *(f16x8*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = v1[it];
+            if (WITH_KT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f16x2 pk; pk[0] = k0[it][e]; pk[1] = k1[it][e];
+                    *(f16x2*)(Kt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pk;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_q(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
+                                                            const int* __restrict__ q_dst, const float* __restrict__ bias,
+                                                            const float* __restrict__ ao, const float* __restrict__ dao,
+                                                            const float* __restrict__ lse_in, float* __restrict__ dqkv,
+                                                            float* __restrict__ dbiasT, int per_group) {
     CFFM_DYN_SMEM(smem);
-    f16* Qs = (f16*)smem;
-    f16* dOs = Qs + 64 * ATT_KS_STRIDE;
-    f16* Ks = dOs + 64 * ATT_KS_STRIDE;
+    f16* Ks = (f16*)smem;
     f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
     f16* Kt = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    f16* Qt = Kt + 32 * ATT_VT_STRIDE;
-    f16* dOt = Qt + 32 * ATT_QT_STRIDE;
-    float* vflag = (float*)(dOt + 32 * ATT_QT_STRIDE);
-    float* slse = vflag + CFFM_NKEY_PAD;
-    float* sD = slse + 64;
-    float* smax = sD + 64;
+    float* vflag = (float*)(Kt + 32 * ATT_VT_STRIDE);
 
     const int h = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
+    const int qcol = 16 * wave + l15;
     const float scale = 0.17677669529663687f;
     const int wb0 = grp * per_group;
     const int wb1 = (wb0 + per_group < G.B * G.nW) ? wb0 + per_group : G.B * G.nW;
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
 
     f32x4 dB[19];
 #pragma unroll
@@ -203,227 +246,217 @@ __global__ void __launch_bounds__(512) k_cfm_attn_bwd(Geo G, const h16* __restri
         const int* ksrc = key_src + w * CFFM_NKEY_PAD;
         const h16* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;   // f16, bias added, q pre-scaled
 
-        // ---------------- stage --------------------------------------------------------------------
-        // global loads in two batches (tables, then every gathered 16-byte segment), as in the forward
-        const int c4 = lane >> 4;
-        int src0[2], src1[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int prk = (it * 8 + wave) * 16 + (lane & 15);
-            const bool ok = prk < CFFM_NKEY_PAD / 2;
-            src0[it] = ok ? ksrc[2 * prk] : -1;
-            src1[it] = ok ? ksrc[2 * prk + 1] : -1;
+        // this lane's query: Q fragment (16 B of f16), dO / O fragments (8 channels), LSE
+        const int dst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;
+        f16x8 qfrag;
+        for (int e = 0; e < 8; ++e) qfrag[e] = (f16)0.f;
+        f32x4 do0 = (f32x4){0.f, 0.f, 0.f, 0.f}, do1 = do0, o0 = do0, o1 = do0;
+        float lq = 0.f;
+        if (qcol < CFFM_WA) {
+            qfrag = ld_h8(base + (long)(w * CFFM_WA + qcol) * 768 + 8 * g);
+            lq = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol];
         }
-        // Q: threads 0..127 own (query pair, 16-byte chunk); dO / O: threads 256..511 own (query pair, 4-channel chunk)
-        const int pr = (tid & 255) >> 3, c = tid & 7, i0 = 2 * pr, i1 = i0 + 1;
-        const int qp = tid >> 2, qc = tid & 3;          // Q item (tid < 128): rows 2qp, 2qp+1, chunk qc
-        int t0 = -1, t1 = -1;
-        if (tid >= 256) {
-            t0 = (i0 < CFFM_WA) ? q_dst[w * CFFM_WA + i0] : -1;
-            t1 = (i1 < CFFM_WA) ? q_dst[w * CFFM_WA + i1] : -1;
+        if (dst >= 0) {
+            const long off = ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 8 * g;
+            do0 = ld4(dao + off); do1 = ld4(dao + off + 4);
+            o0 = ld4(ao + off); o1 = ld4(ao + off + 4);
         }
-        f16x8 z8;
-        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
-        f16x8 k0[2], k1[2], v0[2], v1[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            k0[it] = k1[it] = v0[it] = v1[it] = z8;
-            if (src0[it] >= 0) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
-            if (src1[it] >= 0) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
-        }
-        f16x8 q0 = z8, q1 = z8;
-        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 r0 = z4, r1 = z4, o0 = z4, o1 = z4;
-        if (tid < 128) {
-            if (2 * qp < CFFM_WA) q0 = ld_h8(base + (long)(w * CFFM_WA + 2 * qp) * 768 + 8 * qc);
-            if (2 * qp + 1 < CFFM_WA) q1 = ld_h8(base + (long)(w * CFFM_WA + 2 * qp + 1) * 768 + 8 * qc);
-        } else if (tid >= 256) {
-            if (t0 >= 0) { const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c; r0 = ld4(dao + off); o0 = ld4(ao + off); }
-            if (t1 >= 0) { const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c; r1 = ld4(dao + off); o1 = ld4(ao + off); }
-        }
-        for (int n = tid; n < CFFM_NKEY_PAD; n += 512) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
-        for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 512)
-            Kt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
-        if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid];
-        // K (row-major + transposed) and V (row-major): straight 16-byte copies, the transposed image as packed key pairs
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int prk = (it * 8 + wave) * 16 + (lane & 15);
-            if (prk < CFFM_NKEY_PAD / 2) {
-                const int n0 = 2 * prk;
-                *(f16x8*)(Ks + n0 * ATT_KS_STRIDE + 8 * c4) = k0[it];
-                *(f16x8*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = k1[it];
-                *(f16x8*)(Vs + n0 * ATT_KS_STRIDE + 8 * c4) = v0[it];
-                *(f16x8*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = v1[it];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    f16x2 pk; pk[0] = k0[it][e]; pk[1] = k1[it][e];
-                    *(f16x2*)(Kt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pk;
-                }
-            }
-        }
-        if (tid < 128) {   // Q rows and the transposed Q image
-            *(f16x8*)(Qs + (2 * qp) * ATT_KS_STRIDE + 8 * qc) = q0;
-            *(f16x8*)(Qs + (2 * qp + 1) * ATT_KS_STRIDE + 8 * qc) = q1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f16x2 pq; pq[0] = q0[e]; pq[1] = q1[e];
-                *(f16x2*)(Qt + (8 * qc + e) * ATT_QT_STRIDE + 2 * qp) = pq;
-            }
-        }
-        // dO / D (threads 256..511); chunk = lane & 7 so the 8 chunks of a query sit in 8 adjacent lanes (D is reduced
-        // with xor-shuffles 1,2,4)
-        float d0 = 0.f, d1 = 0.f, amax = 0.f;
-        if (tid >= 256) {
-            d0 = r0[0] * o0[0] + r0[1] * o0[1] + r0[2] * o0[2] + r0[3] * o0[3];
-            d1 = r1[0] * o1[0] + r1[1] * o1[1] + r1[2] * o1[2] + r1[3] * o1[3];
-            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
-        }
-        d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64); d0 += __shfl_xor(d0, 4, 64);
-        d1 += __shfl_xor(d1, 1, 64); d1 += __shfl_xor(d1, 2, 64); d1 += __shfl_xor(d1, 4, 64);
-        amax = wave_max(amax);
-        if (lane == 0) smax[wave] = amax;
-        __syncthreads();
-        // power-of-two rescale of dO so that max|dO * sc| is in [1,2)
-        const float am = fmaxf(fmaxf(smax[4], smax[5]), fmaxf(smax[6], smax[7]));
+        stage_kv<256, true>(base, ksrc, Ks, Vs, Kt, vflag, tid);
+
+        float Dq = (do0[0] * o0[0] + do0[1] * o0[1]) + (do0[2] * o0[2] + do0[3] * o0[3]) + (do1[0] * o1[0] + do1[1] * o1[1]) +
+                   (do1[2] * o1[2] + do1[3] * o1[3]);
+        Dq += __shfl_xor(Dq, 16, 64);
+        Dq += __shfl_xor(Dq, 32, 64);
+        float am = 0.f;
+        for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(do0[e]), fabsf(do1[e])));
+        am = wave_max(am);
         int ex = 0;
         if (am > 0.f) frexpf(am, &ex);
-        const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f;
-        const float isc = 1.f / sc;
-        if (tid >= 256) {
-            r0 *= sc; r1 *= sc;
-            if (c == 0) { sD[i0] = d0 * sc; sD[i1] = d1 * sc; }
-            *(f16x4*)(dOs + i0 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r0);
-            *(f16x4*)(dOs + i1 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r1);
-            for (int e = 0; e < 4; ++e) {
-                f16x2 pq; pq[0] = (f16)r0[e]; pq[1] = (f16)r1[e];
-                *(f16x2*)(dOt + (4 * c + e) * ATT_QT_STRIDE + i0) = pq;
-            }
-        }
+        const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f, isc = 1.f / sc;   // max|dO * sc| in [1,2) for this wave
+        Dq *= sc;
+        f16x8 dofrag;
+        for (int e = 0; e < 4; ++e) { dofrag[e] = (f16)(do0[e] * sc); dofrag[4 + e] = (f16)(do1[e] * sc); }
         __syncthreads();
 
-        if (wave < 4 && !(CFFM_ABLATE & 2)) {
-            // ---------------- role A: query owners -> dQ, dBias ----------------------------------------
-            const int qcol = 16 * wave + l15;
-            const f16x8 qfrag = *(const f16x8*)(Qs + qcol * ATT_KS_STRIDE + 8 * g);
-            const f16x8 dofrag = *(const f16x8*)(dOs + qcol * ATT_KS_STRIDE + 8 * g);
-            const float lq = slse[qcol], Dq = sD[qcol];
-            const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
-            f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-            f32x4 bcur[2] = {ld4(brow), ld4(brow + 16)};   // bias tiles are fetched one key-tile pair ahead
+        f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        f32x4 bcur[2] = {ld4(brow), ld4(brow + 16)};   // bias tiles are fetched one key-tile pair ahead
 #pragma unroll
-            for (int kt = 0; kt < 10; ++kt) {
-                f16x4 dsh[2];
-                f32x4 bnxt[2] = {bcur[0], bcur[1]};
-                if (kt < 9) {
-                    bnxt[0] = ld4(brow + 16 * (2 * kt + 2));
-                    if (2 * kt + 3 < 19) bnxt[1] = ld4(brow + 16 * (2 * kt + 3));
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int t = 2 * kt + u;
-                    if (t < 19) {
-                        const f16x8 kf = *(const f16x8*)(Ks + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
-                        const f16x8 vf = *(const f16x8*)(Vs + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
-                        f32x4 sv = mfma16x16x32_f16(kf, qfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
-                        const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});
-                        sv += bcur[u] + *(const f32x4*)(vflag + 16 * t + 4 * g);
-                        f32x4 ds;
-                        for (int r = 0; r < 4; ++r) ds[r] = fast_exp(sv[r] - lq) * (dp[r] - Dq);
-                        dB[t < 19 ? t : 0] += ds * isc;
-                        dsh[u] = to_f16x4(ds);
-                    } else {
-                        dsh[u] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                    }
-                }
-                const f16x8 dsf = cat_f16x4(dsh[0], dsh[1]);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const f16* kr = Kt + (16 * mt + l15) * ATT_VT_STRIDE + 32 * kt + 4 * g;
-                    const f16x8 ka = cat_f16x4(*(const f16x4*)kr, *(const f16x4*)(kr + 16));
-                    dq[mt] = mfma16x16x32_f16(ka, dsf, dq[mt]);
-                }
-                bcur[0] = bnxt[0];
-                bcur[1] = bnxt[1];
-                sched_fence();
+        for (int kt = 0; kt < 10; ++kt) {
+            f16x4 dsh[2];
+            f32x4 bnxt[2] = {bcur[0], bcur[1]};
+            if (kt < 9) {
+                bnxt[0] = ld4(brow + 16 * (2 * kt + 2));
+                if (2 * kt + 3 < 19) bnxt[1] = ld4(brow + 16 * (2 * kt + 3));
             }
-            if (qcol < CFFM_WA) {
-                float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
-                *(f32x4*)(drow) = dq[0] * (scale * isc);      // d(raw q): the stored q carries the 32^-0.5 factor
-                *(f32x4*)(drow + 16) = dq[1] * (scale * isc);
-            }
-        } else if (wave >= 4 && !(CFFM_ABLATE & 4)) {
-            // ---------------- role B: key owners -> dK, dV ---------------------------------------------
-            f32x4 bt[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) bt[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + 16 * (wave - 4) + l15) * CFFM_NQ_PAD + 4 * g + 16 * mt);
-            for (int t = wave - 4; t < 19; t += 4) {
-                const int key = 16 * t + l15;
-                f32x4 bn[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) bn[mt] = bt[mt];
-                if (t + 4 < 19) {
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) bn[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + key + 64) * CFFM_NQ_PAD + 4 * g + 16 * mt);
-                }
-                const f16x8 kfrag = *(const f16x8*)(Ks + key * ATT_KS_STRIDE + 8 * g);
-                const f16x8 vfrag = *(const f16x8*)(Vs + key * ATT_KS_STRIDE + 8 * g);
-                const float vf = vflag[key];
-                f16x4 ph[4], dsh[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const f16x8 qa = *(const f16x8*)(Qs + (16 * mt + l15) * ATT_KS_STRIDE + 8 * g);
-                    const f16x8 da = *(const f16x8*)(dOs + (16 * mt + l15) * ATT_KS_STRIDE + 8 * g);
-                    f32x4 sv = mfma16x16x32_f16(qa, kfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    const f32x4 dp = mfma16x16x32_f16(da, vfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    sv += bt[mt] + vf;
-                    const f32x4 lq = *(const f32x4*)(slse + 16 * mt + 4 * g), Dq = *(const f32x4*)(sD + 16 * mt + 4 * g);
-                    f32x4 p, ds;
-                    for (int r = 0; r < 4; ++r) { p[r] = fast_exp(sv[r] - lq[r]); ds[r] = p[r] * (dp[r] - Dq[r]); }
-                    ph[mt] = to_f16x4(p);
-                    dsh[mt] = to_f16x4(ds);
-                }
-                f32x4 dv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-                f32x4 dk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 pf = cat_f16x4(ph[2 * ks], ph[2 * ks + 1]);
-                    const f16x8 sf = cat_f16x4(dsh[2 * ks], dsh[2 * ks + 1]);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const f16* orow = dOt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
-                        const f16* qrow = Qt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
-                        dv[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)orow, *(const f16x4*)(orow + 16)), pf, dv[dt]);
-                        dk[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)qrow, *(const f16x4*)(qrow + 16)), sf, dk[dt]);
-                    }
-                }
-                // dK^T/dV^T tiles sit as [d = 16dt+4g+r][key = l15]: every lane owns 16 contiguous bytes of a key row.
-                // They go to this window's slot of the partial buffer (plain stores); k_dkv_gather sums, per token
-                // row, the slots of every window that reads it -- deterministic, no atomics on shared rows.
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) bt[mt] = bn[mt];
-                if (ksrc[key] >= 0) {
-                    float* prow = dkv_part + ((long)wb * CFFM_NKEY_PAD + key) * 512 + h * CFFM_HD + 4 * g;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        *(f32x4*)(prow + 16 * dt) = dk[dt] * isc;
-                        *(f32x4*)(prow + 256 + 16 * dt) = dv[dt] * isc;
-                    }
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * kt + u;
+                if (t < 19) {
+                    const f16x8 kf = *(const f16x8*)(Ks + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
+                    const f16x8 vf = *(const f16x8*)(Vs + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
+                    f32x4 sv = mfma16x16x32_f16(kf, qfrag, bcur[u] + *(const f32x4*)(vflag + 16 * t + 4 * g));
+                    const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    f32x4 ds;
+                    for (int r = 0; r < 4; ++r) ds[r] = fast_exp(sv[r] - lq) * (dp[r] - Dq);
+                    dB[t < 19 ? t : 0] += ds * isc;
+                    dsh[u] = to_f16x4(ds);
+                } else {
+                    dsh[u] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
                 }
             }
+            const f16x8 dsf = cat_f16x4(dsh[0], dsh[1]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f16* kr = Kt + (16 * mt + l15) * ATT_VT_STRIDE + 32 * kt + 4 * g;
+                const f16x8 ka = cat_f16x4(*(const f16x4*)kr, *(const f16x4*)(kr + 16));
+                dq[mt] = mfma16x16x32_f16(ka, dsf, dq[mt]);
+            }
+            bcur[0] = bnxt[0];
+            bcur[1] = bnxt[1];
+        }
+        if (qcol < CFFM_WA) {
+            float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
+            *(f32x4*)(drow) = dq[0] * (scale * isc);      // d(raw q): the stored q carries the 32^-0.5 factor
+            *(f32x4*)(drow + 16) = dq[1] * (scale * isc);
         }
         __syncthreads();  // LDS is restaged for the next window
     }
-
-    if (wave < 4) {
-        const int qcol = 16 * wave + l15;
-        if (qcol < CFFM_WA) {
+    if (qcol < CFFM_WA) {
 #pragma unroll
-            for (int t = 0; t < 19; ++t)
-                for (int r = 0; r < 4; ++r) {
-                    const int key = 16 * t + 4 * g + r;
-                    if (key < CFFM_NKEY) atomicAdd(dbiasT + ((long)h * CFFM_NKEY_PAD + key) * CFFM_NQ_PAD + qcol, dB[t][r]);
-                }
+        for (int t = 0; t < 19; ++t)
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * g + r;
+                if (key < CFFM_NKEY) atomicAdd(dbiasT + ((long)h * CFFM_NKEY_PAD + key) * CFFM_NQ_PAD + qcol, dB[t][r]);
+            }
+    }
+}
+
+// grid: B*nW*8 workgroups (head fastest), 256 threads
+__global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
+                                                             const int* __restrict__ q_dst, const float* __restrict__ biasT,
+                                                             const float* __restrict__ ao, const float* __restrict__ dao,
+                                                             const float* __restrict__ lse_in, float* __restrict__ dkv_part) {
+    CFFM_DYN_SMEM(smem);
+    f16* Qs = (f16*)smem;
+    f16* dOs = Qs + 64 * ATT_KS_STRIDE;
+    f16* Ks = dOs + 64 * ATT_KS_STRIDE;
+    f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+    f16* Qt = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+    f16* dOt = Qt + 32 * ATT_QT_STRIDE;
+    float* vflag = (float*)(dOt + 32 * ATT_QT_STRIDE);
+    float* slse = vflag + CFFM_NKEY_PAD;
+    float* sD = slse + 64;
+    float* smax = sD + 64;
+
+    const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int* ksrc = key_src + w * CFFM_NKEY_PAD;
+    const h16* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;
+
+    // Q: threads 0..127 own (query pair, 16-byte chunk); dO / O: every thread owns (query pair, 4-channel chunk)
+    const int pr = tid >> 3, c = tid & 7, i0 = 2 * pr, i1 = i0 + 1;
+    const int qp = tid >> 2, qc = tid & 3;
+    const int t0 = (i0 < CFFM_WA) ? q_dst[w * CFFM_WA + i0] : -1, t1 = (i1 < CFFM_WA) ? q_dst[w * CFFM_WA + i1] : -1;
+    f16x8 z8;
+    for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
+    f16x8 q0 = z8, q1 = z8;
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 r0 = z4, r1 = z4, o0 = z4, o1 = z4;
+    if (tid < 128) {
+        if (2 * qp < CFFM_WA) q0 = ld_h8(base + (long)(w * CFFM_WA + 2 * qp) * 768 + 8 * qc);
+        if (2 * qp + 1 < CFFM_WA) q1 = ld_h8(base + (long)(w * CFFM_WA + 2 * qp + 1) * 768 + 8 * qc);
+    }
+    if (t0 >= 0) { const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c; r0 = ld4(dao + off); o0 = ld4(ao + off); }
+    if (t1 >= 0) { const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c; r1 = ld4(dao + off); o1 = ld4(ao + off); }
+    if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid];
+    stage_kv<256, false>(base, ksrc, Ks, Vs, nullptr, vflag, tid);
+    if (tid < 128) {   // Q rows and the transposed Q image
+        *(f16x8*)(Qs + (2 * qp) * ATT_KS_STRIDE + 8 * qc) = q0;
+        *(f16x8*)(Qs + (2 * qp + 1) * ATT_KS_STRIDE + 8 * qc) = q1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f16x2 pq; pq[0] = q0[e]; pq[1] = q1[e];
+            *(f16x2*)(Qt + (8 * qc + e) * ATT_QT_STRIDE + 2 * qp) = pq;
+        }
+    }
+    // D = rowsum(dO * O) (the 8 chunks of a query sit in 8 adjacent lanes) and the window's |dO| maximum
+    float d0 = r0[0] * o0[0] + r0[1] * o0[1] + r0[2] * o0[2] + r0[3] * o0[3];
+    float d1 = r1[0] * o1[0] + r1[1] * o1[1] + r1[2] * o1[2] + r1[3] * o1[3];
+    float amax = 0.f;
+    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
+    d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64); d0 += __shfl_xor(d0, 4, 64);
+    d1 += __shfl_xor(d1, 1, 64); d1 += __shfl_xor(d1, 2, 64); d1 += __shfl_xor(d1, 4, 64);
+    amax = wave_max(amax);
+    if (lane == 0) smax[wave] = amax;
+    __syncthreads();
+    const float am = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    int ex = 0;
+    if (am > 0.f) frexpf(am, &ex);
+    const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f, isc = 1.f / sc;   // max|dO * sc| in [1,2)
+    r0 *= sc; r1 *= sc;
+    if (c == 0) { sD[i0] = d0 * sc; sD[i1] = d1 * sc; }
+    *(f16x4*)(dOs + i0 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r0);
+    *(f16x4*)(dOs + i1 * ATT_KS_STRIDE + 4 * c) = to_f16x4(r1);
+    for (int e = 0; e < 4; ++e) {
+        f16x2 pq; pq[0] = (f16)r0[e]; pq[1] = (f16)r1[e];
+        *(f16x2*)(dOt + (4 * c + e) * ATT_QT_STRIDE + i0) = pq;
+    }
+    __syncthreads();
+
+    f32x4 bt[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) bt[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + 16 * wave + l15) * CFFM_NQ_PAD + 4 * g + 16 * mt);
+    for (int t = wave; t < 19; t += 4) {
+        const int key = 16 * t + l15;
+        f32x4 bn[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) bn[mt] = bt[mt];
+        if (t + 4 < 19) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) bn[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + key + 64) * CFFM_NQ_PAD + 4 * g + 16 * mt);
+        }
+        const f16x8 kfrag = *(const f16x8*)(Ks + key * ATT_KS_STRIDE + 8 * g);
+        const f16x8 vfrag = *(const f16x8*)(Vs + key * ATT_KS_STRIDE + 8 * g);
+        const float vf = vflag[key];
+        f16x4 ph[4], dsh[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f16x8 qa = *(const f16x8*)(Qs + (16 * mt + l15) * ATT_KS_STRIDE + 8 * g);
+            const f16x8 da = *(const f16x8*)(dOs + (16 * mt + l15) * ATT_KS_STRIDE + 8 * g);
+            const f32x4 sv = mfma16x16x32_f16(qa, kfrag, bt[mt] + vf);
+            const f32x4 dp = mfma16x16x32_f16(da, vfrag, (f32x4){0.f, 0.f, 0.f, 0.f});
+            const f32x4 lq = *(const f32x4*)(slse + 16 * mt + 4 * g), Dq = *(const f32x4*)(sD + 16 * mt + 4 * g);
+            f32x4 p, ds;
+            for (int r = 0; r < 4; ++r) { p[r] = fast_exp(sv[r] - lq[r]); ds[r] = p[r] * (dp[r] - Dq[r]); }
+            ph[mt] = to_f16x4(p);
+            dsh[mt] = to_f16x4(ds);
+        }
+        f32x4 dv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        f32x4 dk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 pf = cat_f16x4(ph[2 * ks], ph[2 * ks + 1]);
+            const f16x8 sf = cat_f16x4(dsh[2 * ks], dsh[2 * ks + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const f16* orow = dOt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
+                const f16* qrow = Qt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
+                dv[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)orow, *(const f16x4*)(orow + 16)), pf, dv[dt]);
+                dk[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)qrow, *(const f16x4*)(qrow + 16)), sf, dk[dt]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) bt[mt] = bn[mt];
+        // dK^T/dV^T tiles sit as [d = 16dt+4g+r][key = l15]: every lane owns 16 contiguous bytes of a key row of this
+        // window's slot in the partial buffer
+        if (ksrc[key] >= 0) {
+            float* prow = dkv_part + ((long)wb * CFFM_NKEY_PAD + key) * 512 + h * CFFM_HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                *(f32x4*)(prow + 16 * dt) = dk[dt] * isc;
+                *(f32x4*)(prow + 256 + 16 * dt) = dv[dt] * isc;
+            }
         }
     }
 }
