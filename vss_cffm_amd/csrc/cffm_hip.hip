@@ -299,7 +299,8 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
 
 static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
     const int total = g->B * g->nW;
-    int ng = total < 64 ? total : 64;  // 8 heads x 64 groups = two 256-thread workgroups per CU
+    const int want = 32 * BWQ_OCC;     // 8 heads x 32 groups = one 256-thread workgroup per CU and occupancy slot
+    int ng = total < want ? total : want;
     *per_group = (total + ng - 1) / ng;
     return (total + *per_group - 1) / *per_group;
 }

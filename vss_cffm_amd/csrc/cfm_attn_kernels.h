@@ -166,6 +166,9 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 // dO is rescaled by a power of two (per wave / per window) so every f16 gradient operand sits near 1 (training-size gradients
 // of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
 // =====================================================================================================
+#ifndef BWQ_OCC
+#define BWQ_OCC 1  // workgroups per CU of the query-owner backward kernel: 1 = 512-register budget, no spills (measured faster than 2)
+#endif
 #define ATT_BWQ_LDS ((2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4)
 #define ATT_BWK_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
                      CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
@@ -217,7 +220,7 @@ __device__ __forceinline__ void stage_kv(const h16* __restrict__ base, const int
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_q(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
+__global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
                                                             const int* __restrict__ q_dst, const float* __restrict__ bias,
                                                             const float* __restrict__ ao, const float* __restrict__ dao,
                                                             const float* __restrict__ lse_in, float* __restrict__ dqkv,

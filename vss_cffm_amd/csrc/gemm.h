@@ -20,15 +20,16 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
         out = lib_scratch((size_t)ksplit * split_stride);
         if (!out) return -1;
     }
-    const unsigned gx = (N + GEMM_BN - 1) / GEMM_BN;
-    // 128-row tiles when they already fill the chip, 64-row tiles otherwise
-    if ((long)gx * ((M + 127) / 128) * ksplit >= 384) {
-        CFFM_LAUNCH((k_gemm_split<128, A_T, B_T, EPI>), (gx, (M + 127) / 128, ksplit), (256), GEMM_LDS(128), st, A, B, out, M, N, K, lda,
-                    ldb, ldc, klen, split_stride, bias, aux);
-    } else {
-        CFFM_LAUNCH((k_gemm_split<64, A_T, B_T, EPI>), (gx, (M + 63) / 64, ksplit), (256), GEMM_LDS(64), st, A, B, out, M, N, K, lda, ldb,
-                    ldc, klen, split_stride, bias, aux);
-    }
+    // Largest tile that still gives every CU >= 2 workgroups (they hide each other's staging / epilogue phases);
+    // 64 x 64 otherwise (small-N layers: proj, fc2, the input-gradient GEMMs into 256 channels).
+    const long b128 = (long)((N + 127) / 128) * ((M + 127) / 128) * ksplit, b64n = (long)((N + 127) / 128) * ((M + 63) / 64) * ksplit;
+#define GEMM_GO(BM_, BN_)                                                                                                      \
+    CFFM_LAUNCH((k_gemm_split<BM_, BN_, A_T, B_T, EPI>), ((N + BN_ - 1) / BN_, (M + BM_ - 1) / BM_, ksplit), (256), GEMM_LDS(BM_, BN_), st, A, \
+                B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux)
+    if (b128 >= 512) GEMM_GO(128, 128);
+    else if (b64n >= 512) GEMM_GO(64, 128);
+    else GEMM_GO(64, 64);
+#undef GEMM_GO
     if (ksplit > 1) {
         const long n4 = split_stride / 4;
         CFFM_LAUNCH(k_sum_splits, ((unsigned)((n4 + 255) / 256)), (256), 0, st, (const float*)out, ksplit, split_stride, C);
@@ -58,7 +59,7 @@ static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int
 }
 // dw[N,K] = dy[M,N]^T x[M,K]: output N x K, contraction = M (long) split over workgroups
 static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
-    const int tiles = ((N + 127) / 128) * ((K + GEMM_BN - 1) / GEMM_BN);
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     int ksplit = (384 + tiles - 1) / tiles;
     const int maxsplit = (int)((M + 4 * GEMM_BK - 1) / (4 * GEMM_BK));   // at least 4 K-tiles per split
     if (ksplit > maxsplit) ksplit = maxsplit;

@@ -13,7 +13,8 @@
 //   forward        y  = x  w^T : A = x  (i=row, k contiguous),  B = w  [N,K]  (k contiguous)        <F,F>
 //   input gradient dx = dy w   : A = dy (k = n contiguous),     B(j=k',k=n) = w[n*K+k'] -> B_T       <F,T>
 //   weight gradient dw = dy^T x: A(i=n,k=m) = dy[m*N+n] -> A_T, B(j=k',k=m) = x[m*K+k'] -> B_T       <T,T>
-// Tiles: BM x 128 x 32 per 256-thread workgroup (2x2 waves, each (BM/2) x 64 as 16x16x32 MFMA tiles), LDS rows
+// Tiles: BM x BN x 32 (BM, BN in {64,128}, chosen so that >= 2-3 workgroups share a CU and hide each other's staging)
+// per 256-thread workgroup (2x2 waves, each (BM/2) x (BN/2) as 16x16x32 MFMA tiles), LDS rows
 // padded to 80 B (conflict-free ds_read_b128 fragments), next K-tile prefetched into registers while the
 // current one is multiplied.  The weight-gradient form splits its long contraction (M ~ 10^4) over
 // gridDim.z: every split writes its own partial output (plain coalesced stores) and a second tiny kernel sums
@@ -60,7 +61,6 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0  // profiling only: 1 = no MFMA, 2 = no global loads in the loop, 4 = no LDS staging in the loop
 #endif
-#define GEMM_BN 128
 #define GEMM_BK 32
 #define GEMM_LD 40  // bf16 per LDS row (32 + 8 pad)
 #define GEMM_TLD 68 // floats per row of the epilogue transposition tile (64 + 4 pad)
@@ -158,13 +158,13 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
     return f;
 }
 
-#define GEMM_LDS(BM) (((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * GEMM_BN) * GEMM_LD * 2) : (4 * 32 * GEMM_TLD * 4))
+#define GEMM_LDS(BM, BN) (((2 * (BM) + 2 * (BN)) * GEMM_LD * 2) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * (BN)) * GEMM_LD * 2) : (4 * 32 * GEMM_TLD * 4))
 
-// grid (ceil(N/128), ceil(M/BM), ksplit).  K range of split z: [z*klen, min(K, (z+1)*klen)), klen multiple of 32.
+// grid (ceil(N/BN), ceil(M/BM), ksplit); BM, BN in {64, 128}; wave tile (BM/2) x (BN/2).  K range of split z: [z*klen, min(K, (z+1)*klen)), klen multiple of 32.
 // EPI: 0 plain (+bias) | 1 GELU: C = raw product (saved for backward), aux = gelu(raw + bias) | 2 residual: C = aux + raw + bias
 //      3 q|k|v: nothing in C; aux (h16 [M,N]) = f16(raw + bias), the q third (cols < 256) also times 32^-0.5 -- exactly the
 //        values the attention kernels used to form from the fp32 product, stored once at half the bytes
-template <int BM, bool A_T, bool B_T, int EPI>
+template <int BM, int BN, bool A_T, bool B_T, int EPI>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                                      const float* __restrict__ bias, float* __restrict__ aux) {
@@ -172,44 +172,44 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
     bf16* Ah = (bf16*)smem;
     bf16* Al = Ah + BM * GEMM_LD;
     bf16* Bh = Al + BM * GEMM_LD;
-    bf16* Bl = Bh + GEMM_BN * GEMM_LD;
+    bf16* Bl = Bh + BN * GEMM_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int kbeg = blockIdx.z * klen, kend = (kbeg + klen < K) ? kbeg + klen : K;
-    constexpr int MT = BM / 32;  // 16-row tiles per wave along M (wave tile = BM/2 x 64)
-    const int wr = (wave >> 1) * (BM / 2), wc = (wave & 1) * 64;
-    f32x4 acc[MT][4];
+    constexpr int MT = BM / 32, NT = BN / 32;  // 16x16 tiles per wave along M and N (wave tile = BM/2 x BN/2)
+    const int wr = (wave >> 1) * (BM / 2), wc = (wave & 1) * (BN / 2);
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     TileRegs<BM> ra;
-    TileRegs<GEMM_BN> rb;
+    TileRegs<BN> rb;
     tile_load<BM, A_T>(ra, A, lda, m0, M, kbeg, kend, tid);
-    tile_load<GEMM_BN, B_T>(rb, B, ldb, n0, N, kbeg, kend, tid);
+    tile_load<BN, B_T>(rb, B, ldb, n0, N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
         if (!(GEMM_ABLATE & 4) || k0 == kbeg) {
             tile_store<BM, A_T>(ra, Ah, Al, tid);
-            tile_store<GEMM_BN, B_T>(rb, Bh, Bl, tid);
+            tile_store<BN, B_T>(rb, Bh, Bl, tid);
         }
         __syncthreads();
         if (k0 + GEMM_BK < kend && !(GEMM_ABLATE & 2)) {  // next K-tile flies while this one is multiplied
             tile_load<BM, A_T>(ra, A, lda, m0, M, k0 + GEMM_BK, kend, tid);
-            tile_load<GEMM_BN, B_T>(rb, B, ldb, n0, N, k0 + GEMM_BK, kend, tid);
+            tile_load<BN, B_T>(rb, B, ldb, n0, N, k0 + GEMM_BK, kend, tid);
         }
-        bf16x8 bh[4], bl[4];
+        bf16x8 bh[NT], bl[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bh[j] = frag_read<GEMM_BN, B_T>(Bh, wc + 16 * j + l15, g);
-            bl[j] = frag_read<GEMM_BN, B_T>(Bl, wc + 16 * j + l15, g);
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = frag_read<BN, B_T>(Bh, wc + 16 * j + l15, g);
+            bl[j] = frag_read<BN, B_T>(Bl, wc + 16 * j + l15, g);
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const bf16x8 ah = frag_read<BM, A_T>(Ah, wr + 16 * i + l15, g);
             const bf16x8 al = frag_read<BM, A_T>(Al, wr + 16 * i + l15, g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 if (GEMM_ABLATE & 1) { acc[i][j][0] += (float)ah[0] + (float)bl[j][0] + (float)al[1] + (float)bh[j][1]; continue; }
                 acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
                 acc[i][j] = mfma16x16x32_bf16(al, bh[j], acc[i][j]);
@@ -222,22 +222,24 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
     // store instruction would touch 4 rows x 64 B; instead each wave transposes 32 rows x 64 columns at a time through
     // its own LDS slice (the K-loop's operand images are dead) and writes whole 256-byte row segments as 16-B stores
     float* T = (float*)smem + wave * (32 * GEMM_TLD);
+    constexpr int WN = BN / 2;            // columns of a wave tile
+    constexpr int LPR = WN / 4;           // lanes per row (16-byte chunks): 16 or 8
 #pragma unroll
     for (int half = 0; half < MT / 2; ++half) {
         wave_lds_sync();
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T[(16 * ii + 4 * g + r) * GEMM_TLD + 16 * j + l15] = acc[2 * half + ii][j][r];
         wave_lds_sync();
-        const int c4 = 4 * (lane & 15), col = n0 + wc + c4;
+        const int c4 = 4 * (lane % LPR), col = n0 + wc + c4;
         f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (bias && blockIdx.z == 0 && col + 3 < N) bv = *(const f32x4*)(bias + col);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rl = (lane >> 4) + 4 * it, row = m0 + wr + 32 * half + rl;
+        for (int it = 0; it < 32 * LPR / 64; ++it) {
+            const int rl = lane / LPR + (64 / LPR) * it, row = m0 + wr + 32 * half + rl;
             if (row >= M) continue;
             f32x4 v = *(const f32x4*)(T + rl * GEMM_TLD + c4);
             float* dst = C + (long)blockIdx.z * split_stride + (long)row * ldc + col;
@@ -265,9 +267,7 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
                 *(f32x4*)dst = v;
             } else {
                 for (int e = 0; e < 4; ++e)
-                    if (col + e < N) {
-                        dst[e] = v[e] + ((bias && blockIdx.z == 0 && col + 3 >= N) ? bias[col + e] : 0.f);
-                    }
+                    if (col + e < N) dst[e] = v[e] + ((bias && blockIdx.z == 0 && col + 3 >= N) ? bias[col + e] : 0.f);
             }
         }
     }
