@@ -3,6 +3,7 @@
 // library are the CFFA / CFM path around them.  Row-major operands are mapped onto rocBLAS'
 // column-major interface by swapping operand roles (C^T = B^T A^T), never by copying.
 #pragma once
+#include <stdlib.h>
 #include "gemm_kernels.h"
 
 // ---- hand-written split-bf16 MFMA path (default) -------------------------------------------------------------
@@ -20,15 +21,14 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
         out = lib_scratch((size_t)ksplit * split_stride);
         if (!out) return -1;
     }
-    // Largest tile that still gives every CU >= 2 workgroups (they hide each other's staging / epilogue phases);
-    // 64 x 64 otherwise (small-N layers: proj, fc2, the input-gradient GEMMs into 256 channels).
-    const long b128 = (long)((N + 127) / 128) * ((M + 127) / 128) * ksplit, b64n = (long)((N + 127) / 128) * ((M + 63) / 64) * ksplit;
-#define GEMM_GO(BM_, BN_)                                                                                                      \
-    CFFM_LAUNCH((k_gemm_split<BM_, BN_, A_T, B_T, EPI>), ((N + BN_ - 1) / BN_, (M + BM_ - 1) / BM_, ksplit), (256), GEMM_LDS(BM_, BN_), st, A, \
+    const long b128 = (long)((N + 127) / 128) * ((M + 127) / 128) * ksplit;
+#define GEMM_GO(BM_, BN_, PF_)                                                                                                    \
+    CFFM_LAUNCH((k_gemm_split<BM_, BN_, A_T, B_T, EPI, PF_>), ((N + BN_ - 1) / BN_, (M + BM_ - 1) / BM_, ksplit), (256), GEMM_LDS(BM_, BN_), st, A, \
                 B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux)
-    if (b128 >= 512) GEMM_GO(128, 128);
-    else if (b64n >= 512) GEMM_GO(64, 128);
-    else GEMM_GO(64, 64);
+    // measured on MI355X (scripts/gemm_bench.py, CFFM-B1 shapes): 128x128 wins when it already gives >= 384 workgroups
+    // (qkv / fc1 forward, the 1024-wide input gradient), 64x64 otherwise; prefetch depth beyond the listed one is neutral.
+    if (b128 >= 384) GEMM_GO(128, 128, 1);
+    else GEMM_GO(64, 64, 3);
 #undef GEMM_GO
     if (ksplit > 1) {
         const long n4 = split_stride / 4;
@@ -130,7 +130,6 @@ static int gemm_tn_lib(const float* dy, const float* x, float* dw, long M, int N
 #endif
 
 // ---- dispatch: CFFM_GEMM=lib selects the exact-fp32 library path (rocBLAS SGEMM; host loops in the emulator build) --------
-#include <stdlib.h>
 static int gemm_use_lib() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("CFFM_GEMM"); v = (e && e[0] == 'l') ? 1 : 0; }

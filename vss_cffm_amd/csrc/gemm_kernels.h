@@ -15,7 +15,7 @@
 //   weight gradient dw = dy^T x: A(i=n,k=m) = dy[m*N+n] -> A_T, B(j=k',k=m) = x[m*K+k'] -> B_T       <T,T>
 // Tiles: BM x BN x 32 (BM, BN in {64,128}, chosen so that >= 2-3 workgroups share a CU and hide each other's staging)
 // per 256-thread workgroup (2x2 waves, each (BM/2) x (BN/2) as 16x16x32 MFMA tiles), LDS rows
-// padded to 80 B (conflict-free ds_read_b128 fragments), next K-tile prefetched into registers while the
+// padded to 80 B (conflict-free ds_read_b128 fragments), the next PF K-tiles in flight in registers while the
 // current one is multiplied.  The weight-gradient form splits its long contraction (M ~ 10^4) over
 // gridDim.z: every split writes its own partial output (plain coalesced stores) and a second tiny kernel sums
 // them -- deterministic, and row-coalesced fp32 atomics measured 3-4x slower than this on gfx950.
@@ -58,9 +58,6 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-#ifndef GEMM_ABLATE
-#define GEMM_ABLATE 0  // profiling only: 1 = no MFMA, 2 = no global loads in the loop, 4 = no LDS staging in the loop
-#endif
 #define GEMM_BK 32
 #define GEMM_LD 40  // bf16 per LDS row (32 + 8 pad)
 #define GEMM_TLD 68 // floats per row of the epilogue transposition tile (64 + 4 pad)
@@ -164,7 +161,7 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
 // EPI: 0 plain (+bias) | 1 GELU: C = raw product (saved for backward), aux = gelu(raw + bias) | 2 residual: C = aux + raw + bias
 //      3 q|k|v: nothing in C; aux (h16 [M,N]) = f16(raw + bias), the q third (cols < 256) also times 32^-0.5 -- exactly the
 //        values the attention kernels used to form from the fp32 product, stored once at half the bytes
-template <int BM, int BN, bool A_T, bool B_T, int EPI>
+template <int BM, int BN, bool A_T, bool B_T, int EPI, int PF>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                                      const float* __restrict__ bias, float* __restrict__ aux) {
@@ -184,39 +181,48 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    TileRegs<BM> ra;
-    TileRegs<BN> rb;
-    tile_load<BM, A_T>(ra, A, lda, m0, M, kbeg, kend, tid);
-    tile_load<BN, B_T>(rb, B, ldb, n0, N, kbeg, kend, tid);
-    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-        if (!(GEMM_ABLATE & 4) || k0 == kbeg) {
-            tile_store<BM, A_T>(ra, Ah, Al, tid);
-            tile_store<BN, B_T>(rb, Bh, Bl, tid);
-        }
-        __syncthreads();
-        if (k0 + GEMM_BK < kend && !(GEMM_ABLATE & 2)) {  // next K-tile flies while this one is multiplied
-            tile_load<BM, A_T>(ra, A, lda, m0, M, k0 + GEMM_BK, kend, tid);
-            tile_load<BN, B_T>(rb, B, ldb, n0, N, k0 + GEMM_BK, kend, tid);
-        }
-        bf16x8 bh[NT], bl[NT];
+    // PF K-tiles are always in flight in registers: a K-step (~0.1-0.4 us of MFMA) is far shorter than the ~1-2 us a
+    // tile takes to arrive from HBM / Infinity Cache, and co-resident workgroups run in lockstep, so they cannot hide
+    // each other's waits; tile t+PF is requested before tile t is multiplied.
+    TileRegs<BM> ra[PF];
+    TileRegs<BN> rb[PF];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bh[j] = frag_read<BN, B_T>(Bh, wc + 16 * j + l15, g);
-            bl[j] = frag_read<BN, B_T>(Bl, wc + 16 * j + l15, g);
-        }
+    for (int u = 0; u < PF; ++u) {   // past kend -> zeros, never used
+        tile_load<BM, A_T>(ra[u], A, lda, m0, M, kbeg + u * GEMM_BK, kend, tid);
+        tile_load<BN, B_T>(rb[u], B, ldb, n0, N, kbeg + u * GEMM_BK, kend, tid);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += PF * GEMM_BK) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const bf16x8 ah = frag_read<BM, A_T>(Ah, wr + 16 * i + l15, g);
-            const bf16x8 al = frag_read<BM, A_T>(Al, wr + 16 * i + l15, g);
+        for (int u = 0; u < PF; ++u) {
+            const int kk = k0 + u * GEMM_BK;
+            if (kk < kend) {   // uniform across the workgroup
+                tile_store<BM, A_T>(ra[u], Ah, Al, tid);
+                tile_store<BN, B_T>(rb[u], Bh, Bl, tid);
+                __syncthreads();
+                if (kk + PF * GEMM_BK < kend) {
+                    tile_load<BM, A_T>(ra[u], A, lda, m0, M, kk + PF * GEMM_BK, kend, tid);
+                    tile_load<BN, B_T>(rb[u], B, ldb, n0, N, kk + PF * GEMM_BK, kend, tid);
+                }
+                bf16x8 bh[NT], bl[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (GEMM_ABLATE & 1) { acc[i][j][0] += (float)ah[0] + (float)bl[j][0] + (float)al[1] + (float)bh[j][1]; continue; }
-                acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
-                acc[i][j] = mfma16x16x32_bf16(al, bh[j], acc[i][j]);
-                acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) {
+                    bh[j] = frag_read<BN, B_T>(Bh, wc + 16 * j + l15, g);
+                    bl[j] = frag_read<BN, B_T>(Bl, wc + 16 * j + l15, g);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const bf16x8 ah = frag_read<BM, A_T>(Ah, wr + 16 * i + l15, g);
+                    const bf16x8 al = frag_read<BM, A_T>(Al, wr + 16 * i + l15, g);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
+                        acc[i][j] = mfma16x16x32_bf16(al, bh[j], acc[i][j]);
+                        acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
+                    }
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
     // epilogue: acc[i][j][r] = C[m0 + wr + 16i + 4g + r][n0 + wc + 16j + l15].  Stored straight from the MFMA layout a
     // store instruction would touch 4 rows x 64 B; instead each wave transposes 32 rows x 64 columns at a time through
