@@ -172,13 +172,20 @@ def main():
             by = algorithmic_bytes_attn_fwd(b, nw, hw)
             ach = by / dur_s / 1e9
             tf = attn_flops(b, nw) / dur_s / 1e12
+            traffic, traffic_note = None, 'no PMC summary found under profiles/'
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_attn_fwd.json')
+            if os.path.isfile(pmc):   # PMC passes are separate rocprofv3 runs (scripts/pmc_attn.sh); per launch at B = 2 clips
+                pj = json.load(open(pmc))
+                traffic = int(pj['hbm_bytes_per_launch_raw'] * b / pj['batch_clips'])
+                traffic_note = 'FETCH_SIZE+WRITE_SIZE of %s, scaled to %d clips; %s' % (pj['source'], b, pj['calibration'])
             roof = {'kernel': 'k_cfm_attn_fwd', 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_note': traffic_note,
                     'algorithmic_bytes_per_launch': by, 'avg_launch_us': stages['cfm_attn_fwd']['avg_us'],
                     'mfma_achieved_tflops': round(tf, 2), 'mfma_peak_tflops': MFMA_F16_PEAK_TF,
                     'mfma_frac': round(tf / MFMA_F16_PEAK_TF, 5),
-                    'note': 'timed live with HIP events on the launch stream inside the timed region; '
-                            'traffic (PMC) is collected by separate rocprofv3 --pmc passes, see profiles/'}
+                    'note': 'achieved = SURVEY 8(d) algorithmic bytes (fp32 q/k/v + output: 18.37 MB per clip-block) / average '
+                            'launch time, timed live with HIP events on the launch stream inside the timed region; q/k/v are '
+                            'stored as f16 since v4, so the real minimum traffic is 11.6 MB per clip-block'}
         out = {
             'metric': 'clips/sec (fwd+bwd) CFFM-B1 480x480 T=4 hot path (CFFA+CFM, decoder_focal depth 2)',
             'value': round(world * b * args.steps / dt, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
