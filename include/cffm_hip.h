@@ -70,7 +70,7 @@ long cffm_layer_saved_floats(const cffm_geom* g, int depth);  /* NHWC stack + de
 long cffm_layer_scratch_floats(const cffm_geom* g);
 
 /* ---- optional per-stage HIP-event timing on the caller's stream (bench.py's live roofline numbers) ---- */
-int cffm_profile_enable(int on);
+int cffm_profile_enable(int stage_mask); /* bit i = stage i; 0 off; -1 all (perturbs: two event records per launch) */
 int cffm_profile_stage_count(void);
 const char* cffm_profile_stage_name(int i);
 int cffm_profile_collect(float* ms /*[stage_count]*/, int* calls /*[stage_count]*/); /* synchronises, sums, clears */

@@ -19,9 +19,13 @@ def step():
     (m(x)[:, -1] * gy).sum().backward()
 for _ in range(5): step()
 n = lib.cffm_profile_stage_count(); ms, cnt = (C.c_float * n)(), (C.c_int * n)()
-lib.cffm_profile_collect(ms, cnt); lib.cffm_profile_enable(1)
+lib.cffm_profile_collect(ms, cnt)
+torch.cuda.synchronize(); import time; t0 = time.perf_counter()
+for _ in range(a.steps): step()
+torch.cuda.synchronize(); clean = time.perf_counter() - t0
+lib.cffm_profile_enable(-1)
 torch.cuda.synchronize(); import time; t0 = time.perf_counter()
 for _ in range(a.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 lib.cffm_profile_enable(0); lib.cffm_profile_collect(ms, cnt)
-print('%s: %.3f ms/step' % (a.lib or 'product', 1e3 * dt / a.steps), ' '.join('%s=%.1fus' % (lib.cffm_profile_stage_name(i).decode(), 1e3 * ms[i] / cnt[i]) for i in range(n) if cnt[i]))
+print('%s: %.3f ms/step (%.3f with stage events)' % (a.lib or 'product', 1e3 * clean / a.steps, 1e3 * dt / a.steps), ' '.join('%s=%.1fus' % (lib.cffm_profile_stage_name(i).decode(), 1e3 * ms[i] / cnt[i]) for i in range(n) if cnt[i]))
