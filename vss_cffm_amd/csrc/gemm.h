@@ -13,7 +13,7 @@ __global__ void k_sum_splits(const float* __restrict__ part, int nsplit, long n,
 template <bool A_T, bool B_T, int EPI = 0>
 static int gemm_split_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int ksplit,
                              hipStream_t st, const float* bias = nullptr, float* aux = nullptr) {
-    int klen = ((K + ksplit - 1) / ksplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    int klen = ((K + ksplit - 1) / ksplit + 63) / 64 * 64;
     ksplit = (K + klen - 1) / klen;
     float* out = C;
     const long split_stride = (long)M * ldc;
@@ -22,13 +22,19 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
         if (!out) return -1;
     }
     const long b128 = (long)((N + 127) / 128) * ((M + 127) / 128) * ksplit;
-#define GEMM_GO(BM_, BN_, PF_)                                                                                                    \
-    CFFM_LAUNCH((k_gemm_split<BM_, BN_, A_T, B_T, EPI, PF_>), ((N + BN_ - 1) / BN_, (M + BM_ - 1) / BM_, ksplit), (256), GEMM_LDS(BM_, BN_), st, A, \
+#define GEMM_GO(BM_, BN_, BK_, PF_)                                                                                                    \
+    CFFM_LAUNCH((k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_>), ((N + BN_ - 1) / BN_, (M + BM_ - 1) / BM_, ksplit), (256), \
+                GEMM_LDS(BM_, BN_, BK_), st, A, \
                 B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux)
     // measured on MI355X (scripts/gemm_bench.py, CFFM-B1 shapes): 128x128 wins when it already gives >= 384 workgroups
     // (qkv / fc1 forward, the 1024-wide input gradient), 64x64 otherwise; prefetch depth beyond the listed one is neutral.
-    if (b128 >= 384) GEMM_GO(128, 128, 1);
-    else GEMM_GO(64, 64, 3);
+    static int bk64 = -1;   // tuning aid: CFFM_GEMM_BK=64
+    if (bk64 < 0) { const char* e = getenv("CFFM_GEMM_BK"); bk64 = (e && atoi(e) == 64) ? 1 : 0; }
+    if (bk64) {
+        if (b128 >= 384) GEMM_GO(128, 128, 64, 1);
+        else GEMM_GO(64, 64, 64, 2);
+    } else if (b128 >= 384) GEMM_GO(128, 128, 32, 1);
+    else GEMM_GO(64, 64, 32, 3);
 #undef GEMM_GO
     if (ksplit > 1) {
         const long n4 = split_stride / 4;
@@ -61,7 +67,7 @@ static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int
 static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     int ksplit = (384 + tiles - 1) / tiles;
-    const int maxsplit = (int)((M + 4 * GEMM_BK - 1) / (4 * GEMM_BK));   // at least 4 K-tiles per split
+    const int maxsplit = (int)((M + 127) / 128);   // at least 128 rows of the contraction per split
     if (ksplit > maxsplit) ksplit = maxsplit;
     if (ksplit < 1) ksplit = 1;
     return gemm_split_launch<true, true>(dy, x, dw, N, K, (int)M, N, K, K, ksplit, st);

@@ -58,35 +58,34 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-#define GEMM_BK 32
-#define GEMM_LD 40  // bf16 per LDS row (32 + 8 pad)
+#define GEMM_LD(BK) ((BK) + 8)  // bf16 per LDS row (BK + 8 pad: 80 / 144 B strides keep ds_read_b128 fragments conflict-free)
 #define GEMM_TLD 68 // floats per row of the epilogue transposition tile (64 + 4 pad)
 
 // LDS image of an operand tile (ROWS x 32 k), hi and lo parts:
-//   k-contiguous operand (TR = false): [ROWS][GEMM_LD] bf16, fragment = one ds_read_b128 of 8 consecutive k;
-//   row-contiguous operand (TR = true): k-PAIR interleaved dwords [16 k-pairs][ROWS + 4]: a thread that loaded the same
+//   k-contiguous operand (TR = false): [ROWS][BK + 8] bf16, fragment = one ds_read_b128 of 8 consecutive k;
+//   row-contiguous operand (TR = true): k-PAIR interleaved dwords [BK/2 k-pairs][ROWS + 4]: a thread that loaded the same
 //     4 rows at k and k+1 (two coalesced 16-B loads) packs (k, k+1) per row into one dword and writes 16 B at once;
 //     a fragment is 4 x ds_read_b32 (k = 8g + 2jj + {0,1}), 16 lanes reading 16 consecutive dwords (conflict-free,
 //     the +4 pad puts the two lane groups of a half-wave on disjoint banks).
 #define GEMM_TS(ROWS) ((ROWS) + 4)
-template <int ROWS>
-struct TileRegs { f32x4 v[ROWS / 32]; };
+template <int ROWS, int BK>
+struct TileRegs { f32x4 v[ROWS * BK / 1024]; };
 
 // global -> registers
-template <int ROWS, bool TR>
-__device__ __forceinline__ void tile_load(TileRegs<ROWS>& r, const float* __restrict__ P, int ld, int row0, int nrows,
+template <int ROWS, bool TR, int BK>
+__device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& r, const float* __restrict__ P, int ld, int row0, int nrows,
                                           int k0, int kend, int tid) {
     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!TR) {
 #pragma unroll
-        for (int it = 0; it < ROWS / 32; ++it) {
+        for (int it = 0; it < ROWS * BK / 1024; ++it) {
             const int item = tid + 256 * it;
-            const int row = row0 + (item >> 3), k = k0 + 4 * (item & 7);
+            const int row = row0 + item / (BK / 4), k = k0 + 4 * (item % (BK / 4));
             r.v[it] = (row < nrows && k < kend) ? *(const f32x4*)(P + (long)row * ld + k) : z;   // kend, k multiples of 4
         }
     } else {
 #pragma unroll
-        for (int it = 0; it < ROWS / 64; ++it) {
+        for (int it = 0; it < ROWS * BK / 2048; ++it) {
             const int item = tid + 256 * it;
             const int kp = item / (ROWS / 4), row = row0 + 4 * (item % (ROWS / 4));
 #pragma unroll
@@ -114,21 +113,21 @@ __device__ __forceinline__ uint32_t pack_bf16(bf16 a, bf16 b) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // registers -> LDS (split into hi / lo bf16 images)
-template <int ROWS, bool TR>
-__device__ __forceinline__ void tile_store(const TileRegs<ROWS>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid) {
+template <int ROWS, bool TR, int BK>
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid) {
     if (!TR) {
 #pragma unroll
-        for (int it = 0; it < ROWS / 32; ++it) {
+        for (int it = 0; it < ROWS * BK / 1024; ++it) {
             const int item = tid + 256 * it;
             bf16x4 h, l;
             split4(r.v[it], h, l);
-            const int row = item >> 3, kc = 4 * (item & 7);
-            *(bf16x4*)(hi + row * GEMM_LD + kc) = h;
-            *(bf16x4*)(lo + row * GEMM_LD + kc) = l;
+            const int row = item / (BK / 4), kc = 4 * (item % (BK / 4));
+            *(bf16x4*)(hi + row * GEMM_LD(BK) + kc) = h;
+            *(bf16x4*)(lo + row * GEMM_LD(BK) + kc) = l;
         }
     } else {
 #pragma unroll
-        for (int it = 0; it < ROWS / 64; ++it) {
+        for (int it = 0; it < ROWS * BK / 2048; ++it) {
             const int item = tid + 256 * it;
             const int kp = item / (ROWS / 4), row = 4 * (item % (ROWS / 4));
             bf16x4 h0, l0, h1, l1;
@@ -144,32 +143,33 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS>& r, bf16* __rest
 }
 
 // one MFMA operand fragment (8 k-slots of row `row`) out of an LDS image
-template <int ROWS, bool TR>
-__device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int row, int g) {
-    if (!TR) return *(const bf16x8*)(img + row * GEMM_LD + 8 * g);
+template <int ROWS, bool TR, int BK>
+__device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int row, int g, int kk /* 0 or 32 */) {
+    if (!TR) return *(const bf16x8*)(img + row * GEMM_LD(BK) + kk + 8 * g);
     u32x4 d;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) d[jj] = ((const uint32_t*)img)[(4 * g + jj) * GEMM_TS(ROWS) + row];
+    for (int jj = 0; jj < 4; ++jj) d[jj] = ((const uint32_t*)img)[(kk / 2 + 4 * g + jj) * GEMM_TS(ROWS) + row];
     bf16x8 f;
     __builtin_memcpy(&f, &d, 16);
     return f;
 }
 
-#define GEMM_LDS(BM, BN) (((2 * (BM) + 2 * (BN)) * GEMM_LD * 2) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * (BN)) * GEMM_LD * 2) : (4 * 32 * GEMM_TLD * 4))
+#define GEMM_LDS(BM, BN, BK) (((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 2) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 2) : (4 * 32 * GEMM_TLD * 4))
 
-// grid (ceil(N/BN), ceil(M/BM), ksplit); BM, BN in {64, 128}; wave tile (BM/2) x (BN/2).  K range of split z: [z*klen, min(K, (z+1)*klen)), klen multiple of 32.
+// grid (ceil(N/BN), ceil(M/BM), ksplit); BM, BN in {64, 128}; BK in {32, 64}; wave tile (BM/2) x (BN/2).
+// K range of split z: [z*klen, min(K, (z+1)*klen)), klen a multiple of BK.
 // EPI: 0 plain (+bias) | 1 GELU: C = raw product (saved for backward), aux = gelu(raw + bias) | 2 residual: C = aux + raw + bias
 //      3 q|k|v: nothing in C; aux (h16 [M,N]) = f16(raw + bias), the q third (cols < 256) also times 32^-0.5 -- exactly the
 //        values the attention kernels used to form from the fp32 product, stored once at half the bytes
-template <int BM, int BN, bool A_T, bool B_T, int EPI, int PF>
+template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                                      const float* __restrict__ bias, float* __restrict__ aux) {
     CFFM_DYN_SMEM(smem);
     bf16* Ah = (bf16*)smem;
-    bf16* Al = Ah + BM * GEMM_LD;
-    bf16* Bh = Al + BM * GEMM_LD;
-    bf16* Bl = Bh + BN * GEMM_LD;
+    bf16* Al = Ah + BM * GEMM_LD(BK);
+    bf16* Bh = Al + BM * GEMM_LD(BK);
+    bf16* Bl = Bh + BN * GEMM_LD(BK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int kbeg = blockIdx.z * klen, kend = (kbeg + klen < K) ? kbeg + klen : K;
@@ -184,40 +184,43 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
     // PF K-tiles are always in flight in registers: a K-step (~0.1-0.4 us of MFMA) is far shorter than the ~1-2 us a
     // tile takes to arrive from HBM / Infinity Cache, and co-resident workgroups run in lockstep, so they cannot hide
     // each other's waits; tile t+PF is requested before tile t is multiplied.
-    TileRegs<BM> ra[PF];
-    TileRegs<BN> rb[PF];
+    TileRegs<BM, BK> ra[PF];
+    TileRegs<BN, BK> rb[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {   // past kend -> zeros, never used
-        tile_load<BM, A_T>(ra[u], A, lda, m0, M, kbeg + u * GEMM_BK, kend, tid);
-        tile_load<BN, B_T>(rb[u], B, ldb, n0, N, kbeg + u * GEMM_BK, kend, tid);
+        tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + u * BK, kend, tid);
+        tile_load<BN, B_T, BK>(rb[u], B, ldb, n0, N, kbeg + u * BK, kend, tid);
     }
-    for (int k0 = kbeg; k0 < kend; k0 += PF * GEMM_BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += PF * BK) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int kk = k0 + u * GEMM_BK;
+            const int kk = k0 + u * BK;
             if (kk < kend) {   // uniform across the workgroup
-                tile_store<BM, A_T>(ra[u], Ah, Al, tid);
-                tile_store<BN, B_T>(rb[u], Bh, Bl, tid);
+                tile_store<BM, A_T, BK>(ra[u], Ah, Al, tid);
+                tile_store<BN, B_T, BK>(rb[u], Bh, Bl, tid);
                 __syncthreads();
-                if (kk + PF * GEMM_BK < kend) {
-                    tile_load<BM, A_T>(ra[u], A, lda, m0, M, kk + PF * GEMM_BK, kend, tid);
-                    tile_load<BN, B_T>(rb[u], B, ldb, n0, N, kk + PF * GEMM_BK, kend, tid);
-                }
-                bf16x8 bh[NT], bl[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bh[j] = frag_read<BN, B_T>(Bh, wc + 16 * j + l15, g);
-                    bl[j] = frag_read<BN, B_T>(Bl, wc + 16 * j + l15, g);
+                if (kk + PF * BK < kend) {
+                    tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kk + PF * BK, kend, tid);
+                    tile_load<BN, B_T, BK>(rb[u], B, ldb, n0, N, kk + PF * BK, kend, tid);
                 }
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const bf16x8 ah = frag_read<BM, A_T>(Ah, wr + 16 * i + l15, g);
-                    const bf16x8 al = frag_read<BM, A_T>(Al, wr + 16 * i + l15, g);
+                for (int ks = 0; ks < BK; ks += 32) {
+                    bf16x8 bh[NT], bl[NT];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
-                        acc[i][j] = mfma16x16x32_bf16(al, bh[j], acc[i][j]);
-                        acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
+                        bh[j] = frag_read<BN, B_T, BK>(Bh, wc + 16 * j + l15, g, ks);
+                        bl[j] = frag_read<BN, B_T, BK>(Bl, wc + 16 * j + l15, g, ks);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const bf16x8 ah = frag_read<BM, A_T, BK>(Ah, wr + 16 * i + l15, g, ks);
+                        const bf16x8 al = frag_read<BM, A_T, BK>(Al, wr + 16 * i + l15, g, ks);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
+                            acc[i][j] = mfma16x16x32_bf16(al, bh[j], acc[i][j]);
+                            acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
+                        }
                     }
                 }
                 __syncthreads();
