@@ -97,6 +97,66 @@ def test_nonsquare_vspw_test_shape_forward():
     assert H.rel_err(y[:, -1].cpu(), yo[:, -1]) < FWD_TOL
 
 
+def test_config4_512x512_batch2():
+    """BASELINE config 4 ("CFFM-B2 512x512, batch 2/GPU"): the B2 head has the same C=256 / depth 2 as B1 (SURVEY.md
+    fact 5); what grows is the grid (64x64 -> padded 70x70, nW=100) and the batch."""
+    depth, b, h, w = 2, 2, 64, 64
+    st = R.layer_state(depth, seed=15)
+    x = R.synth_input('x', (b, 4, 256, h, w), seed=16)
+    gy = R.synth_input('g', (b, 256, h, w), seed=17, scale=1.0)
+    m = build_layer(depth, st)
+    xg = x.to(dev()).requires_grad_(True)
+    y = m(xg)
+    (y[:, -1] * gy.to(dev())).sum().backward()
+    xo = x.clone().requires_grad_(True)
+    yo = O.layer_forward(xo, st, depth)
+    (yo[:, -1] * gy).sum().backward()
+    assert H.rel_err(y[:, -1], yo[:, -1]) < FWD_TOL
+    assert H.rel_err(xg.grad, xo.grad) < BWD_TOL
+
+
+def test_config5_gtc_8_prototypes_full_size():
+    """BASELINE config 5: CFFM++-B1 480x480, 8 global-context prototype tokens -> decoder_swin on 60x60 tokens."""
+    import vss_cffm_amd as V
+    b, h, w, k = 2, 60, 60, 8
+    st = R.gtc_layer_state(1, seed=18)
+    m = V.BasicLayer_cluster(dim=256, depth=1, num_heads=8, window_size=7)
+    m.load_state_dict(st, strict=False)
+    m.to(dev())
+    x = R.synth_input('gx', (b, h * w, 256), seed=19)
+    c = R.synth_input('gc', (b, k, 256), seed=20)
+    xg, cg = x.to(dev()).requires_grad_(True), c.to(dev()).requires_grad_(True)
+    y = m(xg, h, w, cg)[0]
+    y.square().sum().backward()
+    xo, co = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    yo = O.gtc_layer_forward(xo, h, w, co, st, 1)
+    yo.square().sum().backward()
+    assert H.rel_err(y, yo) < 5e-5
+    assert H.rel_err(xg.grad, xo.grad) < 1e-4 and H.rel_err(cg.grad, co.grad) < 1e-4
+
+
+def test_backward_is_deterministic_except_bias_atomics():
+    """dK/dV (gather), dX, weight gradients are bit-reproducible run to run; only the position-bias gradient is
+    accumulated with fp32 atomics across workgroups (a few ulps of run-to-run noise)."""
+    st = R.layer_state(1, seed=21)
+    x = R.synth_input('x', (2, 4, 256, 21, 14), seed=22)
+    gy = R.synth_input('g', (2, 256, 21, 14), seed=23, scale=1.0)
+    m = build_layer(1, st)
+    outs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        xg = x.to(dev()).requires_grad_(True)
+        (m(xg)[:, -1] * gy.to(dev())).sum().backward()
+        outs.append((xg.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        if 'relative_position_bias' in k:
+            assert H.rel_err(outs[0][1][k], outs[1][1][k]) < 1e-5, k
+        else:
+            assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
 def test_tiny_and_degenerate_grids():
     for (h, w) in [(1, 1), (7, 7), (6, 15)]:
         st = R.layer_state(1, seed=10)
