@@ -12,7 +12,7 @@ __global__ void k_sum_splits(const float* __restrict__ part, int nsplit, long n,
 
 template <bool A_T, bool B_T, int EPI = 0>
 static int gemm_split_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int ksplit,
-                             hipStream_t st, const float* bias = nullptr, float* aux = nullptr) {
+                             hipStream_t st, const float* bias = nullptr, float* aux = nullptr, int prefer_big = 0) {
     int klen = ((K + ksplit - 1) / ksplit + 63) / 64 * 64;
     ksplit = (K + klen - 1) / klen;
     float* out = C;
@@ -33,7 +33,7 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
     if (bk64) {
         if (b128 >= 384) GEMM_GO(128, 128, 64, 1);
         else GEMM_GO(64, 64, 64, 2);
-    } else if (b128 >= 384) GEMM_GO(128, 128, 32, 1);
+    } else if (b128 >= 384 || prefer_big) GEMM_GO(128, 128, 32, 1);
     else GEMM_GO(64, 64, 32, 3);
 #undef GEMM_GO
     if (ksplit > 1) {
@@ -65,12 +65,15 @@ static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int
 }
 // dw[N,K] = dy[M,N]^T x[M,K]: output N x K, contraction = M (long) split over workgroups
 static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int ksplit = (384 + tiles - 1) / tiles;
+    // 128x128 tiles halve the operand re-reads through the CU load path (the bound of these kernels: see gemm_kernels.h);
+    // enough contraction splits to give every CU a workgroup
+    const int big = (N >= 128 && K >= 128);
+    const int tiles = big ? ((N + 127) / 128) * ((K + 127) / 128) : ((N + 63) / 64) * ((K + 63) / 64);
+    int ksplit = (320 + tiles - 1) / tiles;
     const int maxsplit = (int)((M + 127) / 128);   // at least 128 rows of the contraction per split
     if (ksplit > maxsplit) ksplit = maxsplit;
     if (ksplit < 1) ksplit = 1;
-    return gemm_split_launch<true, true>(dy, x, dw, N, K, (int)M, N, K, K, ksplit, st);
+    return gemm_split_launch<true, true>(dy, x, dw, N, K, (int)M, N, K, K, ksplit, st, nullptr, nullptr, big);
 }
 
 #ifdef CFFM_EMU

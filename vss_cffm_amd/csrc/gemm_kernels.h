@@ -13,7 +13,12 @@
 //   forward        y  = x  w^T : A = x  (i=row, k contiguous),  B = w  [N,K]  (k contiguous)        <F,F>
 //   input gradient dx = dy w   : A = dy (k = n contiguous),     B(j=k',k=n) = w[n*K+k'] -> B_T       <F,T>
 //   weight gradient dw = dy^T x: A(i=n,k=m) = dy[m*N+n] -> A_T, B(j=k',k=m) = x[m*K+k'] -> B_T       <T,T>
-// Tiles: BM x BN x 32 (BM, BN in {64,128}, chosen so that >= 2-3 workgroups share a CU and hide each other's staging)
+// What bounds it (measured, scripts/gemm_bench.py): with fp32 operands a BM x BN tile moves (BM+BN)*4 bytes per
+// 2*BM*BN flops through the CU's vector-load path, i.e. BM*BN/(2(BM+BN)) flop/B: 16 for 64x64, 32 for 128x128; at the
+// ~6.8 TB/s the 256 CUs pull from L2 / Infinity Cache that is ~110 / ~220 TF -- what the kernels reach (100 / 170 TF;
+// rocBLAS SGEMM: 60-100 TF).  K-tile depth (BK 32 vs 64) and prefetch depth are neutral; the small-N layers do not
+// have enough output to give 256 CUs 128x128 tiles, hence their lower rate.
+// Tiles: BM x BN x 32 (BM, BN in {64,128})
 // per 256-thread workgroup (2x2 waves, each (BM/2) x (BN/2) as 16x16x32 MFMA tiles), LDS rows
 // padded to 80 B (conflict-free ds_read_b128 fragments), the next PF K-tiles in flight in registers while the
 // current one is multiplied.  The weight-gradient form splits its long contraction (M ~ 10^4) over
