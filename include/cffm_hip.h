@@ -59,7 +59,7 @@ typedef struct cffm_block_grads {
 
 /* float offsets of the activations one block saves for its backward (inside its slice of `saved`) */
 typedef struct cffm_block_ws {
-    long mean1, rstd1, M, zall, qkv, bpack, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, total;
+    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, total;
 } cffm_block_ws;
 
 int cffm_abi_version(void);
@@ -88,22 +88,18 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
                      const float* dzall, const float* dres /* [B*HW,256] added to the target-frame grad, may be NULL */,
                      float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs,
                      float* dgamma, float* dbeta, float* dM, float* const dpool_b[4], void* stream);
-/* bias / biasT: dense [8,64,304] / [8,304,64] tables (either may be NULL; for inspection and tests);
- * bpack: the compact pack the attention kernels read (CFFM_BIAS_PACK_FLOATS floats, may be NULL):
- *   ring keys dense in both orientations [8,64,192] + [8,192,64], own-window / pooled slots as small tables [8,672] */
-#define CFFM_BIAS_PACK_FLOATS (2 * 8 * 64 * 192 + 8 * 672)
-int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias, float* biasT,
-                       float* bpack, void* stream);
+int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias /*[8,64,304]*/,
+                       float* biasT /*[8,304,64] or NULL*/, void* stream);
 int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* const dpool[4], void* stream);
 /* qkv16 [B*RC,768] f16 = zall w^T + b with the q third times 32^-0.5 (cffm_linear_qkv_fwd) */
 int cffm_linear_qkv_fwd(const float* zall, const float* w /*[768,256]*/, const float* b /*[768]*/, void* qkv16, long M,
                         void* stream);
 int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src /*[nW,304]*/, const int* q_dst /*[nW,49]*/,
-                  const float* bpack, float* ao /*[B*HW,256]*/, float* lse /*[B*nW*8,64]*/, void* stream);
+                  const float* bias, float* ao /*[B*HW,256]*/, float* lse /*[B*nW*8,64]*/, void* stream);
 /* inv_ptr [RC+1] / inv_idx: CSR inverse of key_src (token row -> the window*304+slot pairs reading it);
  * dkv_part: scratch [B*nW*304*512] floats for the per-window dK/dV rows the gather pass sums */
 int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst,
-                  const int* inv_ptr, const int* inv_idx, const float* bpack, const float* ao,
+                  const int* inv_ptr, const int* inv_idx, const float* bias, const float* biasT, const float* ao,
                   const float* dao, const float* lse, float* dqkv /*[B*RC,768] fp32: d(zall w^T), overwritten*/,
                   float* dbiasT /*[8,304,64], overwritten*/, float* dkv_part, void* stream);
 /* y[M,N] = x[M,K] w[N,K]^T ;  dx[M,K] = dy[M,N] w[N,K] ;  dw[N,K] = dy[M,N]^T x[M,K]   (row-major, no bias) */

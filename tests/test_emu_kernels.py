@@ -81,13 +81,13 @@ def run_stage_checks(lib, device):
         off += n
     assert off == rc
     # --- bias
-    bias, biasT, bpack = f(8, 64, 304), f(8, 304, 64), f(2 * 8 * 64 * 192 + 8 * 672)
+    bias, biasT = f(8, 64, 304), f(8, 304, 64)
     rp = (C.c_void_p * 4)(*[p[k].data_ptr() for k in ('attn.relative_position_bias_table_to_windows.0',
                                                         'attn.relative_position_bias_table_to_windows_clips.0',
                                                         'attn.relative_position_bias_table_to_windows_clips.1',
                                                         'attn.relative_position_bias_table_to_windows_clips.2')])
     assert lib.cffm_bias_assemble(P(p['attn.relative_position_bias_table']),
-                                  P(p['attn.relative_position_bias_table_to_neighbors']), rp, P(bias), P(biasT), P(bpack), stream) == 0
+                                  P(p['attn.relative_position_bias_table_to_neighbors']), rp, P(bias), P(biasT), stream) == 0
     assert torch.equal(bias[:, :49, :289].cpu(), it['bias'])
     assert torch.equal(biasT.transpose(1, 2), bias)
     assert float(bias[:, 49:].abs().max()) == 0 and float(bias[:, :, 289:].abs().max()) == 0
@@ -100,11 +100,7 @@ def run_stage_checks(lib, device):
     ks, qd = geometry.tables(h0, w0)
     ks, qd = torch.from_numpy(np.array(ks)).to(device), torch.from_numpy(np.array(qd)).to(device)
     ao, lse = f(b * hw, 256), f(b * nw * 8, 64)
-    # the compact pack must reproduce the dense table: ring columns directly, the rest through the per-key lookup
-    ringq = bpack[:8 * 64 * 192].view(8, 64, 192).cpu()
-    assert torch.equal(ringq[:, :49, 49:181], it['bias'][:, :, 49:181]) and float(ringq[:, :, :49].abs().max()) == 0
-    assert torch.equal(bpack[8 * 64 * 192:2 * 8 * 64 * 192].view(8, 192, 64).transpose(1, 2).cpu(), ringq)
-    assert lib.cffm_attn_fwd(C.byref(g), P(qkv), P(ks), P(qd), P(bpack), P(ao), P(lse), stream) == 0
+    assert lib.cffm_attn_fwd(C.byref(g), P(qkv), P(ks), P(qd), P(bias), P(ao), P(lse), stream) == 0
     ao_ref = torch.zeros(b, hp * wp, 256)
     ao_ref[:, win.view(-1)] = it['ao'].reshape(b, nw * 49, 256)
     ao_ref = ao_ref.view(b, hp, wp, 256)[:, :h0, :w0].reshape(b * hw, 256)

@@ -128,7 +128,8 @@ int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* o) {
     o->M = p; p += up(CFFM_NCELL * CFFM_WA);
     o->zall = p; p += up(B * RC * CFFM_C);
     o->qkv = p; p += up(B * RC * 768 / 2);   // f16 q|k|v
-    o->bpack = p; p += up(BP_TOTAL);   // compact position-bias pack (ring dense x2 orientations + small tables)
+    o->bias = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
+    o->biasT = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     o->lse = p; p += up(B * nW * CFFM_HEADS * CFFM_NQ_PAD);
     o->ao = p; p += up(B * HW * CFFM_C);
     o->x1 = p; p += up(B * HW * CFFM_C);
@@ -268,17 +269,13 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
     return 0;
 }
 
-int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias, float* biasT, float* bpack,
-                       void* stream) {
+int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias, float* biasT, void* stream) {
     PROF(ST_BIAS_ASM);
     BiasTables t;
     t.own = own; t.ring = ring;
     for (int i = 0; i < 4; ++i) t.pool[i] = pool[i];
-    if (bias) {   // dense [8,64,304] (+ transposed) tables: kept for tests / inspection, the kernels read the pack
-        const int n = CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD;
-        CFFM_LAUNCH(k_bias_assemble, ((n + 255) / 256), (256), 0, (hipStream_t)stream, t, bias, biasT);
-    }
-    if (bpack) CFFM_LAUNCH(k_bias_pack, ((BP_TOTAL + 255) / 256), (256), 0, (hipStream_t)stream, t, bpack);
+    const int n = CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD;
+    CFFM_LAUNCH(k_bias_assemble, ((n + 255) / 256), (256), 0, (hipStream_t)stream, t, bias, biasT);
     CHECK_LAUNCH("bias_assemble");
     return 0;
 }
@@ -293,12 +290,12 @@ int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* con
     return 0;
 }
 
-int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst, const float* bpack, float* ao,
+int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst, const float* bias, float* ao,
                   float* lse, void* stream) {
     PROF(ST_ATTN_FWD);
-    REQUIRE(g && qkv16 && key_src && q_dst && bpack && ao && lse, "attn_fwd: null");
+    REQUIRE(g && qkv16 && key_src && q_dst && bias && ao && lse, "attn_fwd: null");
     CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
-                key_src, q_dst, bpack, ao, lse);
+                key_src, q_dst, bias, ao, lse);
     CHECK_LAUNCH("attn_fwd");
     return 0;
 }
@@ -312,18 +309,18 @@ static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
 }
 
 int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst,
-                  const int* inv_ptr, const int* inv_idx, const float* bpack, const float* ao,
+                  const int* inv_ptr, const int* inv_idx, const float* bias, const float* biasT, const float* ao,
                   const float* dao, const float* lse, float* dqkv, float* dbiasT, float* dkv_part, void* stream) {
     PROF(ST_ATTN_BWD);
     hipStream_t st = (hipStream_t)stream;
-    REQUIRE(g && qkv16 && bpack && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
+    REQUIRE(g && qkv16 && biasT && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
     hipMemsetAsync(dbiasT, 0, (size_t)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD * sizeof(float), st);
     int per;
     const int ng = attn_bwd_groups(g, &per);
-    CFFM_LAUNCH(k_cfm_attn_bwd_q, (CFFM_HEADS, ng), (256), ATT_BWQ_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst, bpack, ao, dao,
+    CFFM_LAUNCH(k_cfm_attn_bwd_q, (CFFM_HEADS, ng), (256), ATT_BWQ_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias, ao, dao,
                 lse, dqkv, dbiasT, per);
     CFFM_LAUNCH(k_cfm_attn_bwd_kv, (g->B * g->nW * CFFM_HEADS), (256), ATT_BWK_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst,
-                bpack, ao, dao, lse, dkv_part);
+                biasT, ao, dao, lse, dkv_part);
     CFFM_LAUNCH(k_dkv_gather, ((g->RC + 3) / 4, g->B), (256), 0, st, to_geo(g), inv_ptr, inv_idx, (const float*)dkv_part, dqkv);
     CHECK_LAUNCH("attn_bwd");
     return 0;
@@ -512,8 +509,8 @@ int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const flo
     TRY(cffm_ln_pool_fwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
                          ws + L.mean1, ws + L.rstd1, stream));
     TRY(cffm_linear_qkv_fwd(ws + L.zall, p->qkv_w, p->qkv_b, ws + L.qkv, NR, stream));
-    TRY(cffm_bias_assemble(p->rpb_own, p->rpb_ring, p->rpb_pool, nullptr, nullptr, ws + L.bpack, stream));
-    TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, ws + L.bpack, ws + L.ao, ws + L.lse, stream));
+    TRY(cffm_bias_assemble(p->rpb_own, p->rpb_ring, p->rpb_pool, ws + L.bias, ws + L.biasT, stream));
+    TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, ws + L.bias, ws + L.ao, ws + L.lse, stream));
     TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_residual_ln(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
                          ws + L.mean2, ws + L.rstd2, NP, stream));
@@ -553,7 +550,7 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     TRY(cffm_linear_bwd_weight(dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dx1, p->proj_w, dao, NP, CFFM_C, CFFM_C, stream));
     // attention
-    TRY(cffm_attn_bwd(g, ws + L.qkv, key_src, q_dst, inv_ptr, inv_idx, ws + L.bpack, ws + L.ao, dao,
+    TRY(cffm_attn_bwd(g, ws + L.qkv, key_src, q_dst, inv_ptr, inv_idx, ws + L.bias, ws + L.biasT, ws + L.ao, dao,
                       ws + L.lse, dqkv, dbiasT, scratch + S.dkvp, stream));
     TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, stream));
     // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)

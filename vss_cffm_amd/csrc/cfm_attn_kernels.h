@@ -24,28 +24,25 @@
 //    (conflict-free ds_read_b64).
 #pragma once
 #include "cffa_kernels.h"
-#include "rowops_kernels.h"
 
 #define ATT_KS_STRIDE 40   // halfs per K/V/Q row in LDS (32 + 8 pad = 80 B)
 #define ATT_VT_STRIDE 328  // halfs per row of a [32][keys] transposed image (164 dwords = 4*41)
 #define ATT_QT_STRIDE 72   // halfs per row of a [32][64 queries] transposed image (36 dwords = 4*9)
 
-#define ATT_BIAS_LDS (BP_TAB_LD * 4 + CFFM_NKEY_PAD * 8)   // the head's small bias tables + the per-key (base, side) lookup
-#define ATT_FWD_LDS ((CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4 + ATT_BIAS_LDS)
+#define ATT_FWD_LDS ((CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 64 * ATT_KS_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4)
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads = 4 waves x 16 queries.
 __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __restrict__ qkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
-                                                       const float* __restrict__ bpack, float* __restrict__ ao,
+                                                       const float* __restrict__ bias, float* __restrict__ ao,
                                                        float* __restrict__ lse_out) {
     CFFM_DYN_SMEM(smem);
     f16* Ks = (f16*)smem;
     f16* Vt = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    float* vflag = (float*)(Vt + 32 * ATT_VT_STRIDE);
-    float* tabs = vflag + CFFM_NKEY_PAD;          // [672] small bias tables of this head
-    int* kbs = (int*)(tabs + BP_TAB_LD);          // [304][2] (base, side) per key slot
+    f16* Qs = Vt + 32 * ATT_VT_STRIDE;
+    float* vflag = (float*)(Qs + 64 * ATT_KS_STRIDE);
 
     const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,10 +73,9 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
         if (src0[it] >= 0) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
         if (src1[it] >= 0) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
     }
-    f16x8 qfrag = z8;                             // this lane's MFMA B fragment: 8 channels of its query, straight from global
-    if (qcol < CFFM_WA) qfrag = ld_h8(base + (long)(w * CFFM_WA + qcol) * 768 + 8 * g);
-    for (int e = tid; e < BP_TAB_LD; e += 256) tabs[e] = bpack[BP_TAB_OFF + h * BP_TAB_LD + e];
-    for (int n = tid; n < CFFM_NKEY_PAD; n += 256) key_bias_lut(n, kbs[2 * n], kbs[2 * n + 1]);
+    const int qi = tid >> 2, qc = tid & 3;
+    f16x8 qv = z8;
+    if (qi < CFFM_WA) qv = ld_h8(base + (long)(w * CFFM_WA + qi) * 768 + 8 * qc);
     for (int n = tid; n < CFFM_NKEY_PAD; n += 256) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
     for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 256)
         Vt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
@@ -97,31 +93,21 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
             }
         }
     }
-    // position bias: the 9 key tiles that contain ring keys (n = 48..191) come from the dense ring array (they fly across
-    // the barrier), everything else is gathered from the head's small tables in LDS through the per-key lookup
-    const float* rrow = bpack + ((long)h * CFFM_NQ_PAD + qcol) * BP_RING_LD + 4 * g;
-    f32x4 ringb[9];
+    *(f16x8*)(Qs + qi * ATT_KS_STRIDE + 8 * qc) = qv;
+    // the wave's 19 bias tiles (L2-resident table) fly across the barrier and land in the MFMA C operands
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
+    f32x4 s[19];
 #pragma unroll
-    for (int t = 3; t < 12; ++t) ringb[t - 3] = ld4(rrow + 16 * t);
+    for (int t = 0; t < 19; ++t) s[t] = ld4(brow + 16 * t);
     __syncthreads();
 
     // ---- S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column -----------------
-    const int qq = qcol < CFFM_WA ? qcol : CFFM_WA - 1, qi = qq / 7, qj = qq % 7;
-    f32x4 s[19];
+    const f16x8 qfrag = *(const f16x8*)(Qs + qcol * ATT_KS_STRIDE + 8 * g);
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 19; ++t) {
-        f32x4 cin = *(const f32x4*)(vflag + 16 * t + 4 * g);
-        if (t >= 3 && t < 12) cin += ringb[t >= 3 && t < 12 ? t - 3 : 0];
-        if (t <= 3 || t >= 11) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = 16 * t + 4 * g + r;
-                cin[r] += tabs[kbs[2 * n] + qi * kbs[2 * n + 1] + qj];
-            }
-        }
         const f16x8 kf = *(const f16x8*)(Ks + (16 * t + (lane & 15)) * ATT_KS_STRIDE + 8 * g);
-        const f32x4 acc = mfma16x16x32_f16(kf, qfrag, cin);   // C-in = bias + mask
+        const f32x4 acc = mfma16x16x32_f16(kf, qfrag, s[t] + *(const f32x4*)(vflag + 16 * t + 4 * g));   // C-in = bias + mask
         s[t] = acc;
         m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
     }
@@ -183,9 +169,9 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 #ifndef BWQ_OCC
 #define BWQ_OCC 1  // workgroups per CU of the query-owner backward kernel: 1 = 512-register budget, no spills (measured faster than 2)
 #endif
-#define ATT_BWQ_LDS ((2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4 + ATT_BIAS_LDS)
+#define ATT_BWQ_LDS ((2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4)
 #define ATT_BWK_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
-                     CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4 + ATT_BIAS_LDS)
+                     CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
 
 // stage the window's K, V rows (and optionally K^T) from the f16 q|k|v rows: two batches of global loads
 template <int NTHREADS, bool WITH_KT>
@@ -235,7 +221,7 @@ __device__ __forceinline__ void stage_kv(const h16* __restrict__ base, const int
 }
 
 __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
-                                                            const int* __restrict__ q_dst, const float* __restrict__ bpack,
+                                                            const int* __restrict__ q_dst, const float* __restrict__ bias,
                                                             const float* __restrict__ ao, const float* __restrict__ dao,
                                                             const float* __restrict__ lse_in, float* __restrict__ dqkv,
                                                             float* __restrict__ dbiasT, int per_group) {
@@ -244,8 +230,6 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
     f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
     f16* Kt = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;
     float* vflag = (float*)(Kt + 32 * ATT_VT_STRIDE);
-    float* tabs = vflag + CFFM_NKEY_PAD;
-    int* kbs = (int*)(tabs + BP_TAB_LD);
 
     const int h = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -254,11 +238,7 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
     const float scale = 0.17677669529663687f;
     const int wb0 = grp * per_group;
     const int wb1 = (wb0 + per_group < G.B * G.nW) ? wb0 + per_group : G.B * G.nW;
-    const float* rrow = bpack + ((long)h * CFFM_NQ_PAD + qcol) * BP_RING_LD + 4 * g;
-    const int qq = qcol < CFFM_WA ? qcol : CFFM_WA - 1, qi = qq / 7, qj = qq % 7;
-    for (int e = tid; e < BP_TAB_LD; e += 256) tabs[e] = bpack[BP_TAB_OFF + h * BP_TAB_LD + e];
-    for (int n = tid; n < CFFM_NKEY_PAD; n += 256) key_bias_lut(n, kbs[2 * n], kbs[2 * n + 1]);
-    // (visible to all waves after the first window's staging barrier)
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
 
     f32x4 dB[19];
 #pragma unroll
@@ -302,28 +282,22 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
         __syncthreads();
 
         f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-        f32x4 ringb[9];   // dense ring part of the position bias (key tiles 3..11), requested before the MFMA loop
-#pragma unroll
-        for (int t = 3; t < 12; ++t) ringb[t - 3] = ld4(rrow + 16 * t);
+        f32x4 bcur[2] = {ld4(brow), ld4(brow + 16)};   // bias tiles are fetched one key-tile pair ahead
 #pragma unroll
         for (int kt = 0; kt < 10; ++kt) {
             f16x4 dsh[2];
+            f32x4 bnxt[2] = {bcur[0], bcur[1]};
+            if (kt < 9) {
+                bnxt[0] = ld4(brow + 16 * (2 * kt + 2));
+                if (2 * kt + 3 < 19) bnxt[1] = ld4(brow + 16 * (2 * kt + 3));
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kt + u;
                 if (t < 19) {
                     const f16x8 kf = *(const f16x8*)(Ks + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
                     const f16x8 vf = *(const f16x8*)(Vs + (16 * t + l15) * ATT_KS_STRIDE + 8 * g);
-                    f32x4 cin = *(const f32x4*)(vflag + 16 * t + 4 * g);
-                    if (t >= 3 && t < 12) cin += ringb[t >= 3 && t < 12 ? t - 3 : 0];
-                    if (t <= 3 || t >= 11) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = 16 * t + 4 * g + r;
-                            cin[r] += tabs[kbs[2 * n] + qi * kbs[2 * n + 1] + qj];
-                        }
-                    }
-                    const f32x4 sv = mfma16x16x32_f16(kf, qfrag, cin);
+                    f32x4 sv = mfma16x16x32_f16(kf, qfrag, bcur[u] + *(const f32x4*)(vflag + 16 * t + 4 * g));
                     const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});
                     f32x4 ds;
                     for (int r = 0; r < 4; ++r) ds[r] = fast_exp(sv[r] - lq) * (dp[r] - Dq);
@@ -340,6 +314,8 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
                 const f16x8 ka = cat_f16x4(*(const f16x4*)kr, *(const f16x4*)(kr + 16));
                 dq[mt] = mfma16x16x32_f16(ka, dsf, dq[mt]);
             }
+            bcur[0] = bnxt[0];
+            bcur[1] = bnxt[1];
         }
         if (qcol < CFFM_WA) {
             float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
@@ -360,7 +336,7 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads
 __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
-                                                             const int* __restrict__ q_dst, const float* __restrict__ bpack,
+                                                             const int* __restrict__ q_dst, const float* __restrict__ biasT,
                                                              const float* __restrict__ ao, const float* __restrict__ dao,
                                                              const float* __restrict__ lse_in, float* __restrict__ dkv_part) {
     CFFM_DYN_SMEM(smem);
@@ -374,16 +350,12 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
     float* slse = vflag + CFFM_NKEY_PAD;
     float* sD = slse + 64;
     float* smax = sD + 64;
-    float* tabs = smax + 16;
-    int* kbs = (int*)(tabs + BP_TAB_LD);
 
     const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     const int* ksrc = key_src + w * CFFM_NKEY_PAD;
     const h16* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;
-    for (int e = tid; e < BP_TAB_LD; e += 256) tabs[e] = bpack[BP_TAB_OFF + h * BP_TAB_LD + e];
-    for (int n = tid; n < CFFM_NKEY_PAD; n += 256) key_bias_lut(n, kbs[2 * n], kbs[2 * n + 1]);
 
     // Q: threads 0..127 own (query pair, 16-byte chunk); dO / O: every thread owns (query pair, 4-channel chunk)
     const int pr = tid >> 3, c = tid & 7, i0 = 2 * pr, i1 = i0 + 1;
@@ -435,36 +407,18 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
     }
     __syncthreads();
 
-    // position bias in the S orientation: this lane's key (one per tile) against 16 queries (4 per query tile).
-    // (qi*side + qj) of those queries is lane-constant: 16 small integers kept in registers.
-    const float* ringT = bpack + BP_RINGT_OFF + (long)h * BP_RING_LD * CFFM_NQ_PAD;
-    int qiv[4][4], qjv[4][4];
+    f32x4 bt[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = 16 * mt + 4 * g + r, qq = q < CFFM_WA ? q : CFFM_WA - 1;
-            qiv[mt][r] = qq / 7;
-            qjv[mt][r] = qq % 7;
-        }
-    const f32x4 z4b = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 bt[4];   // ring part of the next tile, requested one tile ahead
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) bt[mt] = (wave >= 3) ? ld4(ringT + (long)(16 * wave + l15) * CFFM_NQ_PAD + 4 * g + 16 * mt) : z4b;
+    for (int mt = 0; mt < 4; ++mt) bt[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + 16 * wave + l15) * CFFM_NQ_PAD + 4 * g + 16 * mt);
     for (int t = wave; t < 19; t += 4) {
         const int key = 16 * t + l15;
         f32x4 bn[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) bn[mt] = z4b;
-        if (t + 4 >= 3 && t + 4 < 12) {   // tiles 3..11 hold the ring keys (n = 48..191)
+        for (int mt = 0; mt < 4; ++mt) bn[mt] = bt[mt];
+        if (t + 4 < 19) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) bn[mt] = ld4(ringT + (long)(key + 64) * CFFM_NQ_PAD + 4 * g + 16 * mt);
+            for (int mt = 0; mt < 4; ++mt) bn[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + key + 64) * CFFM_NQ_PAD + 4 * g + 16 * mt);
         }
-        const int kb0 = kbs[2 * key], kb1 = kbs[2 * key + 1];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bt[mt][r] += tabs[kb0 + qiv[mt][r] * kb1 + qjv[mt][r]];
         const f16x8 kfrag = *(const f16x8*)(Ks + key * ATT_KS_STRIDE + 8 * g);
         const f16x8 vfrag = *(const f16x8*)(Vs + key * ATT_KS_STRIDE + 8 * g);
         const float vf = vflag[key];

@@ -59,52 +59,6 @@ __global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __re
     if (biasT) biasT[((long)h * CFFM_NKEY_PAD + n) * CFFM_NQ_PAD + q] = v;
 }
 
-// ---- compact position-bias pack read by the attention kernels --------------------------------------------------
-// Of the 289 key slots only the 132 ring keys have a dense, unstructured bias [49 x 132]; the own-window and pooled
-// slots index small per-head tables through (query - key) offsets.  The dense [64 x 304] fp32 tile (78 KB per
-// (window, head)) was 2/3 of every attention workgroup's L2->LDS traffic, so the kernels read instead:
-//   ringq [8][64][192]  bias of ring keys at column n (zeros elsewhere, n < 192), query-major  (S^T orientation)
-//   ringT [8][192][64]  the same, key-major                                                     (S orientation)
-//   tab   [8][672]      [7 x 0.0 | own 169 | P0 121 | f0 169 | f1 121 | f2 81]: bias(q, n) = tab[base(n) + qi*side(n) + qj]
-//                       (ring / pad keys have base = side = 0 and land on the zeros for every qj in 0..6)
-#define BP_RING_LD 192
-#define BP_TAB_LD 672
-#define BP_RINGT_OFF (CFFM_HEADS * CFFM_NQ_PAD * BP_RING_LD)
-#define BP_TAB_OFF (2 * CFFM_HEADS * CFFM_NQ_PAD * BP_RING_LD)
-#define BP_TOTAL (BP_TAB_OFF + CFFM_HEADS * BP_TAB_LD)
-// per-key lookup: offset of the (q = 0) entry in `tab` and the row length of the key's table; (0,0) -> the zero entries
-__device__ __forceinline__ void key_bias_lut(int n, int& base, int& side) {
-    base = 0; side = 0;
-    if (n < 49) { base = 7 + (6 - n / 7) * 13 + (6 - n % 7); side = 13; return; }
-    if (n < 181 || n >= CFFM_NKEY) return;
-    int s0, kk, off;
-    if (n < 206) { s0 = 181; kk = 5; off = 176; }
-    else if (n < 255) { s0 = 206; kk = 7; off = 297; }
-    else if (n < 280) { s0 = 255; kk = 5; off = 466; }
-    else { s0 = 280; kk = 3; off = 587; }
-    side = 6 + kk;
-    base = off + (kk - 1 - (n - s0) / kk) * side + (kk - 1 - (n - s0) % kk);
-}
-__global__ void __launch_bounds__(256) k_bias_pack(BiasTables t, float* __restrict__ pack) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= BP_TOTAL) return;
-    float v = 0.f;
-    if (e < BP_TAB_OFF) {
-        int h, q, n;
-        if (e < BP_RINGT_OFF) { n = e % BP_RING_LD; q = (e / BP_RING_LD) % CFFM_NQ_PAD; h = e / (BP_RING_LD * CFFM_NQ_PAD); }
-        else { const int f = e - BP_RINGT_OFF; q = f % CFFM_NQ_PAD; n = (f / CFFM_NQ_PAD) % BP_RING_LD; h = f / (CFFM_NQ_PAD * BP_RING_LD); }
-        if (q < CFFM_WA && n >= 49 && n < 181) v = t.ring[(h * 49 + q) * 132 + (n - 49)];
-    } else {
-        const int f = e - BP_TAB_OFF, h = f / BP_TAB_LD, i = f % BP_TAB_LD;
-        if (i >= 7 && i < 176) v = t.own[(i - 7) * CFFM_HEADS + h];
-        else if (i >= 176 && i < 297) v = t.pool[0][h * 121 + (i - 176)];
-        else if (i >= 297 && i < 466) v = t.pool[1][h * 169 + (i - 297)];
-        else if (i >= 466 && i < 587) v = t.pool[2][h * 121 + (i - 466)];
-        else if (i >= 587 && i < 668) v = t.pool[3][h * 81 + (i - 587)];
-    }
-    pack[e] = v;
-}
-
 // dbiasT [8][304][64] (key-major, as the attention backward accumulates it) -> the six tables.
 // Gather form (no atomics): one thread per table entry sums the <= 49 (query, key) pairs that index it.
 __global__ void __launch_bounds__(256) k_bias_scatter(const float* __restrict__ dbiasT, BiasTablesG g) {
