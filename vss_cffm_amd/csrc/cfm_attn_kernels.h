@@ -25,6 +25,9 @@
 #pragma once
 #include "cffa_kernels.h"
 
+#ifndef FWD_ABLATE
+#define FWD_ABLATE 0  // profiling only: 1 no bias loads, 2 no K/V gathers, 4 no softmax exp, 8 no PV MFMA, 16 no V^T LDS writes
+#endif
 #define ATT_KS_STRIDE 40   // halfs per K/V/Q row in LDS (32 + 8 pad = 80 B)
 #define ATT_VT_STRIDE 328  // halfs per row of a [32][keys] transposed image (164 dwords = 4*41)
 #define ATT_QT_STRIDE 72   // halfs per row of a [32][64 queries] transposed image (36 dwords = 4*9)
@@ -70,8 +73,8 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
         k0[it] = k1[it] = v0[it] = v1[it] = z8;
-        if (src0[it] >= 0) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
-        if (src1[it] >= 0) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
+        if (src0[it] >= 0 && !(FWD_ABLATE & 2)) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
+        if (src1[it] >= 0 && !(FWD_ABLATE & 2)) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
     }
     const int qi = tid >> 2, qc = tid & 3;
     f16x8 qv = z8;
@@ -86,10 +89,12 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
             const int n0 = 2 * pr;
             *(f16x8*)(Ks + n0 * ATT_KS_STRIDE + 8 * c4) = k0[it];
             *(f16x8*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = k1[it];
+            if (!(FWD_ABLATE & 16)) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 f16x2 pv; pv[0] = v0[it][e]; pv[1] = v1[it][e];
                 *(f16x2*)(Vt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pv;
+            }
             }
         }
     }
@@ -98,7 +103,7 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
     const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
     f32x4 s[19];
 #pragma unroll
-    for (int t = 0; t < 19; ++t) s[t] = ld4(brow + 16 * t);
+    for (int t = 0; t < 19; ++t) s[t] = (FWD_ABLATE & 1) ? (f32x4){0.f, 0.f, 0.f, 0.f} : ld4(brow + 16 * t);
     __syncthreads();
 
     // ---- S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column -----------------
@@ -117,7 +122,8 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 #pragma unroll
     for (int t = 0; t < 19; ++t) {
         f32x4 p;
-        p[0] = fast_exp(s[t][0] - m); p[1] = fast_exp(s[t][1] - m); p[2] = fast_exp(s[t][2] - m); p[3] = fast_exp(s[t][3] - m);
+        if (FWD_ABLATE & 4) { p = s[t] - m; } else {
+        p[0] = fast_exp(s[t][0] - m); p[1] = fast_exp(s[t][1] - m); p[2] = fast_exp(s[t][2] - m); p[3] = fast_exp(s[t][3] - m); }
         s[t] = p;
         l += (p[0] + p[1]) + (p[2] + p[3]);
     }
@@ -135,6 +141,7 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
         for (int mt = 0; mt < 2; ++mt) {
             const f16* vr = Vt + (16 * mt + (lane & 15)) * ATT_VT_STRIDE + 32 * kt + 4 * g;
             const f16x8 vf = cat_f16x4(*(const f16x4*)vr, *(const f16x4*)(vr + 16));
+            if (FWD_ABLATE & 8) { o[mt][0] += (float)vf[0] + (float)pf[0]; } else
             o[mt] = mfma16x16x32_f16(vf, pf, o[mt]);
         }
     }
