@@ -180,30 +180,39 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 #define ATT_BWK_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
                      CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
 
-// stage the window's K, V rows (and optionally K^T) from the f16 q|k|v rows: two batches of global loads
-template <int NTHREADS, bool WITH_KT>
-__device__ __forceinline__ void stage_kv(const h16* __restrict__ base, const int* __restrict__ ksrc, f16* Ks, f16* Vs, f16* Kt,
-                                         float* vflag, int tid) {
-    constexpr int NW = NTHREADS / 64, NIT = (CFFM_NKEY_PAD / 2 + NW * 16 - 1) / (NW * 16);
-    const int lane = tid & 63, wave = tid >> 6, c4 = lane >> 4;
+// A window's K / V rows on their way from the f16 q|k|v rows to LDS, held in registers so that the gather of window w+1
+// can be in flight while window w is multiplied (kv_load: key-table entries, then the 16-byte row segments; kv_store:
+// K, V row-major (+ optionally K^T as packed key pairs) and the key-validity flags, which come from the same entries).
+template <int NTHREADS>
+struct KvRegs {
+    static constexpr int NW = NTHREADS / 64, NIT = (CFFM_NKEY_PAD / 2 + NW * 16 - 1) / (NW * 16);
     int src0[NIT], src1[NIT];
+    f16x8 k0[NIT], k1[NIT], v0[NIT], v1[NIT];
+};
+template <int NTHREADS>
+__device__ __forceinline__ void kv_load(KvRegs<NTHREADS>& r, const h16* __restrict__ base, const int* __restrict__ ksrc, int tid) {
+    constexpr int NW = KvRegs<NTHREADS>::NW, NIT = KvRegs<NTHREADS>::NIT;
+    const int lane = tid & 63, wave = tid >> 6, c4 = lane >> 4;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int prk = (it * NW + wave) * 16 + (lane & 15);
         const bool ok = prk < CFFM_NKEY_PAD / 2;
-        src0[it] = ok ? ksrc[2 * prk] : -1;
-        src1[it] = ok ? ksrc[2 * prk + 1] : -1;
+        r.src0[it] = ok ? ksrc[2 * prk] : -1;
+        r.src1[it] = ok ? ksrc[2 * prk + 1] : -1;
     }
     f16x8 z8;
     for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
-    f16x8 k0[NIT], k1[NIT], v0[NIT], v1[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        k0[it] = k1[it] = v0[it] = v1[it] = z8;
-        if (src0[it] >= 0) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
-        if (src1[it] >= 0) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
+        r.k0[it] = r.k1[it] = r.v0[it] = r.v1[it] = z8;
+        if (r.src0[it] >= 0) { r.k0[it] = ld_h8(base + (long)r.src0[it] * 768 + 256 + 8 * c4); r.v0[it] = ld_h8(base + (long)r.src0[it] * 768 + 512 + 8 * c4); }
+        if (r.src1[it] >= 0) { r.k1[it] = ld_h8(base + (long)r.src1[it] * 768 + 256 + 8 * c4); r.v1[it] = ld_h8(base + (long)r.src1[it] * 768 + 512 + 8 * c4); }
     }
-    for (int n = tid; n < CFFM_NKEY_PAD; n += NTHREADS) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
+}
+template <int NTHREADS, bool WITH_KT>
+__device__ __forceinline__ void kv_store(const KvRegs<NTHREADS>& r, f16* Ks, f16* Vs, f16* Kt, float* vflag, int tid) {
+    constexpr int NW = KvRegs<NTHREADS>::NW, NIT = KvRegs<NTHREADS>::NIT;
+    const int lane = tid & 63, wave = tid >> 6, c4 = lane >> 4;
     if (WITH_KT)
         for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += NTHREADS)
             Kt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
@@ -212,18 +221,51 @@ __device__ __forceinline__ void stage_kv(const h16* __restrict__ base, const int
         const int prk = (it * NW + wave) * 16 + (lane & 15);
         if (prk < CFFM_NKEY_PAD / 2) {
             const int n0 = 2 * prk;
-            *(f16x8*)(Ks + n0 * ATT_KS_STRIDE + 8 * c4) = k0[it];
-            *(f16x8*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = k1[it];
-            *(f16x8*)(Vs + n0 * ATT_KS_STRIDE + 8 * c4) = v0[it];
-            *(f16x8*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = v1[it];
+            if (c4 == 0) { vflag[n0] = r.src0[it] >= 0 ? 0.f : -INFINITY; vflag[n0 + 1] = r.src1[it] >= 0 ? 0.f : -INFINITY; }
+            *(f16x8*)(Ks + n0 * ATT_KS_STRIDE + 8 * c4) = r.k0[it];
+            *(f16x8*)(Ks + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = r.k1[it];
+            *(f16x8*)(Vs + n0 * ATT_KS_STRIDE + 8 * c4) = r.v0[it];
+            *(f16x8*)(Vs + (n0 + 1) * ATT_KS_STRIDE + 8 * c4) = r.v1[it];
             if (WITH_KT) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    f16x2 pk; pk[0] = k0[it][e]; pk[1] = k1[it][e];
+                    f16x2 pk; pk[0] = r.k0[it][e]; pk[1] = r.k1[it][e];
                     *(f16x2*)(Kt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pk;
                 }
             }
         }
+    }
+}
+template <int NTHREADS, bool WITH_KT>
+__device__ __forceinline__ void stage_kv(const h16* __restrict__ base, const int* __restrict__ ksrc, f16* Ks, f16* Vs, f16* Kt,
+                                         float* vflag, int tid) {
+    KvRegs<NTHREADS> r;
+    kv_load<NTHREADS>(r, base, ksrc, tid);
+    kv_store<NTHREADS, WITH_KT>(r, Ks, Vs, Kt, vflag, tid);
+}
+
+// the query-owner lane's own operands of one window: Q fragment, dO / O (8 channels), LSE, destination pixel
+struct QLaneRegs {
+    f16x8 qfrag;
+    f32x4 do0, do1, o0, o1;
+    float lq;
+};
+__device__ __forceinline__ void qlane_load(QLaneRegs& r, const Geo& G, const h16* __restrict__ base, const int* __restrict__ q_dst,
+                                           const float* __restrict__ ao, const float* __restrict__ dao,
+                                           const float* __restrict__ lse_in, int wb, int h, int qcol, int g) {
+    const int w = wb % G.nW, b = wb / G.nW;
+    const int dst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;
+    for (int e = 0; e < 8; ++e) r.qfrag[e] = (f16)0.f;
+    r.do0 = r.do1 = r.o0 = r.o1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    r.lq = 0.f;
+    if (qcol < CFFM_WA) {
+        r.qfrag = ld_h8(base + (long)(w * CFFM_WA + qcol) * 768 + 8 * g);
+        r.lq = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol];
+    }
+    if (dst >= 0) {
+        const long off = ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 8 * g;
+        r.do0 = ld4(dao + off); r.do1 = ld4(dao + off + 4);
+        r.o0 = ld4(ao + off); r.o1 = ld4(ao + off + 4);
     }
 }
 
@@ -251,27 +293,28 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
 #pragma unroll
     for (int t = 0; t < 19; ++t) dB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Software pipeline over the group's windows: while window wb is multiplied, the K/V gather and this lane's Q / dO / O
+    // operands of window wb+1 are already in flight in registers (the 512-register budget of one workgroup per CU pays
+    // for it), so the per-window gather latency is off the critical path.
+    KvRegs<256> kv;
+    QLaneRegs ql;
+    if (wb0 < wb1) {
+        const h16* base0 = qkv + (long)(wb0 / G.nW) * G.RC * 768 + h * CFFM_HD;
+        kv_load<256>(kv, base0, key_src + (wb0 % G.nW) * CFFM_NKEY_PAD, tid);
+        qlane_load(ql, G, base0, q_dst, ao, dao, lse_in, wb0, h, qcol, g);
+    }
     for (int wb = wb0; wb < wb1; ++wb) {
         const int w = wb % G.nW, b = wb / G.nW;
-        const int* ksrc = key_src + w * CFFM_NKEY_PAD;
-        const h16* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;   // f16, bias added, q pre-scaled
-
-        // this lane's query: Q fragment (16 B of f16), dO / O fragments (8 channels), LSE
-        const int dst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;
-        f16x8 qfrag;
-        for (int e = 0; e < 8; ++e) qfrag[e] = (f16)0.f;
-        f32x4 do0 = (f32x4){0.f, 0.f, 0.f, 0.f}, do1 = do0, o0 = do0, o1 = do0;
-        float lq = 0.f;
-        if (qcol < CFFM_WA) {
-            qfrag = ld_h8(base + (long)(w * CFFM_WA + qcol) * 768 + 8 * g);
-            lq = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol];
+        kv_store<256, true>(kv, Ks, Vs, Kt, vflag, tid);
+        const f16x8 qfrag = ql.qfrag;
+        const f32x4 do0 = ql.do0, do1 = ql.do1, o0 = ql.o0, o1 = ql.o1;
+        const float lq = ql.lq;
+        __syncthreads();
+        if (wb + 1 < wb1) {
+            const h16* basen = qkv + (long)((wb + 1) / G.nW) * G.RC * 768 + h * CFFM_HD;
+            kv_load<256>(kv, basen, key_src + ((wb + 1) % G.nW) * CFFM_NKEY_PAD, tid);
+            qlane_load(ql, G, basen, q_dst, ao, dao, lse_in, wb + 1, h, qcol, g);
         }
-        if (dst >= 0) {
-            const long off = ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 8 * g;
-            do0 = ld4(dao + off); do1 = ld4(dao + off + 4);
-            o0 = ld4(ao + off); o1 = ld4(ao + off + 4);
-        }
-        stage_kv<256, true>(base, ksrc, Ks, Vs, Kt, vflag, tid);
 
         float Dq = (do0[0] * o0[0] + do0[1] * o0[1]) + (do0[2] * o0[2] + do0[3] * o0[3]) + (do1[0] * o1[0] + do1[1] * o1[1]) +
                    (do1[2] * o1[2] + do1[3] * o1[3]);
@@ -286,7 +329,6 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
         Dq *= sc;
         f16x8 dofrag;
         for (int e = 0; e < 4; ++e) { dofrag[e] = (f16)(do0[e] * sc); dofrag[4 + e] = (f16)(do1[e] * sc); }
-        __syncthreads();
 
         f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         f32x4 bcur[2] = {ld4(brow), ld4(brow + 16)};   // bias tiles are fetched one key-tile pair ahead
