@@ -117,16 +117,21 @@ def main():
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local_rank], gradient_as_bucket_view=True,
                                                           broadcast_buffers=False)
-    opt = torch.optim.AdamW(layer.parameters(), lr=6e-5, weight_decay=0.01, fused=True)
+    # the reference's optimizer (local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:35), as this package's one-launch kernel
+    opt = V.optim.AdamW(layer.parameters(), lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
     gen = torch.Generator(device='cpu').manual_seed(1000 + rank)
     b = args.batch
     x = (torch.randn(b, T, 256, GRID, GRID, generator=gen) * 1.5).to(dev)
-    gy = (torch.randn(b, 256, GRID, GRID, generator=gen) / (b * 256 * GRID * GRID)).to(dev)
+    # upstream gradient of the layer output [B,4,256,H,W]: the head consumes only the new target frame
+    # (cffm_head.py:145 `_c_further[:,-1]`), so frames 0..2 receive zeros; fixed synthetic values on the target frame
+    gy = torch.zeros(b, T, 256, GRID, GRID)
+    gy[:, -1] = torch.randn(b, 256, GRID, GRID, generator=gen) / (b * 256 * GRID * GRID)
+    gy = gy.to(dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
         y = model(x)
-        (y[:, -1] * gy).sum().backward()
+        y.backward(gy)
         opt.step()
 
     for _ in range(args.warmup):

@@ -159,6 +159,22 @@ int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* 
                         const float* dy_tgt_nchw, float* dx_nchw, const int* key_src, const int* q_dst,
                         const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream);
 
+/* ---- parameter update of the training step (the reference trains the head with AdamW, lr 6e-5, betas (0.9, 0.999),
+ * weight decay 0.01: local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:35) ----
+ * One launch over every parameter tensor of the hot path: `chunks` is a device table, one entry per <= CFFM_ADAMW_CHUNK
+ * consecutive elements of one tensor.  Decoupled weight decay, bias-corrected moments, exactly torch.optim.AdamW
+ * (amsgrad off): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
+#define CFFM_ADAMW_CHUNK 2048
+typedef struct {
+    float* p;           /* parameter values (updated in place) */
+    const float* g;     /* gradient */
+    float* m;           /* first moment (updated) */
+    float* v;           /* second moment (updated) */
+    long n;             /* 1..CFFM_ADAMW_CHUNK elements */
+} cffm_adamw_chunk;
+int cffm_adamw_step(const cffm_adamw_chunk* chunks /* device */, int nchunks, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int step /* t >= 1 */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
 ABI_VERSION = 1
 
-vp, ci, cl = C.c_void_p, C.c_int, C.c_long
+vp, ci, cl, cd = C.c_void_p, C.c_int, C.c_long, C.c_double
 
 
 class Geom(C.Structure):
@@ -73,6 +73,7 @@ SIGNATURES = {
     'cffm_layer_backward': (ci, [GP, ci, BP, BP, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_gtc_attn_fwd': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_gtc_attn_bwd': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    'cffm_adamw_step': (ci, [vp, ci, cd, cd, cd, cd, cd, ci, vp]),
 }
 
 

@@ -41,10 +41,10 @@ static Geo to_geo(const cffm_geom* g) {
 // Optional per-stage HIP-event timing on the caller's stream (bench.py's live `roofline` numbers):
 // when enabled every stage-level entry point brackets its launches with two events.
 enum { ST_TRANSPOSE, ST_POOLMAT, ST_LN_POOL_FWD, ST_LN_POOL_BWD, ST_BIAS_ASM, ST_BIAS_SCT, ST_ATTN_FWD, ST_ATTN_BWD,
-       ST_GEMM, ST_COLSUM, ST_RES_LN, ST_LN_BWD, ST_GELU, ST_GELU_BWD, ST_RES_OUT, ST_GTC_FWD, ST_GTC_BWD, ST_LN, ST_COUNT };
+       ST_GEMM, ST_COLSUM, ST_RES_LN, ST_LN_BWD, ST_GELU, ST_GELU_BWD, ST_RES_OUT, ST_GTC_FWD, ST_GTC_BWD, ST_LN, ST_ADAMW, ST_COUNT };
 static const char* const k_stage_names[ST_COUNT] = {"transpose", "pool_matrix", "ln_pool_fwd", "ln_pool_bwd", "bias_assemble",
     "bias_scatter", "cfm_attn_fwd", "cfm_attn_bwd", "linear_gemm", "colsum", "residual_ln", "ln_bwd", "bias_gelu", "gelu_bwd",
-    "residual_out", "gtc_attn_fwd", "gtc_attn_bwd", "layernorm"};
+    "residual_out", "gtc_attn_fwd", "gtc_attn_bwd", "layernorm", "adamw"};
 #ifndef CFFM_EMU
 #include <vector>
 struct ProfRec { int stage; hipEvent_t e0, e1; };
@@ -464,6 +464,20 @@ int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------- optimizer
+int cffm_adamw_step(const cffm_adamw_chunk* chunks, int nchunks, double lr, double beta1, double beta2, double eps, double weight_decay,
+                    int step, void* stream) {
+    static_assert(sizeof(cffm_adamw_chunk) == sizeof(AdamwChunk), "chunk layout");
+    if (nchunks <= 0) return 0;
+    REQUIRE(step >= 1, "adamw: step must be >= 1, got %d", step);
+    PROF(ST_ADAMW);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    CFFM_LAUNCH(k_adamw, ((unsigned)nchunks), (256), 0, (hipStream_t)stream, (const AdamwChunk*)chunks, (float)(1.0 - lr * weight_decay), (float)beta1,
+                (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
+    CHECK_LAUNCH("adamw");
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------- CFFM++ (GTC) stages
 int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean, float* rstd,

@@ -22,18 +22,28 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
         if (!out) return -1;
     }
     const long b128 = (long)((N + 127) / 128) * ((M + 127) / 128) * ksplit;
-#define GEMM_GO(BM_, BN_, BK_, PF_)                                                                                                    \
-    CFFM_LAUNCH((k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_>), ((N + BN_ - 1) / BN_, (M + BM_ - 1) / BM_, ksplit), (256), \
+#ifdef CFFM_EMU
+#define GEMM_BIG_LDS(BM_, BN_, BK_, PF_)
+#else   // more than 64 KiB of dynamic LDS has to be granted per kernel, once
+#define GEMM_BIG_LDS(BM_, BN_, BK_, PF_)                                                                                      \
+    if (GEMM_LDS(BM_, BN_, BK_) > 65536) {                                                                                    \
+        static bool granted = false;                                                                                          \
+        if (!granted) {                                                                                                       \
+            if (hipFuncSetAttribute((const void*)k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_>,                              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS(BM_, BN_, BK_)) != hipSuccess)       \
+                return -1;                                                                                                    \
+            granted = true;                                                                                                   \
+        }                                                                                                                     \
+    }
+#endif
+#define GEMM_GO(BM_, BN_, BK_, PF_) do {                                                                                               \
+    GEMM_BIG_LDS(BM_, BN_, BK_, PF_)                                                                                                   \
+    CFFM_LAUNCH((k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_>), ((unsigned)(((N + BN_ - 1) / BN_) * ((M + BM_ - 1) / BM_) * ksplit)), (256), \
                 GEMM_LDS(BM_, BN_, BK_), st, A, \
-                B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux)
+                B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux); } while (0)
     // measured on MI355X (scripts/gemm_bench.py, CFFM-B1 shapes): 128x128 wins when it already gives >= 384 workgroups
     // (qkv / fc1 forward, the 1024-wide input gradient), 64x64 otherwise; prefetch depth beyond the listed one is neutral.
-    static int bk64 = -1;   // tuning aid: CFFM_GEMM_BK=64
-    if (bk64 < 0) { const char* e = getenv("CFFM_GEMM_BK"); bk64 = (e && atoi(e) == 64) ? 1 : 0; }
-    if (bk64) {
-        if (b128 >= 384) GEMM_GO(128, 128, 64, 1);
-        else GEMM_GO(64, 64, 64, 2);
-    } else if (b128 >= 384 || prefer_big) GEMM_GO(128, 128, 32, 1);
+    if (b128 >= 384 || prefer_big) GEMM_GO(128, 128, 32, 1);
     else GEMM_GO(64, 64, 32, 3);
 #undef GEMM_GO
     if (ksplit > 1) {

@@ -63,6 +63,9 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
     }
 }
 
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0   // profiling builds only: 1 no global loads in the K-loop, 2 no split / LDS stores, 4 no MFMAs
+#endif
 #define GEMM_LD(BK) ((BK) + 8)  // bf16 per LDS row (BK + 8 pad: 80 / 144 B strides keep ds_read_b128 fragments conflict-free)
 #define GEMM_TLD 68 // floats per row of the epilogue transposition tile (64 + 4 pad)
 
@@ -106,6 +109,56 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& r, const float* __
                 r.v[2 * it + h] = v;
             }
         }
+    }
+}
+
+// Raw buffer loads for the K-loop's fast path: a buffer resource carries the operand's extent, so a tile row past the
+// matrix reads as zeros without a branch, and the address is one per-thread VGPR offset (fixed for the whole kernel) plus a
+// scalar offset that walks the contraction -- no per-tile vector address arithmetic, no exec-mask branches between the
+// MFMAs (which would split the loop body into basic blocks and forbid interleaving the split with the multiplication).
+#ifdef CFFM_EMU
+struct buf_t { const char* p; uint32_t n; };
+static inline buf_t buf_make(const void* p, uint32_t bytes) { return buf_t{(const char*)p, bytes}; }
+static inline f32x4 buf_ld16(buf_t r, uint32_t voff, uint32_t soff) {
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t o = voff + soff + 4 * e;
+        float f = 0.f;
+        if (o + 4 <= r.n) __builtin_memcpy(&f, r.p + o, 4);
+        v[e] = f;
+    }
+    return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t buf_t;
+__device__ __forceinline__ buf_t buf_make(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld16(buf_t r, uint32_t voff, uint32_t soff) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    f32x4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+#endif
+// this thread's fixed byte offset inside an operand tile (whole tiles: the same items as tile_load)
+template <int ROWS, bool TR, int BK>
+__device__ __forceinline__ uint32_t tile_voff(int ld, int tid) {
+    if (!TR) return (uint32_t)(((tid / (BK / 4)) * ld + 4 * (tid % (BK / 4))) * 4);
+    return (uint32_t)((2 * (tid / (ROWS / 4)) * ld + 4 * (tid % (ROWS / 4))) * 4);
+}
+// global -> registers, branch-free; soff = byte offset of the tile origin ((row0*ld + k0)*4, or (k0*ld + row0)*4 when TR)
+template <int ROWS, bool TR, int BK>
+__device__ __forceinline__ void tile_load_fast(TileRegs<ROWS, BK>& r, buf_t rs, uint32_t voff, uint32_t soff, uint32_t ld4) {
+    if (!TR) {
+#pragma unroll
+        for (int it = 0; it < ROWS * BK / 1024; ++it) r.v[it] = buf_ld16(rs, voff, soff + it * (1024 / BK) * ld4);
+    } else {
+#pragma unroll
+        for (int it = 0; it < ROWS * BK / 2048; ++it)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) r.v[2 * it + h] = buf_ld16(rs, voff, soff + (it * (2048 / ROWS) + h) * ld4);
     }
 }
 
@@ -159,7 +212,21 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
     return f;
 }
 
-#define GEMM_LDS(BM, BN, BK) (((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 2) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 2) : (4 * 32 * GEMM_TLD * 4))
+#define GEMM_LDS(BM, BN, BK) (((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 4) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 4) : (4 * 32 * GEMM_TLD * 4))
+
+// Scheduling hint for the pipelined K-loop body: issue the split's VALU work / LDS traffic between consecutive MFMAs
+// (a wave issues in order: without it the compiler emits the MFMAs back to back and the split as a phase of its own).
+#ifdef CFFM_EMU
+#define GEMM_INTERLEAVE(NMFMA)
+#else
+#define GEMM_INTERLEAVE(NMFMA)                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < (NMFMA); ++q_) {                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */            \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* 3 VALU */            \
+        __builtin_amdgcn_sched_group_barrier(0x300, 1, 0); /* 1 DS read/write */   \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* 1 VMEM read */       \
+    }
+#endif
 
 // grid (ceil(N/BN), ceil(M/BM), ksplit); BM, BN in {64, 128}; BK in {32, 64}; wave tile (BM/2) x (BN/2).
 // K range of split z: [z*klen, min(K, (z+1)*klen)), klen a multiple of BK.
@@ -176,8 +243,15 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
     bf16* Bh = Al + BM * GEMM_LD(BK);
     bf16* Bl = Bh + BN * GEMM_LD(BK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int kbeg = blockIdx.z * klen, kend = (kbeg + klen < K) ? kbeg + klen : K;
+    // XCD-aware placement (speed only): workgroup b runs on XCD b % 8, each XCD with its own 4 MiB L2.  The 1-D grid is
+    // re-numbered so that every XCD owns a CONTIGUOUS run of (k-slice, row panel, column tile) triples, column tile
+    // fastest: the tiles that share an A row panel / a k-slice then hit the same L2 instead of eight different ones.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+    const int bz = lin / (ntn * ntm), by = (lin / ntn) % ntm, bx = lin % ntn;
+    const int n0 = bx * BN, m0 = by * BM;
+    const int kbeg = bz * klen, kend = (kbeg + klen < K) ? kbeg + klen : K;
     constexpr int MT = BM / 32, NT = BN / 32;  // 16x16 tiles per wave along M and N (wave tile = BM/2 x BN/2)
     const int wr = (wave >> 1) * (BM / 2), wc = (wave & 1) * (BN / 2);
     f32x4 acc[MT][NT];
@@ -186,40 +260,86 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // PF K-tiles are always in flight in registers: a K-step (~0.1-0.4 us of MFMA) is far shorter than the ~1-2 us a
-    // tile takes to arrive from HBM / Infinity Cache, and co-resident workgroups run in lockstep, so they cannot hide
-    // each other's waits; tile t+PF is requested before tile t is multiplied.
+    // Software pipeline, one barrier per K-tile: the LDS operand images are double-buffered, so while tile t is
+    // multiplied out of buffer t&1 the SAME wave splits tile t+1 (already in registers) into buffer (t+1)&1 -- the split's
+    // VALU work and LDS writes issue in the shadow of the MFMAs instead of in a phase of their own -- and tiles
+    // t+2 .. t+1+PF are in flight from L2 / HBM into registers (a K-step is far shorter than that latency, and
+    // co-resident workgroups run in lockstep, so they cannot hide each other's waits).
+    constexpr int IMG = (2 * BM + 2 * BN) * GEMM_LD(BK);   // bf16 elements of one buffer (Ah | Al | Bh | Bl)
     TileRegs<BM, BK> ra[PF];
     TileRegs<BN, BK> rb[PF];
+    const int NKT = (kend - kbeg + BK - 1) / BK;
+    tile_load<BM, A_T, BK>(ra[0], A, lda, m0, M, kbeg, kend, tid);
+    tile_load<BN, B_T, BK>(rb[0], B, ldb, n0, N, kbeg, kend, tid);
+    tile_store<BM, A_T, BK>(ra[0], Ah, Al, tid);
+    tile_store<BN, B_T, BK>(rb[0], Bh, Bl, tid);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {   // past kend -> zeros, never used
-        tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + u * BK, kend, tid);
-        tile_load<BN, B_T, BK>(rb[u], B, ldb, n0, N, kbeg + u * BK, kend, tid);
+    for (int u = 0; u < PF; ++u) {   // tile 1+u -> register set u (past kend -> zeros, never used)
+        tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + (1 + u) * BK, kend, tid);
+        tile_load<BN, B_T, BK>(rb[u], B, ldb, n0, N, kbeg + (1 + u) * BK, kend, tid);
     }
-    for (int k0 = kbeg; k0 < kend; k0 += PF * BK) {
+    __syncthreads();
+    int t0 = 0;
+    // Fast path (whole K-tiles; a row-contiguous operand also whole row tiles): while at least 2*PF tiles remain every
+    // step multiplies, splits and loads unconditionally, so the loop body is ONE basic block and the scheduling hints
+    // below can place the split's VALU work / LDS writes / buffer loads between the MFMAs.
+    if ((kend - kbeg) % BK == 0 && (!A_T || M % BM == 0) && (!B_T || N % BN == 0) && !(GEMM_ABLATE & 8)) {
+        const buf_t rsa = buf_make(A, (uint32_t)((A_T ? K : M) * (long)lda * 4)), rsb = buf_make(B, (uint32_t)((B_T ? K : N) * (long)ldb * 4));
+        const uint32_t va = tile_voff<BM, A_T, BK>(lda, tid), vb = tile_voff<BN, B_T, BK>(ldb, tid);
+        const uint32_t lda4 = lda * 4, ldb4 = ldb * 4;
+        // byte offset of tile 0 and per-tile advance
+        const uint32_t sa0 = A_T ? (uint32_t)(kbeg * lda + m0) * 4 : (uint32_t)(m0 * lda + kbeg) * 4, dsa = A_T ? BK * lda4 : BK * 4;
+        const uint32_t sb0 = B_T ? (uint32_t)(kbeg * ldb + n0) * 4 : (uint32_t)(n0 * ldb + kbeg) * 4, dsb = B_T ? BK * ldb4 : BK * 4;
+        for (; t0 + 2 * PF < NKT; t0 += PF) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int kk = k0 + u * BK;
-            if (kk < kend) {   // uniform across the workgroup
-                tile_store<BM, A_T, BK>(ra[u], Ah, Al, tid);
-                tile_store<BN, B_T, BK>(rb[u], Bh, Bl, tid);
-                __syncthreads();
-                if (kk + PF * BK < kend) {
-                    tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kk + PF * BK, kend, tid);
-                    tile_load<BN, B_T, BK>(rb[u], B, ldb, n0, N, kk + PF * BK, kend, tid);
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;
+                const int cur = (t & 1) * IMG, nxt = IMG - cur;
+                bf16x8 bh[NT], bl[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bh[j] = frag_read<BN, B_T, BK>(Bh + cur, wc + 16 * j + l15, g, 0);
+                    bl[j] = frag_read<BN, B_T, BK>(Bl + cur, wc + 16 * j + l15, g, 0);
                 }
 #pragma unroll
-                for (int ks = 0; ks < BK; ks += 32) {
+                for (int i = 0; i < MT; ++i) {
+                    const bf16x8 ah = frag_read<BM, A_T, BK>(Ah + cur, wr + 16 * i + l15, g, 0);
+                    const bf16x8 al = frag_read<BM, A_T, BK>(Al + cur, wr + 16 * i + l15, g, 0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
+                        acc[i][j] = mfma16x16x32_bf16(al, bh[j], acc[i][j]);
+                        acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
+                    }
+                }
+                tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid);
+                tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid);
+                tile_load_fast<BM, A_T, BK>(ra[u], rsa, va, sa0 + (t + 1 + PF) * dsa, lda4);
+                tile_load_fast<BN, B_T, BK>(rb[u], rsb, vb, sb0 + (t + 1 + PF) * dsb, ldb4);
+                GEMM_INTERLEAVE(3 * MT * NT);
+                __syncthreads();
+            }
+        }
+    }
+    static_assert(BK == 32, "the pipelined K-loop is written for 32-deep tiles");
+    for (; t0 < NKT; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u;
+            if (t < NKT) {   // uniform across the workgroup
+                const int cur = (t & 1) * IMG, nxt = IMG - cur;
+#pragma unroll
+                for (int ks = 0; ks < ((GEMM_ABLATE & 4) ? 0 : BK); ks += 32) {
                     bf16x8 bh[NT], bl[NT];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        bh[j] = frag_read<BN, B_T, BK>(Bh, wc + 16 * j + l15, g, ks);
-                        bl[j] = frag_read<BN, B_T, BK>(Bl, wc + 16 * j + l15, g, ks);
+                        bh[j] = frag_read<BN, B_T, BK>(Bh + cur, wc + 16 * j + l15, g, ks);
+                        bl[j] = frag_read<BN, B_T, BK>(Bl + cur, wc + 16 * j + l15, g, ks);
                     }
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        const bf16x8 ah = frag_read<BM, A_T, BK>(Ah, wr + 16 * i + l15, g, ks);
-                        const bf16x8 al = frag_read<BM, A_T, BK>(Al, wr + 16 * i + l15, g, ks);
+                        const bf16x8 ah = frag_read<BM, A_T, BK>(Ah + cur, wr + 16 * i + l15, g, ks);
+                        const bf16x8 al = frag_read<BM, A_T, BK>(Al + cur, wr + 16 * i + l15, g, ks);
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
                             acc[i][j] = mfma16x16x32_bf16(ah, bl[j], acc[i][j]);
@@ -227,6 +347,14 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
                             acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
                         }
                     }
+                }
+                if (t + 1 < NKT && !(GEMM_ABLATE & 2)) {
+                    tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid);
+                    tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid);
+                }
+                if (t + 1 + PF < NKT && !(GEMM_ABLATE & 1)) {
+                    tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + (t + 1 + PF) * BK, kend, tid);
+                    tile_load<BN, B_T, BK>(rb[u], B, ldb, n0, N, kbeg + (t + 1 + PF) * BK, kend, tid);
                 }
                 __syncthreads();
             }
@@ -250,13 +378,13 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
         wave_lds_sync();
         const int c4 = 4 * (lane % LPR), col = n0 + wc + c4;
         f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (bias && blockIdx.z == 0 && col + 3 < N) bv = *(const f32x4*)(bias + col);
+        if (bias && bz == 0 && col + 3 < N) bv = *(const f32x4*)(bias + col);
 #pragma unroll
         for (int it = 0; it < 32 * LPR / 64; ++it) {
             const int rl = lane / LPR + (64 / LPR) * it, row = m0 + wr + 32 * half + rl;
             if (row >= M) continue;
             f32x4 v = *(const f32x4*)(T + rl * GEMM_TLD + c4);
-            float* dst = C + (long)blockIdx.z * split_stride + (long)row * ldc + col;
+            float* dst = C + (long)bz * split_stride + (long)row * ldc + col;
             if (EPI == 1 && col + 3 < N) {          // N % 4 == 0 for every fused use
                 *(f32x4*)dst = v;
                 f32x4 a;
@@ -281,7 +409,7 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
                 *(f32x4*)dst = v;
             } else {
                 for (int e = 0; e < 4; ++e)
-                    if (col + e < N) dst[e] = v[e] + ((bias && blockIdx.z == 0 && col + 3 >= N) ? bias[col + e] : 0.f);
+                    if (col + e < N) dst[e] = v[e] + ((bias && bz == 0 && col + 3 >= N) ? bias[col + e] : 0.f);
             }
         }
     }

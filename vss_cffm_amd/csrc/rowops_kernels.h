@@ -283,3 +283,34 @@ __global__ void __launch_bounds__(256) k_qkv_to_f16(const float* __restrict__ ra
         ((h16x4*)out)[e] = o;
     }
 }
+
+// --------------------------------------------------------------------------- AdamW over a table of tensor chunks
+// One workgroup per chunk (<= 2048 consecutive elements of one tensor): 7 streams of 4 B per element (p, g, m, v in;
+// p, m, v out), every one a 16-byte access per lane when the chunk is 16-byte aligned.  A multi-tensor launch whose
+// chunks are 64 K elements leaves most of the 256 CUs idle on a 1.6 M-parameter model; 2 K-element chunks give ~800
+// workgroups and the update runs at the HBM rate.
+struct AdamwChunk { float* p; const float* g; float* m; float* v; long n; };
+__global__ void __launch_bounds__(256) k_adamw(const AdamwChunk* __restrict__ chunks, float decay /* 1 - lr*wd */, float beta1,
+                                                float beta2, float omb1 /* 1 - beta1, rounded from double */, float omb2, float eps,
+                                                float step_size /* lr / bc1 */, float inv_sqrt_bc2) {
+    const AdamwChunk c = chunks[blockIdx.x];
+    const bool vec = (((uintptr_t)c.p | (uintptr_t)c.g | (uintptr_t)c.m | (uintptr_t)c.v) & 15) == 0;
+    const long n4 = vec ? c.n / 4 : 0;
+    for (long e = threadIdx.x; e < n4; e += 256) {
+        f32x4 p = ((const f32x4*)c.p)[e], m = ((const f32x4*)c.m)[e], v = ((const f32x4*)c.v)[e];
+        const f32x4 g = ((const f32x4*)c.g)[e];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = beta1 * m[k] + omb1 * g[k];
+            v[k] = beta2 * v[k] + omb2 * g[k] * g[k];
+            p[k] = p[k] * decay - step_size * (m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps));
+        }
+        ((f32x4*)c.p)[e] = p; ((f32x4*)c.m)[e] = m; ((f32x4*)c.v)[e] = v;
+    }
+    for (long e = 4 * n4 + threadIdx.x; e < c.n; e += 256) {
+        const float g = c.g[e];
+        const float m = beta1 * c.m[e] + omb1 * g, v = beta2 * c.v[e] + omb2 * g * g;
+        c.m[e] = m; c.v[e] = v;
+        c.p[e] = c.p[e] * decay - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    }
+}
