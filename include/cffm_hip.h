@@ -106,6 +106,10 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream);
 int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream);
 int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream);
+/* n <= 4 independent weight gradients (dw_i[N_i,K_i] = dy_i[M_i,N_i]^T x_i[M_i,K_i]) in one launch: the four Linear layers of a
+ * block (qkv / proj / fc1 / fc2 .weight.grad, cffm_transformer.py:374, :381, :18-19), none of which feeds the backward chain */
+typedef struct { const float* dy; const float* x; float* dw; long M; int N; int K; } cffm_wgrad;
+int cffm_linear_bwd_weight_group(const cffm_wgrad* problems /* host */, int n, void* stream);
 /* fused Mlp halves: hraw = x w^T (raw, kept for backward), act = gelu(hraw + b)  |  out = res + x w^T + b */
 int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K,
                          void* stream);

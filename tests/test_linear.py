@@ -1,0 +1,71 @@
+"""The Linear GEMM entry points of the C ABI (forward, input gradient, weight gradient, grouped weight gradients) against
+fp64 matmuls, at ragged shapes (rows not a multiple of the 32-deep K-tile, outputs not a multiple of the 64/128 tiles) and
+at shapes that take the whole-tile fast path and several k-slices.  Tolerance: split-bf16 operands (hi+lo, ~2^-17 per
+product, fp32 accumulate) -> 2e-5 relative to the result's norm.  CPU: emulator build; GPU: product library."""
+import ctypes as C
+
+import pytest
+import torch
+
+from tests import emu
+from vss_cffm_amd import _lib
+
+TOL = 2e-5
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b).norm() / b.norm())
+
+
+def run_linear_checks(lib, device, shapes, group_rows):
+    gen = torch.Generator().manual_seed(3)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
+    for (M, N, K) in shapes:
+        x, w, dy = (torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(M, N, generator=gen))
+        xd, wd, dyd = x.to(device), w.to(device), dy.to(device)
+        y, dx, dw = (torch.full((M, N), 7., device=device), torch.full((M, K), 7., device=device), torch.full((N, K), 7., device=device))
+        assert lib.cffm_linear_fwd(P(xd), P(wd), P(y), M, N, K, stream) == 0
+        assert lib.cffm_linear_bwd_input(P(dyd), P(wd), P(dx), M, N, K, stream) == 0
+        assert lib.cffm_linear_bwd_weight(P(dyd), P(xd), P(dw), M, N, K, stream) == 0
+        assert rel(y, x.double() @ w.double().T) < TOL, (M, N, K)
+        assert rel(dx, dy.double() @ w.double()) < TOL, (M, N, K)
+        assert rel(dw, dy.double().T @ x.double()) < TOL, (M, N, K)
+    # grouped weight gradients: the block's four shapes (N, K), two row counts as in the block (q|k|v rows vs target rows)
+    class WGrad(C.Structure):
+        _fields_ = [('dy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('M', C.c_long), ('N', C.c_int), ('K', C.c_int)]
+    for rows_qkv, rows_tgt in group_rows:
+        prob, keep, want = (WGrad * 4)(), [], []
+        for i, (M, N, K) in enumerate([(rows_qkv, 768, 256), (rows_tgt, 1024, 256), (rows_tgt, 256, 1024), (rows_tgt, 256, 256)]):
+            dy, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+            dyd, xd, dw = dy.to(device), x.to(device), torch.full((N, K), 7., device=device)
+            keep += [dyd, xd, dw]
+            want.append(dy.double().T @ x.double())
+            prob[i] = WGrad(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), M, N, K)
+        assert lib.cffm_linear_bwd_weight_group(prob, 4, stream) == 0
+        for i in range(4):
+            assert rel(keep[3 * i + 2], want[i]) < TOL, (rows_qkv, rows_tgt, i)
+    # a problem the grouped kernel cannot tile (N not a multiple of 128) takes the one-by-one path, same results
+    prob = (WGrad * 1)()
+    dy, x = torch.randn(70, 96, generator=gen), torch.randn(70, 40, generator=gen)
+    dyd, xd, dw = dy.to(device), x.to(device), torch.zeros(96, 40, device=device)
+    prob[0] = WGrad(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), 70, 96, 40)
+    assert lib.cffm_linear_bwd_weight_group(prob, 1, stream) == 0
+    assert rel(dw, dy.double().T @ x.double()) < TOL
+    assert lib.cffm_linear_bwd_weight_group(prob, 5, stream) != 0       # more than 4 problems: error, not a crash
+
+
+def test_linear_emulated():
+    with emu.active():
+        # small (the emulator runs one fiber per GPU thread): ragged + one whole-tile multi-slice case
+        run_linear_checks(emu.lib(), torch.device('cpu'), [(70, 96, 40), (130, 256, 64), (256, 128, 128)], [(200, 136), (1056, 1024)])
+
+
+@pytest.mark.gpu
+def test_linear_gpu():
+    lib = _lib.get()
+    shapes = [(70, 96, 40), (1000, 256, 256), (7200, 1024, 256), (7200, 256, 1024), (10368, 768, 256), (6480, 256, 256), (3969, 768, 256)]
+    run_linear_checks(lib, torch.device('cuda:0'), shapes, [(10368, 7200), (200, 136), (12960, 12960), (3969, 3600)])

@@ -58,6 +58,7 @@ SIGNATURES = {
     'cffm_linear_fwd': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_input': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_bwd_weight_group': (ci, [vp, ci, vp]),
     'cffm_linear_gelu_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_residual_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_colsum': (ci, [vp, cl, ci, vp, vp]),

@@ -201,6 +201,9 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
 // one partial record per workgroup, part[blk][LNP_REC] = dgamma[256] | dbeta[256] | dM[15*49] | dpool_bias[4]
 // (zeros outside this frame's cells); k_reduce_partials sums the records -- no contended atomics.
 #define LNP_REC (2 * CFFM_C + CFFM_NCELL * CFFM_WA + 4)
+#ifndef LNPB_ABLATE
+#define LNPB_ABLATE 0   // profiling builds only: 1 no dM reductions, 2 no LN reductions, 4 no dx stores
+#endif
 __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
                                                       const float* __restrict__ x_tgt, long tgt_bs,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -267,19 +270,29 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
         for (int c = 0; c < ncell; ++c) {
             const f32x4 dp = *(const f32x4*)(&sdP[c][4 * lane]);
             dz += sM[c * CFFM_WA + i] * dp;
+#if !(LNPB_ABLATE & 1)
             const float dm = wave_sum(dp[0] * z[0] + dp[1] * z[1] + dp[2] * z[2] + dp[3] * z[3]);
-            if (lane == 0) sdM[c * CFFM_WA + i] = dm;  // pixel i belongs to exactly one wave: no conflict
+            if (lane == 0) sdM[c * CFFM_WA + i] = dm;
+#endif  // pixel i belongs to exactly one wave: no conflict
         }
         ag += dz * xh;
         ab += dz;
         const f32x4 gz = dz * gm;
+#if LNPB_ABLATE & 2
+        const float m1 = gz[0], m2 = gz[1];
+#else
         const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
         const float m2 = wave_sum(gz[0] * xh[0] + gz[1] * xh[1] + gz[2] * xh[2] + gz[3] * xh[3]) * (1.f / CFFM_C);
+#endif
         f32x4 dx = (gz - m1 - xh * m2) * rs;
         if (frame == 3 && dres) dx += *(const f32x4*)(dres + ((long)b * G.HW + pix) * CFFM_C + 4 * lane);
         float* dst = dxf + pix * CFFM_C + 4 * lane;
+#if LNPB_ABLATE & 4
+        ag += dx;
+#else
         if (accum) dx += *(const f32x4*)dst;
         *(f32x4*)dst = dx;
+#endif
     }
     *(f32x4*)(&red[wave][0][4 * lane]) = ag;
     *(f32x4*)(&red[wave][1][4 * lane]) = ab;

@@ -339,6 +339,16 @@ int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, i
     return gemm_tn(dy, x, dw, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_weight: gemm failed") : 0;
 }
 
+int cffm_linear_bwd_weight_group(const cffm_wgrad* problems, int n, void* stream) {
+    REQUIRE(problems && n >= 1 && n <= 4, "linear_bwd_weight_group: 1..4 problems");
+    static_assert(sizeof(cffm_wgrad) == sizeof(GemmTN), "wgrad layout");
+    for (int i = 0; i < n; ++i) REQUIRE(problems[i].dy && problems[i].x && problems[i].dw, "linear_bwd_weight_group: null operand");
+    PROF(ST_GEMM);
+    if (gemm_tn_group((const GemmTN*)problems, n, (hipStream_t)stream)) return fail(-3, "linear_bwd_weight_group: gemm failed");
+    CHECK_LAUNCH("linear_bwd_weight_group");
+    return 0;
+}
+
 // q|k|v Linear feeding the CFM kernels: qkv16[M,768] (f16) = x w^T + b, q third times 32^-0.5 (cffm_transformer.py:374, :528)
 int cffm_linear_qkv_fwd(const float* x, const float* w, const float* b, void* qkv16, long M, void* stream) {
     REQUIRE(x && w && b && qkv16, "linear_qkv_fwd: null");
@@ -551,17 +561,14 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     float* dM = scratch + S.dM;
     float* dbiasT = scratch + S.dbiasT;
     // x2 = x1 + act W2^T + b2
-    TRY(cffm_linear_bwd_weight(dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID, stream));
     TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
     // act = gelu(hraw + b1); hraw = z2 W1^T
     TRY(cffm_gelu_bwd(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, stream));
-    TRY(cffm_linear_bwd_weight(dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dact, p->fc1_w, dz2, NP, CFFM_HID, CFFM_C, stream));
     // z2 = LN2(x1); x1 also feeds the residual
     TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1,
                              gr->fc2_b /* = colsum(dout) */, gr->proj_b /* = colsum(dx1) */, stream));
     // x1 = xt + ao Wp^T + bp
-    TRY(cffm_linear_bwd_weight(dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dx1, p->proj_w, dao, NP, CFFM_C, CFFM_C, stream));
     // attention
     TRY(cffm_attn_bwd(g, ws + L.qkv, key_src, q_dst, inv_ptr, inv_idx, ws + L.bias, ws + L.biasT, ws + L.ao, dao,
@@ -569,8 +576,14 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, stream));
     // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)
     TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
-    TRY(cffm_linear_bwd_weight(dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C, stream));
     TRY(cffm_linear_bwd_input(dqkv, p->qkv_w, dzall, NR, 768, CFFM_C, stream));
+    // the four weight gradients, deferred to here (their operands dout, dact, dx1, dqkv are all still intact; ln_pool_bwd
+    // below overwrites dout) and issued as one grouped launch
+    const cffm_wgrad wg[4] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C},
+                              {dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C},
+                              {dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID},
+                              {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
+    TRY(cffm_linear_bwd_weight_group(wg, 4, stream));
     // CFFA
     TRY(cffm_ln_pool_bwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1,
                          dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, gr->norm1_w, gr->norm1_b, dM, gr->pool_b, stream));

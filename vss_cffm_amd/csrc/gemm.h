@@ -86,6 +86,67 @@ static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int
     return gemm_split_launch<true, true>(dy, x, dw, N, K, (int)M, N, K, K, ksplit, st, nullptr, nullptr, big);
 }
 
+// ---- grouped weight gradients: dw_p[N_p,K_p] = dy_p[M_p,N_p]^T x_p[M_p,K_p], p < n <= 4, one launch (k_gemm_group_tt) --------
+struct GemmTN { const float* dy; const float* x; float* dw; long M; int N, K; };
+static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st) {
+    bool groupable = n >= 1 && n <= GEMM_GROUP_MAX;
+    for (int p = 0; p < n && groupable; ++p) groupable = pr[p].N % 128 == 0 && pr[p].K % 128 == 0 && pr[p].M >= 32;
+    if (!groupable) {
+        for (int p = 0; p < n; ++p)
+            if (gemm_tn_split(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st)) return -1;
+        return 0;
+    }
+    // one slice length for every problem: ~480 workgroups (two per CU are co-resident: 80 KB of LDS each)
+    long units = 0;
+    for (int p = 0; p < n; ++p) units += (long)(pr[p].N / 128) * (pr[p].K / 128) * ((pr[p].M + 31) / 32);
+    long ksteps = (units + 479) / 480;
+    if (ksteps < 4) ksteps = 4;
+    const int klen = (int)ksteps * 32;
+    GemmGroup G;
+    SumGroup Sg;
+    size_t part_floats = 0;
+    int ksplit[GEMM_GROUP_MAX];
+    for (int p = 0; p < n; ++p) {
+        ksplit[p] = (int)((pr[p].M + klen - 1) / klen);
+        if (ksplit[p] > 1) part_floats += (size_t)ksplit[p] * pr[p].N * pr[p].K;
+    }
+    float* part = part_floats ? lib_scratch(part_floats) : nullptr;
+    if (part_floats && !part) return -1;
+    int wg = 0, blk = 0, nsum = 0;
+    for (int p = 0; p < n; ++p) {
+        G.A[p] = pr[p].dy; G.B[p] = pr[p].x;
+        G.M[p] = pr[p].N; G.N[p] = pr[p].K; G.K[p] = (int)pr[p].M;
+        G.C[p] = pr[p].dw;
+        if (ksplit[p] > 1) {
+            G.C[p] = part;
+            Sg.part[nsum] = part; Sg.out[nsum] = pr[p].dw; Sg.n[nsum] = (long)pr[p].N * pr[p].K; Sg.nsplit[nsum] = ksplit[p];
+            blk += (int)((Sg.n[nsum] / 4 + 255) / 256);
+            Sg.blk_end[nsum] = blk;
+            ++nsum;
+            part += (size_t)ksplit[p] * pr[p].N * pr[p].K;
+        }
+        wg += (pr[p].N / 128) * (pr[p].K / 128) * ksplit[p];
+        G.wg_end[p] = wg;
+    }
+    for (int p = n; p < GEMM_GROUP_MAX; ++p) { G.A[p] = G.B[p] = nullptr; G.C[p] = nullptr; G.M[p] = G.N[p] = 128; G.K[p] = 0; G.wg_end[p] = wg; }
+    G.klen = klen; G.n = n;
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void*)k_gemm_group_tt, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS(128, 128, 32)) != hipSuccess)
+            return -1;
+        granted = true;
+    }
+#endif
+    CFFM_LAUNCH(k_gemm_group_tt, ((unsigned)wg), (256), GEMM_LDS(128, 128, 32), st, G);
+    if (nsum) {
+        Sg.cnt = nsum;
+        for (int q = nsum; q < 4; ++q) { Sg.part[q] = nullptr; Sg.out[q] = nullptr; Sg.n[q] = 0; Sg.nsplit[q] = 0; Sg.blk_end[q] = blk; }
+        CFFM_LAUNCH(k_sum_splits_group, ((unsigned)blk), (256), 0, st, Sg);
+    }
+    return 0;
+}
+
 #ifdef CFFM_EMU
 // TEST INFRASTRUCTURE (emulator build only): naive host loops standing in for rocBLAS.
 static int gemm_nt_lib(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t) {
@@ -162,4 +223,10 @@ static int gemm_nn(const float* dy, const float* w, float* dx, long M, int N, in
 }
 static int gemm_tn(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
     return gemm_use_lib() ? gemm_tn_lib(dy, x, dw, M, N, K, st) : gemm_tn_split(dy, x, dw, M, N, K, st);
+}
+static int gemm_tn_group(const GemmTN* pr, int n, hipStream_t st) {
+    if (!gemm_use_lib()) return gemm_tn_group_split(pr, n, st);
+    for (int p = 0; p < n; ++p)
+        if (gemm_tn_lib(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st)) return -1;
+    return 0;
 }

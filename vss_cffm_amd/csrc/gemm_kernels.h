@@ -233,23 +233,24 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
 // EPI: 0 plain (+bias) | 1 GELU: C = raw product (saved for backward), aux = gelu(raw + bias) | 2 residual: C = aux + raw + bias
 //      3 q|k|v: nothing in C; aux (h16 [M,N]) = f16(raw + bias), the q third (cols < 256) also times 32^-0.5 -- exactly the
 //        values the attention kernels used to form from the fp32 product, stored once at half the bytes
+// XCD-aware placement (speed only): workgroup b runs on XCD b % 8, each XCD with its own 4 MiB L2.  The 1-D grid is
+// re-numbered so that every XCD owns a CONTIGUOUS run of (k-slice, row panel, column tile) triples, column tile
+// fastest: the tiles that share an A row panel / a k-slice then hit the same L2 instead of eight different ones.
+__device__ __forceinline__ int xcd_linear_id() {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+}
+
+// One output tile (bx, by) of k-slice bz: the whole body of the GEMM kernels below.
 template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF>
-__global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                     int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
-                                                     const float* __restrict__ bias, float* __restrict__ aux) {
-    CFFM_DYN_SMEM(smem);
+__device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                          int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
+                                          const float* __restrict__ bias, float* __restrict__ aux, int bx, int by, int bz) {
     bf16* Ah = (bf16*)smem;
     bf16* Al = Ah + BM * GEMM_LD(BK);
     bf16* Bh = Al + BM * GEMM_LD(BK);
     bf16* Bl = Bh + BN * GEMM_LD(BK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
-    // XCD-aware placement (speed only): workgroup b runs on XCD b % 8, each XCD with its own 4 MiB L2.  The 1-D grid is
-    // re-numbered so that every XCD owns a CONTIGUOUS run of (k-slice, row panel, column tile) triples, column tile
-    // fastest: the tiles that share an A row panel / a k-slice then hit the same L2 instead of eight different ones.
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
-    const int bz = lin / (ntn * ntm), by = (lin / ntn) % ntm, bx = lin % ntn;
     const int n0 = bx * BN, m0 = by * BM;
     const int kbeg = bz * klen, kend = (kbeg + klen < K) ? kbeg + klen : K;
     constexpr int MT = BM / 32, NT = BN / 32;  // 16x16 tiles per wave along M and N (wave tile = BM/2 x BN/2)
@@ -413,4 +414,41 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
             }
         }
     }
+}
+
+template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF>
+__global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                     int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
+                                                     const float* __restrict__ bias, float* __restrict__ aux) {
+    CFFM_DYN_SMEM(smem);
+    const int lin = xcd_linear_id();
+    const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+    gemm_tile<BM, BN, BK, A_T, B_T, EPI, PF>(smem, A, B, C, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux, lin % ntn,
+                                             (lin / ntn) % ntm, lin / (ntn * ntm));
+}
+
+// Up to GEMM_GROUP_MAX independent weight-gradient GEMMs (dw = dy^T x, <T,T>, 128x128 tiles) in ONE launch.  The four of a
+// block (fc2, fc1, proj, qkv) have 4-16 output tiles each and a contraction of ~10^4 rows: launched one by one each needs
+// ~20 k-slices to occupy 256 CUs, i.e. 12 K-steps per workgroup between a prologue and a 64 KB partial-tile epilogue, and
+// its own partial-sum pass.  None of them feeds the backward chain, so they are deferred and share one grid: ~480
+// workgroups with one common slice length (2-3x longer), a third of the partial traffic and one summation launch.
+#define GEMM_GROUP_MAX 4
+struct GemmGroup {
+    const float* A[GEMM_GROUP_MAX];
+    const float* B[GEMM_GROUP_MAX];
+    float* C[GEMM_GROUP_MAX];          // partial outputs [ksplit][M][N] (or the output itself when ksplit == 1)
+    int M[GEMM_GROUP_MAX], N[GEMM_GROUP_MAX], K[GEMM_GROUP_MAX];
+    int wg_end[GEMM_GROUP_MAX];        // exclusive prefix of workgroups per problem (after XCD re-numbering)
+    int klen, n;
+};
+__global__ void __launch_bounds__(256) k_gemm_group_tt(GemmGroup G) {
+    CFFM_DYN_SMEM(smem);
+    int lin = xcd_linear_id(), p = 0;
+#pragma unroll
+    for (int q = 0; q < GEMM_GROUP_MAX - 1; ++q)
+        if (q + 1 < G.n && lin >= G.wg_end[q]) p = q + 1;
+    if (p > 0) lin -= G.wg_end[p - 1];
+    const int M = G.M[p], N = G.N[p], ntn = N / 128, ntm = M / 128;
+    gemm_tile<128, 128, 32, true, true, 0, 1>(smem, G.A[p], G.B[p], G.C[p], M, N, G.K[p], M, N, N, G.klen, (long)M * N, nullptr,
+                                              nullptr, lin % ntn, (lin / ntn) % ntm, lin / (ntn * ntm));
 }

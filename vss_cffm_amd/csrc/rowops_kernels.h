@@ -269,6 +269,32 @@ __global__ void __launch_bounds__(256) k_sum_splits(const float* __restrict__ pa
     ((f32x4*)out)[i] = a + b;
 }
 
+// the same for the outputs of a grouped weight-gradient launch (k_gemm_group_tt): one launch sums every problem's partials
+struct SumGroup {
+    const float* part[4];
+    float* out[4];
+    long n[4];          // floats per output (multiple of 4)
+    int nsplit[4];
+    int blk_end[4];     // exclusive prefix of 256-thread blocks per problem
+    int cnt;
+};
+__global__ void __launch_bounds__(256) k_sum_splits_group(SumGroup G) {
+    int blk = blockIdx.x, p = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q + 1 < G.cnt && blk >= G.blk_end[q]) p = q + 1;
+    if (p > 0) blk -= G.blk_end[p - 1];
+    const long i = (long)blk * 256 + threadIdx.x, n = G.n[p];
+    if (i * 4 >= n) return;
+    const float* part = G.part[p];
+    const int nsplit = G.nsplit[p];
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
+    int s = 0;
+    for (; s + 1 < nsplit; s += 2) { a += ((const f32x4*)(part + (long)s * n))[i]; b += ((const f32x4*)(part + (long)(s + 1) * n))[i]; }
+    if (s < nsplit) a += ((const f32x4*)(part + (long)s * n))[i];
+    ((f32x4*)G.out[p])[i] = a + b;
+}
+
 // q|k|v fp32 product -> f16 with the Linear bias and the q scale folded in (only used by the exact-fp32 library GEMM
 // path; the hand-written GEMM does this in its epilogue)
 __global__ void __launch_bounds__(256) k_qkv_to_f16(const float* __restrict__ raw, const float* __restrict__ bias, h16* __restrict__ out,
