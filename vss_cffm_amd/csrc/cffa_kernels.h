@@ -16,21 +16,43 @@
 // --------------------------------------------------------------------------- batched transpose
 // dst[n][c][r] = src[n][r][c]; src rows x cols, batch strides given (elements).
 // NCHW -> NHWC : rows = C, cols = H*W.   NHWC -> NCHW : rows = H*W, cols = C.
+// 64 x 64 tiles through LDS; 16-byte global accesses on both sides whenever the contiguous extents allow it (the layer's
+// shapes always do: 256 channels, H*W a multiple of 4 for the 60 x 60 grid); otherwise 4-byte accesses, same tile walk.
 __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, float* __restrict__ dst,
                                                     int rows, int cols, long src_bs, long dst_bs) {
-    __shared__ float tile[64][65];
+    __shared__ float tile[64][65];   // tile[c][r]; odd stride: the scalar LDS accesses below are at most 2-way conflicted
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const float* s = src + (long)blockIdx.z * src_bs;
     float* d = dst + (long)blockIdx.z * dst_bs;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int k = 0; k < 16; ++k) {
-        int r = r0 + ty + 4 * k, c = c0 + tx;
-        tile[ty + 4 * k][tx] = (r < rows && c < cols) ? s[(long)r * cols + c] : 0.f;
+    const int q = threadIdx.x & 15, p = threadIdx.x >> 4;
+    const bool vin = (cols % 4 == 0) && (src_bs % 4 == 0) && (((uintptr_t)src & 15) == 0);
+    const bool vout = (rows % 4 == 0) && (dst_bs % 4 == 0) && (((uintptr_t)dst & 15) == 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + p + 16 * k, c = c0 + 4 * q;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            if (vin && c + 3 < cols) v = *(const f32x4*)(s + (long)r * cols + c);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < cols) v[e] = s[(long)r * cols + c + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[4 * q + e][p + 16 * k] = v[e];
     }
     __syncthreads();
-    for (int k = 0; k < 16; ++k) {
-        int c = c0 + ty + 4 * k, r = r0 + tx;
-        if (r < rows && c < cols) d[(long)c * rows + r] = tile[tx][ty + 4 * k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cl = p + 16 * k, c = c0 + cl, r = r0 + 4 * q;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[cl][4 * q + e];
+        if (c < cols) {
+            if (vout && r + 3 < rows) *(f32x4*)(d + (long)c * rows + r) = v;
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (r + e < rows) d[(long)c * rows + r + e] = v[e];
+        }
     }
 }
 
@@ -57,7 +79,7 @@ __device__ __forceinline__ void cell_geom(int g, int& grp, int& u, int& v, int& 
 struct PoolW { const float* w[4]; };  // pool_layers.0, pool_layers_clips.{0,1,2} weights
 struct PoolWG { float* w[4]; };
 
-__global__ void __launch_bounds__(256) k_pool_matrix(PoolW pw, float* __restrict__ M) {
+__device__ __forceinline__ void pool_matrix_body(const PoolW& pw, float* __restrict__ M) {
     for (int e = threadIdx.x; e < CFFM_NCELL * CFFM_WA; e += 256) {
         const int g = e / CFFM_WA, i = e % CFFM_WA, py = i / 7, px = i % 7;
         int grp, u, v, wsg;
@@ -74,6 +96,8 @@ __global__ void __launch_bounds__(256) k_pool_matrix(PoolW pw, float* __restrict
         M[e] = m;
     }
 }
+
+__global__ void __launch_bounds__(256) k_pool_matrix(PoolW pw, float* __restrict__ M) { pool_matrix_body(pw, M); }
 
 // dW_pool[grp][k] = sum_{g in grp, i} dM[g][i] * dM[g][i]/dw.  One wave per weight (111 weights): lanes over
 // the 49 pixels, loop over the group's cells, wave reduction.

@@ -194,8 +194,58 @@ static void seg_add(RedSegs& r, int off, int width, float* out, int accumulate) 
     const int k = r.nseg++;
     r.off[k] = off; r.width[k] = width; r.out[k] = out; r.accumulate[k] = accumulate;
 }
+// Deferred second stages: inside a block backward (RedScope) the reductions are queued -- each with its own slice of a
+// library-owned record buffer -- and run as ONE launch at the end of the scope; outside a scope they launch at once.
+static float* g_red = nullptr;
+static size_t g_red_floats = 0;
+static struct { bool active; size_t bump; RedJobs jobs; } g_rq = {false, 0, {}};
+static void redq_flush(hipStream_t st) {
+    RedJobs& J = g_rq.jobs;
+    if (J.njob == 1) {
+        CFFM_LAUNCH(k_reduce_records, ((J.total[0] + 63) / 64), (1024), 0, st, J.part[0], J.nblk[0], J.stride[0], J.total[0], J.segs[0]);
+    } else if (J.njob > 1) {
+        CFFM_LAUNCH(k_reduce_records_multi, ((unsigned)J.blk_end[J.njob - 1]), (1024), 0, st, J);
+    }
+    J.njob = 0;
+}
+struct RedScope {
+    hipStream_t st;
+    explicit RedScope(hipStream_t s) : st(s) { g_rq.active = true; g_rq.bump = 0; g_rq.jobs.njob = 0; }
+    void finish() { redq_flush(st); g_rq.active = false; }
+    ~RedScope() { g_rq.active = false; g_rq.jobs.njob = 0; }
+};
+// block-partial record buffer of one reduction
+static float* red_scratch(size_t nfloats, hipStream_t st) {
+    if (!g_rq.active) return lib_scratch(nfloats);
+    nfloats = (nfloats + 63) / 64 * 64;
+    if (g_rq.bump + nfloats > g_red_floats) {
+        redq_flush(st);   // queued jobs read the old buffer
+        const size_t want = 2 * (g_rq.bump + nfloats);
+#ifdef CFFM_EMU
+        free(g_red);
+        g_red = (float*)malloc(want * sizeof(float));
+#else
+        if (g_red) { (void)hipDeviceSynchronize(); (void)hipFree(g_red); }
+        if (hipMalloc((void**)&g_red, want * sizeof(float)) != hipSuccess) g_red = nullptr;
+#endif
+        g_red_floats = g_red ? want : 0;
+        g_rq.bump = 0;
+        if (!g_red) return nullptr;
+    }
+    float* p = g_red + g_rq.bump;
+    g_rq.bump += nfloats;
+    return p;
+}
 static void reduce_records(const float* part, int nblk, int stride, int total, const RedSegs& segs, hipStream_t st) {
-    CFFM_LAUNCH(k_reduce_records, ((total + 63) / 64), (1024), 0, st, part, nblk, stride, total, segs);
+    if (!g_rq.active) {
+        CFFM_LAUNCH(k_reduce_records, ((total + 63) / 64), (1024), 0, st, part, nblk, stride, total, segs);
+        return;
+    }
+    RedJobs& J = g_rq.jobs;
+    if (J.njob == RED_MAXJOB) redq_flush(st);
+    const int j = J.njob++;
+    J.part[j] = part; J.nblk[j] = nblk; J.stride[j] = stride; J.total[j] = total; J.segs[j] = segs;
+    J.blk_end[j] = (j ? J.blk_end[j - 1] : 0) + (total + 63) / 64;
 }
 
 static unsigned ew_grid(long n4) {
@@ -254,7 +304,7 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
     PoolBG pb;
     for (int i = 0; i < 4; ++i) pb.b[i] = dpool_b[i];
     const int nblk = g->nW * 4 * g->B;
-    float* part = lib_scratch((size_t)nblk * LNP_REC);
+    float* part = red_scratch((size_t)nblk * LNP_REC, st);
     REQUIRE(part, "ln_pool_bwd: scratch allocation failed");
     CFFM_LAUNCH(k_ln_pool_bwd, (g->nW, 4, g->B), (256), 0, st, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma, beta, M, mean, rstd,
                 dzall, dres, dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, part);
@@ -394,7 +444,7 @@ int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
     REQUIRE(cols % 256 == 0, "colsum: cols must be a multiple of 256");
     int slices = (int)((rows + 31) / 32);
     if (slices > 256) slices = 256;
-    float* part = lib_scratch((size_t)slices * cols);
+    float* part = red_scratch((size_t)slices * cols, st);
     REQUIRE(part, "colsum: scratch allocation failed");
     CFFM_LAUNCH(k_colsum_partial, (cols / 256, slices), (256), 0, st, a, rows, cols, part);
     RedSegs segs;
@@ -422,7 +472,7 @@ int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, 
     hipStream_t st = (hipStream_t)stream;
     const int rpb = 32;
     const int nblk = (int)((nrows + rpb - 1) / rpb);
-    float* part = lib_scratch((size_t)nblk * 1024);
+    float* part = red_scratch((size_t)nblk * 1024, st);
     REQUIRE(part, "ln_bwd_residual: scratch allocation failed");
     CFFM_LAUNCH(k_ln_bwd_residual, (nblk), (256), 0, st, x1, mean, rstd, gamma, dz2, dres, dx1, part, nrows, rpb);
     RedSegs segs;
@@ -453,7 +503,7 @@ int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, in
     const int nblk = (int)((rows + rpb - 1) / rpb);
     float* part = nullptr;
     if (db1) {
-        part = lib_scratch((size_t)nblk * CFFM_HID);
+        part = red_scratch((size_t)nblk * CFFM_HID, st);
         REQUIRE(part, "gelu_bwd: scratch allocation failed");
     }
     CFFM_LAUNCH(k_gelu_bwd, (nblk), (256), 0, st, hraw, b1, dact, part, rows, rpb);
@@ -521,19 +571,49 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
 }
 
 // ------------------------------------------------------------------------------------------- block
+// bias tiles + pooling matrices of `n` blocks (workspaces ws0 + i*ws_stride) in ceil(n / PREP_MAXD) launches
+static int param_prep(const cffm_block_params* params, int n, float* ws0, long ws_stride, const cffm_block_ws& L, void* stream) {
+    PROF(ST_BIAS_ASM);
+    const int nb = (CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD + 255) / 256;
+    for (int d0 = 0; d0 < n; d0 += PREP_MAXD) {
+        const int nd = (n - d0 < PREP_MAXD) ? n - d0 : PREP_MAXD;
+        PrepArgs a;
+        for (int d = 0; d < PREP_MAXD; ++d) {
+            const cffm_block_params& p = params[d0 + (d < nd ? d : 0)];
+            float* ws = ws0 + (long)(d0 + (d < nd ? d : 0)) * ws_stride;
+            a.t[d].own = p.rpb_own; a.t[d].ring = p.rpb_ring;
+            for (int i = 0; i < 4; ++i) { a.t[d].pool[i] = p.rpb_pool[i]; a.pw[d].w[i] = p.pool_w[i]; }
+            a.bias[d] = ws + L.bias; a.biasT[d] = ws + L.biasT; a.M[d] = ws + L.M;
+        }
+        CFFM_LAUNCH(k_param_prep, (nb + 1, nd), (256), 0, (hipStream_t)stream, a);
+    }
+    CHECK_LAUNCH("param_prep");
+    return 0;
+}
+
+static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, const float* x_ref, long ref_bs,
+                              const float* x_tgt, long tgt_bs, const int* key_src, const int* q_dst, float* ws,
+                              float* scratch, void* stream);
 int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const float* x_ref, long ref_bs,
                        const float* x_tgt, long tgt_bs, const int* key_src, const int* q_dst, float* ws,
                        float* scratch, void* stream) {
     REQUIRE(g && p && ws && scratch, "block_forward: null");
     cffm_block_ws L;
     cffm_block_ws_layout(g, &L);
+    TRY(param_prep(p, 1, ws, 0, L, stream));
+    return block_forward_impl(g, p, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, ws, scratch, stream);
+}
+// the block after its parameter-only inputs (ws.bias, ws.biasT, ws.M) have been prepared
+static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, const float* x_ref, long ref_bs,
+                              const float* x_tgt, long tgt_bs, const int* key_src, const int* q_dst, float* ws,
+                              float* scratch, void* stream) {
+    cffm_block_ws L;
+    cffm_block_ws_layout(g, &L);
     const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
     float* yraw = scratch;  // [NP,256] transient (proj output, later fc2 output)
-    TRY(cffm_pool_matrix(p->pool_w, ws + L.M, stream));
     TRY(cffm_ln_pool_fwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
                          ws + L.mean1, ws + L.rstd1, stream));
     TRY(cffm_linear_qkv_fwd(ws + L.zall, p->qkv_w, p->qkv_b, ws + L.qkv, NR, stream));
-    TRY(cffm_bias_assemble(p->rpb_own, p->rpb_ring, p->rpb_pool, ws + L.bias, ws + L.biasT, stream));
     TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, ws + L.bias, ws + L.ao, ws + L.lse, stream));
     TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
     TRY(cffm_residual_ln(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
@@ -560,6 +640,7 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     float* dzall = scratch + S.dzall;
     float* dM = scratch + S.dM;
     float* dbiasT = scratch + S.dbiasT;
+    RedScope reductions((hipStream_t)stream);   // the four parameter-gradient reductions below run as one launch (finish())
     // x2 = x1 + act W2^T + b2
     TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
     // act = gelu(hraw + b1); hraw = z2 W1^T
@@ -587,6 +668,8 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     // CFFA
     TRY(cffm_ln_pool_bwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1,
                          dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, gr->norm1_w, gr->norm1_b, dM, gr->pool_b, stream));
+    reductions.finish();
+    CHECK_LAUNCH("block_backward reductions");
     TRY(cffm_pool_matrix_bwd(dM, gr->pool_w, stream));
     return 0;
 }
@@ -602,11 +685,12 @@ int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* p
     float* xs = saved;  // NHWC stack [B,4,HW,C]
     float* blk0 = saved + up((long)g->B * 4 * img);
     TRY(cffm_transpose(x_nchw, xs, g->B * 4, CFFM_C, (int)HW, img, img, stream));
+    TRY(param_prep(params, depth, blk0, L.total, L, stream));
     for (int i = 0; i < depth; ++i) {
         float* ws = blk0 + (long)i * L.total;
         const float* tgt = (i == 0) ? xs + 3 * img : blk0 + (long)(i - 1) * L.total + L.x2;
         const long tgt_bs = (i == 0) ? 4 * img : img;
-        TRY(cffm_block_forward(g, &params[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, ws, scratch, stream));
+        TRY(block_forward_impl(g, &params[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, ws, scratch, stream));
     }
     TRY(cffm_transpose(blk0 + (long)(depth - 1) * L.total + L.x2, y_tgt_nchw, g->B, (int)HW, CFFM_C, img, img, stream));
     return 0;

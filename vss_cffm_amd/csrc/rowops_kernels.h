@@ -7,6 +7,7 @@
 // One wave per 256-channel row (1 KiB coalesced f32x4 accesses), 4 rows per workgroup.
 #pragma once
 #include "cffm_common.h"
+#include "cffa_kernels.h"
 
 // --------------------------------------------------------------------------- position-bias tables
 struct BiasTables {
@@ -45,7 +46,7 @@ __device__ __forceinline__ int bias_locate(int h, int q, int n, int& off) {
 
 // bias [8][64][304] (query-major, for the S^T = K Q^T orientation) and biasT [8][304][64]
 // (key-major, for the S = Q K^T orientation of the backward); pad entries are 0.
-__global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __restrict__ bias, float* __restrict__ biasT) {
+__device__ __forceinline__ void bias_assemble_body(const BiasTables& t, float* __restrict__ bias, float* __restrict__ biasT) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD) return;
     const int n = e % CFFM_NKEY_PAD, q = (e / CFFM_NKEY_PAD) % CFFM_NQ_PAD, h = e / (CFFM_NKEY_PAD * CFFM_NQ_PAD);
@@ -57,6 +58,24 @@ __global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __re
     }
     bias[e] = v;
     if (biasT) biasT[((long)h * CFFM_NKEY_PAD + n) * CFFM_NQ_PAD + q] = v;
+}
+__global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __restrict__ bias, float* __restrict__ biasT) {
+    bias_assemble_body(t, bias, biasT);
+}
+// Everything a layer's blocks derive from parameters alone (dense bias tiles, composed pooling matrices), for up to
+// PREP_MAXD blocks in one launch: grid (bias workgroups + 1, blocks), the last workgroup of a row builds the pooling matrix.
+#define PREP_MAXD 4
+struct PrepArgs {
+    BiasTables t[PREP_MAXD];
+    PoolW pw[PREP_MAXD];
+    float* bias[PREP_MAXD];
+    float* biasT[PREP_MAXD];
+    float* M[PREP_MAXD];
+};
+__global__ void __launch_bounds__(256) k_param_prep(PrepArgs a) {
+    const int d = blockIdx.y;
+    if (blockIdx.x == gridDim.x - 1) pool_matrix_body(a.pw[d], a.M[d]);
+    else bias_assemble_body(a.t[d], a.bias[d], a.biasT[d]);
 }
 
 // dbiasT [8][304][64] (key-major, as the attention backward accumulates it) -> the six tables.
@@ -194,6 +213,50 @@ __global__ void __launch_bounds__(1024) k_reduce_records(const float* __restrict
     if (ry == 0 && c < total) {
         float v = 0.f;
         for (int k = 0; k < 16; ++k) v += red[k][cx];
+        for (int k = 0; k < segs.nseg; ++k)
+            if (c >= segs.off[k] && c < segs.off[k] + segs.width[k]) {
+                float* o = segs.out[k] + (c - segs.off[k]);
+                *o = segs.accumulate[k] ? *o + v : v;
+            }
+    }
+}
+
+// The same for up to RED_MAXJOB record sets in one launch: the block backward defers its four reductions (fc1 bias /
+// LN2 + fc2/proj bias / q|k|v bias / LN1 + pooling) to its end -- none of their results is read earlier.
+#define RED_MAXJOB 4
+struct RedJobs {
+    int njob;
+    int blk_end[RED_MAXJOB];        // exclusive prefix of 64-column workgroups per job
+    const float* part[RED_MAXJOB];
+    int nblk[RED_MAXJOB], stride[RED_MAXJOB], total[RED_MAXJOB];
+    RedSegs segs[RED_MAXJOB];
+};
+__global__ void __launch_bounds__(1024) k_reduce_records_multi(RedJobs J) {
+    __shared__ float red[16][64];
+    int blk = blockIdx.x, j = 0;
+#pragma unroll
+    for (int q = 0; q < RED_MAXJOB - 1; ++q)
+        if (q + 1 < J.njob && blk >= J.blk_end[q]) j = q + 1;
+    if (j > 0) blk -= J.blk_end[j - 1];
+    const float* __restrict__ part = J.part[j];
+    const int nblk = J.nblk[j], stride = J.stride[j], total = J.total[j];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blk * 64 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < total) {
+        int b = ry;
+        for (; b + 48 < nblk; b += 64) {
+            s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 16) * stride + c];
+            s2 += part[(long)(b + 32) * stride + c]; s3 += part[(long)(b + 48) * stride + c];
+        }
+        for (; b < nblk; b += 16) s0 += part[(long)b * stride + c];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && c < total) {
+        float v = 0.f;
+        for (int k = 0; k < 16; ++k) v += red[k][cx];
+        const RedSegs& segs = J.segs[j];
         for (int k = 0; k < segs.nseg; ++k)
             if (c >= segs.off[k] && c < segs.off[k] + segs.width[k]) {
                 float* o = segs.out[k] + (c - segs.off[k]);
