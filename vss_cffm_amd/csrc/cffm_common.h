@@ -137,6 +137,58 @@ __device__ __forceinline__ f32x4 mfma16x16x4_f32(float a, float b, f32x4 c) {
 #endif
 }
 
+// ---- raw buffer loads ------------------------------------------------------------------------------------------
+// A buffer resource carries the extent of an array: a load whose byte offset (per-lane VGPR part + uniform SGPR part) falls
+// outside returns zeros instead of faulting, so gathers with "no such row" entries need neither a branch nor 64-bit
+// address arithmetic -- the lane passes BUF_OOB as its offset.  (Range check: vgpr_offset >= num_records - sgpr_offset.)
+#define BUF_OOB 0xFFFFFFF0u
+#ifdef CFFM_EMU
+struct buf_t { const char* p; uint32_t n; };
+static inline buf_t buf_make(const void* p, uint32_t bytes) { return buf_t{(const char*)p, bytes}; }
+static inline void buf_ld_bytes(buf_t r, uint32_t voff, uint32_t soff, void* dst, int ndw) {
+    for (int e = 0; e < ndw; ++e) {
+        const uint64_t o = (uint64_t)voff + 4 * e;
+        uint32_t w = 0;
+        if (soff <= r.n && o + 4 <= (uint64_t)(r.n - soff)) __builtin_memcpy(&w, r.p + soff + o, 4);
+        __builtin_memcpy((char*)dst + 4 * e, &w, 4);
+    }
+}
+static inline f32x4 buf_ld16(buf_t r, uint32_t voff, uint32_t soff) {
+    float t[4];
+    buf_ld_bytes(r, voff, soff, t, 4);
+    return (f32x4){t[0], t[1], t[2], t[3]};
+}
+static inline float buf_ld4(buf_t r, uint32_t voff, uint32_t soff) {
+    float t;
+    buf_ld_bytes(r, voff, soff, &t, 1);
+    return t;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t buf_t;
+__device__ __forceinline__ buf_t buf_make(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld16(buf_t r, uint32_t voff, uint32_t soff) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    f32x4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+__device__ __forceinline__ float buf_ld4(buf_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+#endif
+// 8 stored halfs through a buffer resource (zeros when out of range)
+__device__ __forceinline__ f16x8 buf_ld_h8(buf_t r, uint32_t voff, uint32_t soff) {
+    const f32x4 raw = buf_ld16(r, voff, soff);
+    h16x8 v;
+    __builtin_memcpy(&v, &raw, 16);
+    f16x8 o;
+    for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+    return o;
+}
+
 // 8 stored halfs (16 B) -> 8 MFMA-operand elements (a no-op copy unless the emulator's fp32-operand switch is on)
 __device__ __forceinline__ f16x8 ld_h8(const h16* p) {
     const h16x8 v = *(const h16x8*)p;

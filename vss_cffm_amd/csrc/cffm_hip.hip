@@ -364,11 +364,14 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     PROF(ST_ATTN_BWD);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(g && qkv16 && biasT && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
-    hipMemsetAsync(dbiasT, 0, (size_t)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD * sizeof(float), st);
     int per;
     const int ng = attn_bwd_groups(g, &per);
+    const long nb = (long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD;   // one bias-gradient tile set per window group
+    float* dbp = lib_scratch((size_t)ng * nb);
+    REQUIRE(dbp, "attn_bwd: scratch allocation failed");
     CFFM_LAUNCH(k_cfm_attn_bwd_q, (CFFM_HEADS, ng), (256), ATT_BWQ_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias, ao, dao,
-                lse, dqkv, dbiasT, per);
+                lse, dqkv, dbp, per);
+    CFFM_LAUNCH(k_sum_splits, ((unsigned)((nb / 4 + 255) / 256)), (256), 0, st, (const float*)dbp, ng, nb, dbiasT);
     CFFM_LAUNCH(k_cfm_attn_bwd_kv, (g->B * g->nW * CFFM_HEADS), (256), ATT_BWK_LDS, st, to_geo(g), (const h16*)qkv16, key_src, q_dst,
                 biasT, ao, dao, lse, dkv_part);
     CFFM_LAUNCH(k_dkv_gather, ((g->RC + 3) / 4, g->B), (256), 0, st, to_geo(g), inv_ptr, inv_idx, (const float*)dkv_part, dqkv);
@@ -376,6 +379,9 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     return 0;
 }
 
+#ifdef BWQ_TIMING
+extern "C" int cffm_debug_bwq(long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwq_t), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#endif
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream) {
     PROF(ST_GEMM);
     return gemm_nt(x, w, y, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_fwd: gemm failed") : 0;

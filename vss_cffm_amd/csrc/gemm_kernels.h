@@ -19,14 +19,17 @@
 // rocBLAS SGEMM: 60-100 TF).  K-tile depth (BK 32 vs 64) and prefetch depth are neutral; the small-N layers do not
 // have enough output to give 256 CUs 128x128 tiles, hence their lower rate.
 // Tiles: BM x BN x 32 (BM, BN in {64,128})
-// per 256-thread workgroup (2x2 waves, each (BM/2) x (BN/2) as 16x16x32 MFMA tiles), LDS rows
-// padded to 80 B (conflict-free ds_read_b128 fragments), the next PF K-tiles in flight in registers while the
+// per 256-thread workgroup (2x2 waves, each (BM/2) x (BN/2) as 16x16x32 MFMA tiles), 64-byte LDS rows
+// with XOR-swizzled 16-byte chunks (conflict-free ds_read_b128 fragments: GEMM_SWZ), the next PF K-tiles in flight in registers while the
 // current one is multiplied.  The weight-gradient form splits its long contraction (M ~ 10^4) over
 // gridDim.z: every split writes its own partial output (plain coalesced stores) and a second tiny kernel sums
 // them -- deterministic, and row-coalesced fp32 atomics measured 3-4x slower than this on gfx950.
 #pragma once
 #include "cffm_common.h"
 
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0   // profiling builds only: 1 no global loads in the K-loop, 2 no split / LDS stores, 4 no MFMAs, 8 no fast path, 16 no split arithmetic
+#endif
 typedef __bf16 bf16;
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -56,6 +59,9 @@ __device__ __forceinline__ f32x4 mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) 
 }
 
 __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
+#if GEMM_ABLATE & 16
+    { float t[4] = {x[0], x[1], x[2], x[3]}; __builtin_memcpy(&hi, &t[0], 8); __builtin_memcpy(&lo, &t[2], 8); return; }
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         hi[e] = (bf16)x[e];
@@ -63,10 +69,13 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-#ifndef GEMM_ABLATE
-#define GEMM_ABLATE 0   // profiling builds only: 1 no global loads in the K-loop, 2 no split / LDS stores, 4 no MFMAs
-#endif
-#define GEMM_LD(BK) ((BK) + 8)  // bf16 per LDS row (BK + 8 pad: 80 / 144 B strides keep ds_read_b128 fragments conflict-free)
+// LDS image of a k-contiguous operand tile: 64-byte rows (32 bf16), NO padding, the four 16-byte chunks of a row stored at
+// chunk ^ 2*((row>>3)&1).  A ds_read_b128 is served in four groups of 16 lanes that are not contiguous ({0-3,12-15,20-27},
+// {4-11,16-19,28-31}, ...: MI355X_MICROARCH.md, LDS table): a group mixes 8 rows of k-chunk g with 8 rows of chunk g+1, so no
+// row padding can separate them (an 80-byte stride measured 45 % of all LDS cycles as bank conflicts: SQ_LDS_BANK_CONFLICT
+// / SQ_LDS_IDX_ACTIVE); with the XOR the 16 lanes of every group cover the 16 bank quads exactly once.
+#define GEMM_SWZ(row) (2 * (((row) >> 3) & 1))
+#define GEMM_IMG(ROWS, BK) (((ROWS) + 4) * (BK))   // bf16 per image: max of the two layouts ([ROWS][BK] | [BK/2][ROWS+4] dwords)
 #define GEMM_TLD 68 // floats per row of the epilogue transposition tile (64 + 4 pad)
 
 // LDS image of an operand tile (ROWS x 32 k), hi and lo parts:
@@ -112,36 +121,10 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& r, const float* __
     }
 }
 
-// Raw buffer loads for the K-loop's fast path: a buffer resource carries the operand's extent, so a tile row past the
-// matrix reads as zeros without a branch, and the address is one per-thread VGPR offset (fixed for the whole kernel) plus a
+// (buf_make / buf_ld16: raw buffer loads, cffm_common.h)  The K-loop's fast path uses them so that a tile row past the
+// matrix reads as zeros without a branch and the address is one per-thread VGPR offset (fixed for the whole kernel) plus a
 // scalar offset that walks the contraction -- no per-tile vector address arithmetic, no exec-mask branches between the
 // MFMAs (which would split the loop body into basic blocks and forbid interleaving the split with the multiplication).
-#ifdef CFFM_EMU
-struct buf_t { const char* p; uint32_t n; };
-static inline buf_t buf_make(const void* p, uint32_t bytes) { return buf_t{(const char*)p, bytes}; }
-static inline f32x4 buf_ld16(buf_t r, uint32_t voff, uint32_t soff) {
-    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t o = voff + soff + 4 * e;
-        float f = 0.f;
-        if (o + 4 <= r.n) __builtin_memcpy(&f, r.p + o, 4);
-        v[e] = f;
-    }
-    return v;
-}
-#else
-typedef __amdgpu_buffer_rsrc_t buf_t;
-__device__ __forceinline__ buf_t buf_make(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_ld16(buf_t r, uint32_t voff, uint32_t soff) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    f32x4 f;
-    __builtin_memcpy(&f, &v, 16);
-    return f;
-}
-#endif
 // this thread's fixed byte offset inside an operand tile (whole tiles: the same items as tile_load)
 template <int ROWS, bool TR, int BK>
 __device__ __forceinline__ uint32_t tile_voff(int ld, int tid) {
@@ -180,8 +163,9 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __
             bf16x4 h, l;
             split4(r.v[it], h, l);
             const int row = item / (BK / 4), kc = 4 * (item % (BK / 4));
-            *(bf16x4*)(hi + row * GEMM_LD(BK) + kc) = h;
-            *(bf16x4*)(lo + row * GEMM_LD(BK) + kc) = l;
+            const int o = row * BK + ((((kc >> 3) ^ GEMM_SWZ(row)) << 3) | (kc & 4));
+            *(bf16x4*)(hi + o) = h;
+            *(bf16x4*)(lo + o) = l;
         }
     } else {
 #pragma unroll
@@ -203,7 +187,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __
 // one MFMA operand fragment (8 k-slots of row `row`) out of an LDS image
 template <int ROWS, bool TR, int BK>
 __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int row, int g, int kk /* 0 or 32 */) {
-    if (!TR) return *(const bf16x8*)(img + row * GEMM_LD(BK) + kk + 8 * g);
+    if (!TR) return *(const bf16x8*)(img + row * BK + kk + 8 * (g ^ GEMM_SWZ(row)));
     u32x4 d;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) d[jj] = ((const uint32_t*)img)[(kk / 2 + 4 * g + jj) * GEMM_TS(ROWS) + row];
@@ -212,7 +196,7 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
     return f;
 }
 
-#define GEMM_LDS(BM, BN, BK) (((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 4) > (4 * 32 * GEMM_TLD * 4) ? ((2 * (BM) + 2 * (BN)) * GEMM_LD(BK) * 4) : (4 * 32 * GEMM_TLD * 4))
+#define GEMM_LDS(BM, BN, BK) (((2 * GEMM_IMG(BM, BK) + 2 * GEMM_IMG(BN, BK)) * 4) > (4 * 32 * GEMM_TLD * 4) ? ((2 * GEMM_IMG(BM, BK) + 2 * GEMM_IMG(BN, BK)) * 4) : (4 * 32 * GEMM_TLD * 4))
 
 // Scheduling hint for the pipelined K-loop body: issue the split's VALU work / LDS traffic between consecutive MFMAs
 // (a wave issues in order: without it the compiler emits the MFMAs back to back and the split as a phase of its own).
@@ -247,9 +231,9 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                                           int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                           const float* __restrict__ bias, float* __restrict__ aux, int bx, int by, int bz) {
     bf16* Ah = (bf16*)smem;
-    bf16* Al = Ah + BM * GEMM_LD(BK);
-    bf16* Bh = Al + BM * GEMM_LD(BK);
-    bf16* Bl = Bh + BN * GEMM_LD(BK);
+    bf16* Al = Ah + GEMM_IMG(BM, BK);
+    bf16* Bh = Al + GEMM_IMG(BM, BK);
+    bf16* Bl = Bh + GEMM_IMG(BN, BK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int n0 = bx * BN, m0 = by * BM;
     const int kbeg = bz * klen, kend = (kbeg + klen < K) ? kbeg + klen : K;
@@ -266,7 +250,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
     // VALU work and LDS writes issue in the shadow of the MFMAs instead of in a phase of their own -- and tiles
     // t+2 .. t+1+PF are in flight from L2 / HBM into registers (a K-step is far shorter than that latency, and
     // co-resident workgroups run in lockstep, so they cannot hide each other's waits).
-    constexpr int IMG = (2 * BM + 2 * BN) * GEMM_LD(BK);   // bf16 elements of one buffer (Ah | Al | Bh | Bl)
+    constexpr int IMG = 2 * GEMM_IMG(BM, BK) + 2 * GEMM_IMG(BN, BK);   // bf16 elements of one buffer (Ah | Al | Bh | Bl)
     TileRegs<BM, BK> ra[PF];
     TileRegs<BN, BK> rb[PF];
     const int NKT = (kend - kbeg + BK - 1) / BK;
