@@ -69,6 +69,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 #endif
 }
+// sum over each aligned group of 16 lanes (a DPP "row"), result in every lane of the group
+__device__ __forceinline__ float row16_sum(float v) {
+#ifdef CFFM_EMU
+    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+#else
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    return v;
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #ifdef CFFM_EMU
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));

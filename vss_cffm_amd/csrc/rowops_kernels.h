@@ -86,38 +86,47 @@ __global__ void __launch_bounds__(256) k_bias_scatter(const float* __restrict__ 
     if (e < n_ring) {  // dense ring table [1,8,49,132]: one-to-one
         const int n = e % 132, q = (e / 132) % 49, h = e / (132 * 49);
         g.ring[e] = dbiasT[((long)h * CFFM_NKEY_PAD + 49 + n) * CFFM_NQ_PAD + q];
-        return;
     }
-    int r = e - n_ring;
-    if (r < n_own) {  // own table [169,8]: idx = (qi-ki+6)*13 + (qj-kj+6)
+    if (blockIdx.x * 256 + 255 < n_ring) return;   // (whole workgroups only: the row sums below are wave-collective)
+    // shared tables: 16 lanes per entry (n_ring is a multiple of 16, so the groups are DPP rows), lane j takes the queries
+    // j, j+16, j+32, j+48 -- four independent loads instead of a 49-step serial loop -- and the row sum combines them
+    const int j = (e - n_ring) & 15;
+    int r = (e - n_ring) >> 4;
+    float acc = 0.f;
+    float* dst = nullptr;
+    if (e < n_ring) {
+        r = -1;       // ring lanes of the one mixed workgroup: no entry
+    } else if (r < n_own) {  // own table [169,8]: idx = (qi-ki+6)*13 + (qj-kj+6)
         const int h = r % CFFM_HEADS, idx = r / CFFM_HEADS, di = idx / 13 - 6, dj = idx % 13 - 6;
-        float acc = 0.f;
-        for (int q = 0; q < 49; ++q) {
-            const int ki = q / 7 - di, kj = q % 7 - dj;
-            if (ki >= 0 && ki < 7 && kj >= 0 && kj < 7) acc += dbiasT[((long)h * CFFM_NKEY_PAD + ki * 7 + kj) * CFFM_NQ_PAD + q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = j + 16 * u, ki = q / 7 - di, kj = q % 7 - dj;
+            if (q < 49 && ki >= 0 && ki < 7 && kj >= 0 && kj < 7) acc += dbiasT[((long)h * CFFM_NKEY_PAD + ki * 7 + kj) * CFFM_NQ_PAD + q];
         }
-        g.own[r] = acc;
-        return;
-    }
-    r -= n_own;
-    const int kks[4] = {5, 7, 5, 3}, bases[4] = {181, 206, 255, 280};
-    for (int t = 0; t < 4; ++t) {
-        const int kk = kks[t], side = 6 + kk, n_t = CFFM_HEADS * side * side;
-        if (r < n_t) {  // pooled tables [8, side*side]: idx = (qi-a+kk-1)*side + (qj-b+kk-1)
-            const int h = r / (side * side), idx = r % (side * side), di = idx / side - (kk - 1), dj = idx % side - (kk - 1);
-            float acc = 0.f;
-            for (int q = 0; q < 49; ++q) {
-                const int a = q / 7 - di, bb = q % 7 - dj;
-                if (a >= 0 && a < kk && bb >= 0 && bb < kk)
-                    acc += dbiasT[((long)h * CFFM_NKEY_PAD + bases[t] + a * kk + bb) * CFFM_NQ_PAD + q];
+        dst = g.own + r;
+    } else {
+        r -= n_own;
+        const int kks[4] = {5, 7, 5, 3}, bases[4] = {181, 206, 255, 280};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = kks[t], side = 6 + kk, n_t = CFFM_HEADS * side * side;
+            if (!dst && r >= 0 && r < n_t) {  // pooled tables [8, side*side]: idx = (qi-a+kk-1)*side + (qj-b+kk-1)
+                const int h = r / (side * side), idx = r % (side * side), di = idx / side - (kk - 1), dj = idx % side - (kk - 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = j + 16 * u, a = q / 7 - di, bb = q % 7 - dj;
+                    if (q < 49 && a >= 0 && a < kk && bb >= 0 && bb < kk)
+                        acc += dbiasT[((long)h * CFFM_NKEY_PAD + bases[t] + a * kk + bb) * CFFM_NQ_PAD + q];
+                }
+                dst = g.pool[t] + r;
             }
-            g.pool[t][r] = acc;
-            return;
+            r -= n_t;
         }
-        r -= n_t;
     }
+    acc = row16_sum(acc);   // every lane of the wave takes part (lanes past the last entry carry zeros)
+    if (dst && j == 0) *dst = acc;
 }
-#define BIAS_SCATTER_THREADS (CFFM_HEADS * 49 * 132 + 169 * CFFM_HEADS + CFFM_HEADS * (121 + 169 + 121 + 81))
+#define BIAS_SCATTER_THREADS (CFFM_HEADS * 49 * 132 + 16 * (169 * CFFM_HEADS + CFFM_HEADS * (121 + 169 + 121 + 81)))
 
 // --------------------------------------------------------------------------- x1 = xt + (yraw + bproj); z2 = LN2(x1)
 __global__ void __launch_bounds__(256) k_residual_ln(const float* __restrict__ xt, long xt_bs, int rows_per_batch,
