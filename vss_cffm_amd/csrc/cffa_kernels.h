@@ -151,6 +151,9 @@ __device__ __forceinline__ int frame_group(int frame) { return frame == 3 ? 0 : 
 // grid (nW, 4 frames, B), 256 threads.  x_ref [B,3,HW,C] (batch stride ref_bs), x_tgt [B,HW,C]
 // (batch stride tgt_bs), both NHWC.  Writes zall rows (target tokens incl. zero rows of padded
 // pixels; pooled rows incl. pool bias) and the per-pixel LayerNorm statistics.
+#ifndef LNPF_BATCH
+#define LNPF_BATCH 4
+#endif
 __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
                                                       const float* __restrict__ x_tgt, long tgt_bs,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -171,40 +174,43 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
     f32x4 acc[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the wave's 12-13 pixel rows (1 KiB each) are all requested before the first is consumed
-    f32x4 xr[13];
+    // the wave's 12-13 pixel rows (1 KiB each) go in batches of LNPF_BATCH, each batch requested before its first row is consumed
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        const int i = wave + 4 * k;
-        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
-        xr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (i < CFFM_WA && y < G.H0 && x < G.W0) xr[k] = *(const f32x4*)(xf + ((long)y * G.W0 + x) * CFFM_C + 4 * lane);
-    }
+    for (int k0 = 0; k0 < 13; k0 += LNPF_BATCH) {
+        f32x4 xr[LNPF_BATCH];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        const int i = wave + 4 * k;
-        if (i >= CFFM_WA) break;
-        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
-        const bool valid = (y < G.H0) && (x < G.W0);  // wave-uniform
-        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-            const long pix = (long)y * G.W0 + x;
-            const f32x4 xv = xr[k];
-            const float mu = wave_sum(xv[0] + xv[1] + xv[2] + xv[3]) * (1.f / CFFM_C);
-            const f32x4 d = xv - mu;
-            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / CFFM_C);
-            const float rs = 1.f / sqrtf(var + CFFM_LN_EPS);
-            z = d * rs * gm + bt;
-            if (lane == 0) {
-                mean_out[((long)b * 4 + frame) * G.HW + pix] = mu;
-                rstd_out[((long)b * 4 + frame) * G.HW + pix] = rs;
-            }
+        for (int kk = 0; kk < LNPF_BATCH; ++kk) {
+            const int i = wave + 4 * (k0 + kk);
+            const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+            xr[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k0 + kk < 13 && i < CFFM_WA && y < G.H0 && x < G.W0) xr[kk] = *(const f32x4*)(xf + ((long)y * G.W0 + x) * CFFM_C + 4 * lane);
         }
-        if (frame == 3) *(f32x4*)(zall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane) = z;
-        if (valid) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c)
-                if (c < ncell) acc[c] += sM[c * CFFM_WA + i] * z;
+        for (int kk = 0; kk < LNPF_BATCH; ++kk) {
+            const int i = wave + 4 * (k0 + kk);
+            if (k0 + kk >= 13 || i >= CFFM_WA) break;
+            const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+            const bool valid = (y < G.H0) && (x < G.W0);  // wave-uniform
+            f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                const long pix = (long)y * G.W0 + x;
+                const f32x4 xv = xr[kk];
+                const float mu = wave_sum(xv[0] + xv[1] + xv[2] + xv[3]) * (1.f / CFFM_C);
+                const f32x4 d = xv - mu;
+                const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / CFFM_C);
+                const float rs = 1.f / sqrtf(var + CFFM_LN_EPS);
+                z = d * rs * gm + bt;
+                if (lane == 0) {
+                    mean_out[((long)b * 4 + frame) * G.HW + pix] = mu;
+                    rstd_out[((long)b * 4 + frame) * G.HW + pix] = rs;
+                }
+            }
+            if (frame == 3) *(f32x4*)(zall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane) = z;
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c)
+                    if (c < ncell) acc[c] += sM[c * CFFM_WA + i] * z;
+            }
         }
     }
 #pragma unroll
@@ -225,98 +231,109 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
 // one partial record per workgroup, part[blk][LNP_REC] = dgamma[256] | dbeta[256] | dM[15*49] | dpool_bias[4]
 // (zeros outside this frame's cells); k_reduce_partials sums the records -- no contended atomics.
 #define LNP_REC (2 * CFFM_C + CFFM_NCELL * CFFM_WA + 4)
+#ifndef LNPB_BATCH
+#define LNPB_BATCH 4
+#endif
 #ifndef LNPB_ABLATE
 #define LNPB_ABLATE 0   // profiling builds only: 1 no dM reductions, 2 no LN reductions, 4 no dx stores
 #endif
-__global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
-                                                      const float* __restrict__ x_tgt, long tgt_bs,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ M, const float* __restrict__ mean_in,
-                                                      const float* __restrict__ rstd_in, const float* __restrict__ dzall,
-                                                      const float* __restrict__ dres,
-                                                      float* __restrict__ dx_ref, long dref_bs, int accum_ref,
-                                                      float* __restrict__ dx_tgt, long dtgt_bs, float* __restrict__ part) {
-    __shared__ float sM[9 * CFFM_WA];
-    __shared__ float sdP[9][CFFM_C];
-    __shared__ float sdM[9 * CFFM_WA];
+// body for a frame with NC pooled cells per window (1, 4 or 9: compile-time, so the per-cell loops unroll and their LDS
+// reads / wave reductions overlap instead of queueing behind each other)
+template <int NC>
+__device__ __forceinline__ void ln_pool_bwd_body(const Geo& G, const float* __restrict__ xf, float* __restrict__ dxf, bool accum,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 const float* __restrict__ M, const float* __restrict__ mean_in,
+                                                 const float* __restrict__ rstd_in, const float* __restrict__ dzall,
+                                                 const float* __restrict__ dres, float* __restrict__ part, int g0, int w, int frame, int b) {
+    __shared__ float sM[NC * CFFM_WA];
+    __shared__ float sdP[NC][CFFM_C];
+    __shared__ float sdM[NC * CFFM_WA];
     __shared__ float red[4][2][CFFM_C];
     __shared__ float sbs[4];
-    const int w = blockIdx.x, frame = blockIdx.y, b = blockIdx.z;
     const int wy = w / G.gx, wx = w % G.gx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int g0, ncell;
-    frame_cells(frame, g0, ncell);
-    for (int e = threadIdx.x; e < ncell * CFFM_WA; e += 256) { sM[e] = M[g0 * CFFM_WA + e]; sdM[e] = 0.f; }
+    for (int e = threadIdx.x; e < NC * CFFM_WA; e += 256) { sM[e] = M[g0 * CFFM_WA + e]; sdM[e] = 0.f; }
     float bsum = 0.f;
-    for (int c = 0; c < ncell; ++c) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
         const float v = dzall[((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + threadIdx.x];
         sdP[c][threadIdx.x] = v;
         bsum += v;
     }
     bsum = wave_sum(bsum);
     if (lane == 0) sbs[wave] = bsum;
-    __syncthreads();
-    const float* xf = (frame == 3) ? x_tgt + (long)b * tgt_bs : x_ref + (long)b * ref_bs + (long)frame * G.HW * CFFM_C;
-    float* dxf = (frame == 3) ? dx_tgt + (long)b * dtgt_bs : dx_ref + (long)b * dref_bs + (long)frame * G.HW * CFFM_C;
-    const bool accum = (frame == 3) ? false : (accum_ref != 0);
     const f32x4 gm = *(const f32x4*)(gamma + 4 * lane), bt = *(const f32x4*)(beta + 4 * lane);
     f32x4 ag = (f32x4){0.f, 0.f, 0.f, 0.f}, ab = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // all global reads of the wave's 12-13 pixels (x rows, LN statistics, target-token gradients) are requested first
-    f32x4 xr[13], dzr[13];
-    float mur[13], rsr[13];
+    // The wave's 12-13 pixels go in batches of LNPB_BATCH = 4 (measured: 13 at once 47 us, 7: 42, 5: 34, 4: 30.5, 3: 30.8).  ALL global reads of a batch are requested before its first pixel
+    // is consumed: x rows, LN statistics, the target-token gradients, and the row that is added to the result (the
+    // residual-path gradient of the target frame, or the dx a later block already accumulated for a reference frame).
+    // Read inside the pixel loop that last row would sit between stores to the same array, where the compiler cannot hoist
+    // it -- one exposed memory round trip per pixel.  Small batches keep the kernel at three workgroups per CU.
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        const int i = wave + 4 * k;
-        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
-        xr[k] = dzr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mur[k] = rsr[k] = 0.f;
-        if (i < CFFM_WA && y < G.H0 && x < G.W0) {
-            const long pix = (long)y * G.W0 + x;
-            xr[k] = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
-            mur[k] = mean_in[((long)b * 4 + frame) * G.HW + pix];
-            rsr[k] = rstd_in[((long)b * 4 + frame) * G.HW + pix];
-            if (frame == 3) {
-                dzr[k] = *(const f32x4*)(dzall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane);
+    for (int k0 = 0; k0 < 13; k0 += LNPB_BATCH) {
+        f32x4 xr[LNPB_BATCH], dzr[LNPB_BATCH], addr[LNPB_BATCH];
+        float mur[LNPB_BATCH], rsr[LNPB_BATCH];
+#pragma unroll
+        for (int kk = 0; kk < LNPB_BATCH; ++kk) {
+            const int i = wave + 4 * (k0 + kk);
+            const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+            xr[kk] = dzr[kk] = addr[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mur[kk] = rsr[kk] = 0.f;
+            if (k0 + kk < 13 && i < CFFM_WA && y < G.H0 && x < G.W0) {
+                const long pix = (long)y * G.W0 + x;
+                xr[kk] = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
+                mur[kk] = mean_in[((long)b * 4 + frame) * G.HW + pix];
+                rsr[kk] = rstd_in[((long)b * 4 + frame) * G.HW + pix];
+                if (frame == 3) {
+                    dzr[kk] = *(const f32x4*)(dzall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane);
+                    if (dres) addr[kk] = *(const f32x4*)(dres + ((long)b * G.HW + pix) * CFFM_C + 4 * lane);
+                } else if (accum) {
+                    addr[kk] = *(const f32x4*)(dxf + pix * CFFM_C + 4 * lane);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        const int i = wave + 4 * k;
-        if (i >= CFFM_WA) break;
-        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
-        if (!((y < G.H0) && (x < G.W0))) continue;  // padded pixel: z is the constant 0
-        const long pix = (long)y * G.W0 + x;
-        const float rs = rsr[k];
-        const f32x4 xh = (xr[k] - mur[k]) * rs;
-        const f32x4 z = xh * gm + bt;
-        f32x4 dz = dzr[k];
-        for (int c = 0; c < ncell; ++c) {
-            const f32x4 dp = *(const f32x4*)(&sdP[c][4 * lane]);
-            dz += sM[c * CFFM_WA + i] * dp;
+        for (int kk = 0; kk < LNPB_BATCH; ++kk) {
+            const int i = wave + 4 * (k0 + kk);
+            if (k0 + kk >= 13 || i >= CFFM_WA) break;
+            const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+            if (!((y < G.H0) && (x < G.W0))) continue;  // padded pixel: z is the constant 0
+            const long pix = (long)y * G.W0 + x;
+            const float rs = rsr[kk];
+            const f32x4 xh = (xr[kk] - mur[kk]) * rs;
+            const f32x4 z = xh * gm + bt;
+            f32x4 dz = dzr[kk];
+            float dm[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 dp = *(const f32x4*)(&sdP[c][4 * lane]);
+                dz += sM[c * CFFM_WA + i] * dp;
+                dm[c] = dp[0] * z[0] + dp[1] * z[1] + dp[2] * z[2] + dp[3] * z[3];
+            }
 #if !(LNPB_ABLATE & 1)
-            const float dm = wave_sum(dp[0] * z[0] + dp[1] * z[1] + dp[2] * z[2] + dp[3] * z[3]);
-            if (lane == 0) sdM[c * CFFM_WA + i] = dm;
-#endif  // pixel i belongs to exactly one wave: no conflict
-        }
-        ag += dz * xh;
-        ab += dz;
-        const f32x4 gz = dz * gm;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dm[c] = wave_sum(dm[c]);   // independent chains: they overlap
+            if (lane == 0)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) sdM[c * CFFM_WA + i] = dm[c];   // pixel i belongs to exactly one wave: no conflict
+#endif
+            ag += dz * xh;
+            ab += dz;
+            const f32x4 gz = dz * gm;
 #if LNPB_ABLATE & 2
-        const float m1 = gz[0], m2 = gz[1];
+            const float m1 = gz[0], m2 = gz[1];
 #else
-        const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
-        const float m2 = wave_sum(gz[0] * xh[0] + gz[1] * xh[1] + gz[2] * xh[2] + gz[3] * xh[3]) * (1.f / CFFM_C);
+            const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
+            const float m2 = wave_sum(gz[0] * xh[0] + gz[1] * xh[1] + gz[2] * xh[2] + gz[3] * xh[3]) * (1.f / CFFM_C);
 #endif
-        f32x4 dx = (gz - m1 - xh * m2) * rs;
-        if (frame == 3 && dres) dx += *(const f32x4*)(dres + ((long)b * G.HW + pix) * CFFM_C + 4 * lane);
-        float* dst = dxf + pix * CFFM_C + 4 * lane;
+            const f32x4 dx = (gz - m1 - xh * m2) * rs + addr[kk];
 #if LNPB_ABLATE & 4
-        ag += dx;
+            ag += dx;
 #else
-        if (accum) dx += *(const f32x4*)dst;
-        *(f32x4*)dst = dx;
+            *(f32x4*)(dxf + pix * CFFM_C + 4 * lane) = dx;
 #endif
+        }
     }
     *(f32x4*)(&red[wave][0][4 * lane]) = ag;
     *(f32x4*)(&red[wave][1][4 * lane]) = ab;
@@ -328,11 +345,29 @@ __global__ void __launch_bounds__(256) k_ln_pool_bwd(Geo G, const float* __restr
     for (int e = threadIdx.x; e < CFFM_NCELL * CFFM_WA + 4; e += 256) {
         float v = 0.f;
         if (e < CFFM_NCELL * CFFM_WA) {
-            if (e >= g0 * CFFM_WA && e < (g0 + ncell) * CFFM_WA) v = sdM[e - g0 * CFFM_WA];
+            if (e >= g0 * CFFM_WA && e < (g0 + NC) * CFFM_WA) v = sdM[e - g0 * CFFM_WA];
         } else if (e - CFFM_NCELL * CFFM_WA == frame_group(frame)) {
             v = sbs[0] + sbs[1] + sbs[2] + sbs[3];
         }
         rec[2 * CFFM_C + e] = v;
     }
+}
+__global__ void __launch_bounds__(256, 3) k_ln_pool_bwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
+                                                      const float* __restrict__ x_tgt, long tgt_bs,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ M, const float* __restrict__ mean_in,
+                                                      const float* __restrict__ rstd_in, const float* __restrict__ dzall,
+                                                      const float* __restrict__ dres,
+                                                      float* __restrict__ dx_ref, long dref_bs, int accum_ref,
+                                                      float* __restrict__ dx_tgt, long dtgt_bs, float* __restrict__ part) {
+    const int w = blockIdx.x, frame = blockIdx.y, b = blockIdx.z;
+    int g0, ncell;
+    frame_cells(frame, g0, ncell);
+    const float* xf = (frame == 3) ? x_tgt + (long)b * tgt_bs : x_ref + (long)b * ref_bs + (long)frame * G.HW * CFFM_C;
+    float* dxf = (frame == 3) ? dx_tgt + (long)b * dtgt_bs : dx_ref + (long)b * dref_bs + (long)frame * G.HW * CFFM_C;
+    const bool accum = (frame == 3) ? false : (accum_ref != 0);
+    if (ncell == 1) ln_pool_bwd_body<1>(G, xf, dxf, accum, gamma, beta, M, mean_in, rstd_in, dzall, dres, part, g0, w, frame, b);
+    else if (ncell == 4) ln_pool_bwd_body<4>(G, xf, dxf, accum, gamma, beta, M, mean_in, rstd_in, dzall, dres, part, g0, w, frame, b);
+    else ln_pool_bwd_body<9>(G, xf, dxf, accum, gamma, beta, M, mean_in, rstd_in, dzall, dres, part, g0, w, frame, b);
 }
 
