@@ -448,11 +448,10 @@ int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
     PROF(ST_COLSUM);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(cols % 256 == 0, "colsum: cols must be a multiple of 256");
-    int slices = (int)((rows + 31) / 32);
-    if (slices > 256) slices = 256;
+    const int slices = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
     float* part = red_scratch((size_t)slices * cols, st);
     REQUIRE(part, "colsum: scratch allocation failed");
-    CFFM_LAUNCH(k_colsum_partial, (cols / 256, slices), (256), 0, st, a, rows, cols, part);
+    CFFM_LAUNCH(k_colsum_partial, (slices), (256), 0, st, a, rows, cols, part);
     RedSegs segs;
     segs.nseg = 0;
     seg_add(segs, 0, cols, out, 0);
@@ -476,7 +475,7 @@ int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, 
                          float* dres_colsum, float* dx1_colsum, void* stream) {
     PROF(ST_LN_BWD);
     hipStream_t st = (hipStream_t)stream;
-    const int rpb = 32;
+    const int rpb = LNB_ROWS;
     const int nblk = (int)((nrows + rpb - 1) / rpb);
     float* part = red_scratch((size_t)nblk * 1024, st);
     REQUIRE(part, "ln_bwd_residual: scratch allocation failed");
@@ -505,7 +504,7 @@ int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, in
     PROF(ST_GELU_BWD);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(cols == CFFM_HID, "gelu_bwd: cols must be %d", CFFM_HID);
-    const int rpb = 16;
+    const int rpb = GELU_BWD_ROWS;
     const int nblk = (int)((rows + rpb - 1) / rpb);
     float* part = nullptr;
     if (db1) {

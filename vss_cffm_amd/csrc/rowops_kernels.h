@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(256) k_residual_ln(const float* __restrict__ x
 // backward of z2 = LN(x1): dx1 = dres + LNbwd(dz2).  Every workgroup writes one partial record
 // part[blk][1024] = dgamma | dbeta | colsum(dres) | colsum(dx1) (the last two are the fc2 / proj bias
 // gradients, folded in because this kernel streams those rows anyway); k_reduce_partials sums them.
+#define LNB_ROWS 16   // rows per workgroup of k_ln_bwd_residual (4 per wave)
 __global__ void __launch_bounds__(256) k_ln_bwd_residual(const float* __restrict__ x1, const float* __restrict__ mean_in,
                                                           const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                           const float* __restrict__ dz2, const float* __restrict__ dres,
@@ -163,23 +164,38 @@ __global__ void __launch_bounds__(256) k_ln_bwd_residual(const float* __restrict
     const f32x4 gm = *(const f32x4*)(gamma + 4 * lane);
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 ag = z4, ab = z4, ar = z4, ax = z4;
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    for (long row = r0 + wave; row < r0 + rows_per_block && row < nrows; row += 4) {
-        const f32x4 xv = *(const f32x4*)(x1 + row * CFFM_C + 4 * lane);
-        const float mu = mean_in[row], rs = rstd_in[row];
-        const f32x4 xh = (xv - mu) * rs;
-        const f32x4 dz = *(const f32x4*)(dz2 + row * CFFM_C + 4 * lane);
+    const long r0 = (long)blockIdx.x * LNB_ROWS;
+    // the wave's LNB_ROWS / 4 rows are all requested before the first is consumed (rows r0 + wave + 4 k)
+    constexpr int RW = LNB_ROWS / 4;
+    f32x4 xr[RW], dzr[RW], drr[RW];
+    float mur[RW], rsr[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        const long row = r0 + wave + 4 * k;
+        xr[k] = dzr[k] = drr[k] = z4;
+        mur[k] = rsr[k] = 0.f;
+        if (row < nrows) {
+            xr[k] = *(const f32x4*)(x1 + row * CFFM_C + 4 * lane);
+            dzr[k] = *(const f32x4*)(dz2 + row * CFFM_C + 4 * lane);
+            if (dres) drr[k] = *(const f32x4*)(dres + row * CFFM_C + 4 * lane);
+            mur[k] = mean_in[row];
+            rsr[k] = rstd_in[row];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        const long row = r0 + wave + 4 * k;
+        if (row >= nrows) break;
+        const float rs = rsr[k];
+        const f32x4 xh = (xr[k] - mur[k]) * rs;
+        const f32x4 dz = dzr[k];
         ag += dz * xh;
         ab += dz;
         const f32x4 gz = dz * gm;
         const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
         const float m2 = wave_sum(gz[0] * xh[0] + gz[1] * xh[1] + gz[2] * xh[2] + gz[3] * xh[3]) * (1.f / CFFM_C);
-        f32x4 dxv = (gz - m1 - xh * m2) * rs;
-        if (dres) {
-            const f32x4 dr = *(const f32x4*)(dres + row * CFFM_C + 4 * lane);
-            ar += dr;
-            dxv += dr;
-        }
+        const f32x4 dxv = (gz - m1 - xh * m2) * rs + drr[k];
+        ar += drr[k];
         ax += dxv;
         *(f32x4*)(dx1 + row * CFFM_C + 4 * lane) = dxv;
     }
@@ -211,6 +227,13 @@ __global__ void __launch_bounds__(1024) k_reduce_records(const float* __restrict
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < total) {
         int b = ry;
+        for (; b + 112 < nblk; b += 128) {   // 8 independent loads in flight per lane
+            const float v0 = part[(long)b * stride + c], v1 = part[(long)(b + 16) * stride + c];
+            const float v2 = part[(long)(b + 32) * stride + c], v3 = part[(long)(b + 48) * stride + c];
+            const float v4 = part[(long)(b + 64) * stride + c], v5 = part[(long)(b + 80) * stride + c];
+            const float v6 = part[(long)(b + 96) * stride + c], v7 = part[(long)(b + 112) * stride + c];
+            s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+        }
         for (; b + 48 < nblk; b += 64) {
             s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 16) * stride + c];
             s2 += part[(long)(b + 32) * stride + c]; s3 += part[(long)(b + 48) * stride + c];
@@ -254,6 +277,13 @@ __global__ void __launch_bounds__(1024) k_reduce_records_multi(RedJobs J) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < total) {
         int b = ry;
+        for (; b + 112 < nblk; b += 128) {   // 8 independent loads in flight per lane
+            const float v0 = part[(long)b * stride + c], v1 = part[(long)(b + 16) * stride + c];
+            const float v2 = part[(long)(b + 32) * stride + c], v3 = part[(long)(b + 48) * stride + c];
+            const float v4 = part[(long)(b + 64) * stride + c], v5 = part[(long)(b + 80) * stride + c];
+            const float v6 = part[(long)(b + 96) * stride + c], v7 = part[(long)(b + 112) * stride + c];
+            s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+        }
         for (; b + 48 < nblk; b += 64) {
             s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 16) * stride + c];
             s2 += part[(long)(b + 32) * stride + c]; s3 += part[(long)(b + 48) * stride + c];
@@ -286,19 +316,36 @@ __global__ void __launch_bounds__(256) k_bias_gelu(const float* __restrict__ hra
 }
 // dhraw = dact * gelu'(hraw + b1) (in place on dact); thread t owns columns 4t..4t+3 of the 1024, a workgroup
 // owns `rows_per_block` rows and writes colsum partials part[blk][1024] (fc1 bias gradient) when part != NULL.
-__global__ void __launch_bounds__(256) k_gelu_bwd(const float* __restrict__ hraw, const float* __restrict__ b1,
-                                                   float* __restrict__ dact, float* __restrict__ part, long nrows,
-                                                   int rows_per_block) {
+#define GELU_BWD_ROWS 16   // rows per workgroup (rows_per_block of the launch must equal it), read in batches of 4
+__global__ void __launch_bounds__(256, 4) k_gelu_bwd(const float* __restrict__ hraw, const float* __restrict__ b1,
+                                                      float* __restrict__ dact, float* __restrict__ part, long nrows,
+                                                      int rows_per_block) {
     const int t = threadIdx.x;
     const f32x4 bb = ((const f32x4*)b1)[t];
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    for (long row = r0; row < r0 + rows_per_block && row < nrows; ++row) {
-        const f32x4 v = ((const f32x4*)(hraw + row * CFFM_HID))[t] + bb;
-        f32x4 d = ((f32x4*)(dact + row * CFFM_HID))[t];
-        d[0] *= gelu_erf_grad(v[0]); d[1] *= gelu_erf_grad(v[1]); d[2] *= gelu_erf_grad(v[2]); d[3] *= gelu_erf_grad(v[3]);
-        ((f32x4*)(dact + row * CFFM_HID))[t] = d;
-        acc += d;
+    // dact is updated in place: a load issued after a store to the same array cannot be hoisted by the compiler, so the
+    // rows go in batches of 4, every row of a batch read before the first is written (8 independent 16-byte loads per lane);
+    // the ~75 registers leave six waves per SIMD to cover the batch boundaries
+    for (long r0 = (long)blockIdx.x * GELU_BWD_ROWS; r0 < (long)(blockIdx.x + 1) * GELU_BWD_ROWS && r0 < nrows; r0 += 4) {
+        f32x4 v[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = d[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r0 + k < nrows) {
+                v[k] = ((const f32x4*)(hraw + (r0 + k) * CFFM_HID))[t];
+                d[k] = ((const f32x4*)(dact + (r0 + k) * CFFM_HID))[t];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r0 + k >= nrows) break;
+            const f32x4 x = v[k] + bb;
+            f32x4 o = d[k];
+            o[0] *= gelu_erf_grad(x[0]); o[1] *= gelu_erf_grad(x[1]); o[2] *= gelu_erf_grad(x[2]); o[3] *= gelu_erf_grad(x[3]);
+            ((f32x4*)(dact + (r0 + k) * CFFM_HID))[t] = o;
+            acc += o;
+            sched_fence();   // one row's arithmetic at a time: keeps the register count low
+        }
     }
     if (part) ((f32x4*)(part + (long)blockIdx.x * CFFM_HID))[t] = acc;
 }
@@ -312,16 +359,21 @@ __global__ void __launch_bounds__(256) k_residual_out(const float* __restrict__ 
 
 // --------------------------------------------------------------------------- column sums (Linear bias grads)
 // part[slice][c] = sum over the slice's rows of a[r][c]; grid (ncol/256, nslices); k_reduce_partials finishes.
+#define COLSUM_ROWS 32   // rows per workgroup
 __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict__ a, long nrows, int ncol, float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const long per = (nrows + gridDim.y - 1) / gridDim.y;
-    const long r0 = (long)blockIdx.y * per, r1 = (r0 + per < nrows) ? r0 + per : nrows;
-    if (c >= ncol) return;
-    float s0 = 0.f, s1 = 0.f;
-    long r = r0;
-    for (; r + 1 < r1; r += 2) { s0 += a[r * ncol + c]; s1 += a[(r + 1) * ncol + c]; }
-    if (r < r1) s0 += a[r * ncol + c];
-    part[(long)blockIdx.y * ncol + c] = s0 + s1;
+    // a workgroup owns COLSUM_ROWS rows and every column: thread t sums the 4 columns 4t.. (16-byte loads, 8 rows in flight)
+    const long r0 = (long)blockIdx.x * COLSUM_ROWS;
+    for (int c4 = threadIdx.x; c4 < ncol / 4; c4 += 256) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k0 = 0; k0 < COLSUM_ROWS; k0 += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (r0 + k0 + k < nrows) ? ((const f32x4*)(a + (r0 + k0 + k) * ncol))[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        ((f32x4*)(part + (long)blockIdx.x * ncol))[c4] = acc;
+    }
 }
 
 // a += b (f32x4)
