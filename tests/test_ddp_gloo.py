@@ -47,9 +47,20 @@ def _worker(rank, world, port, out):
         x, g = _clip(rank)
         y = model(x)
         (y[:, -1] * g).sum().backward()
-    grads = {k: p.grad.clone() for k, p in model.module.named_parameters()}
-    assert all(v is not None for v in grads.values())
+        grads = {k: p.grad.clone() for k, p in model.module.named_parameters()}
+        assert all(v is not None for v in grads.values())
+        # the step of bench.py: this package's one-launch AdamW on gradients that are views into DDP's buckets
+        import vss_cffm_amd as V
+        before = {k: p.detach().clone() for k, p in model.module.named_parameters()}
+        V.optim.AdamW(model.module.parameters(), lr=1e-3, weight_decay=0.01).step()
+        ref = [torch.nn.Parameter(before[k].clone()) for k in before]
+        for q, k in zip(ref, before):
+            q.grad = grads[k].clone()
+        torch.optim.AdamW(ref, lr=1e-3, weight_decay=0.01).step()
+        for q, (k, p) in zip(ref, model.module.named_parameters()):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-7, msg=k)
     torch.save(grads, os.path.join(out, 'rank%d.pt' % rank))
+    torch.save({k: p.detach().clone() for k, p in model.module.named_parameters()}, os.path.join(out, 'param%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,8 +70,10 @@ def test_ddp_world_size_2_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     g0, g1 = (torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r)) for r in range(world))
+    p0, p1 = (torch.load(os.path.join(str(tmp_path), 'param%d.pt' % r)) for r in range(world))
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k            # all-reduced: identical on both ranks
+        assert torch.equal(p0[k], p1[k]), k            # ... and so are the updated parameters
     # single-process reference: mean of the two ranks' own gradients
     from tests import emu, helpers as H
     per_rank = []
