@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
     // is 64 B of f16 = four 16-byte chunks c4.
     const int qcol = 16 * wave + (lane & 15), g = lane >> 4;
     const int c4 = lane >> 4;
+    const int qdst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;   // needed only by the epilogue: requested with the first batch
     int src0[3], src1[3];
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
@@ -168,8 +169,8 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 
     // ---- epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821) ------------
     if (g == 0) lse_out[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol] = (qcol < CFFM_WA) ? m + logf(l) : 0.f;
-    if (qcol < CFFM_WA) {
-        const int dst = q_dst[w * CFFM_WA + qcol];
+    {
+        const int dst = qdst;
         if (dst >= 0) {
             const float inv = 1.f / l;
             float* orow = ao + ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 4 * g;
@@ -193,6 +194,9 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 // dO is rescaled by a power of two (per wave / per window) so every f16 gradient operand sits near 1 (training-size gradients
 // of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
 // =====================================================================================================
+#ifndef BWK_ABLATE
+#define BWK_ABLATE 0   // profiling builds only: 1 staging only (no key-tile loop), 2 no partial-row stores
+#endif
 #ifndef BWQ_ABLATE
 #define BWQ_ABLATE 0   // profiling builds only: 1 no dB flush, 2 no exp, 4 no dQ product, 8 no dP product
 #endif
@@ -527,7 +531,7 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
     f32x4 bt[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) bt[mt] = ld4(biasT + ((long)h * CFFM_NKEY_PAD + 16 * wave + l15) * CFFM_NQ_PAD + 4 * g + 16 * mt);
-    for (int t = wave; t < 19; t += 4) {
+    for (int t = wave; t < ((BWK_ABLATE & 1) ? 0 : 19); t += 4) {
         const int key = 16 * t + l15;
         f32x4 bn[4];
 #pragma unroll
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
         for (int mt = 0; mt < 4; ++mt) bt[mt] = bn[mt];
         // dK^T/dV^T tiles sit as [d = 16dt+4g+r][key = l15]: every lane owns 16 contiguous bytes of a key row of this
         // window's slot in the partial buffer
-        if (ksrc[key] >= 0) {
+        if (vf == 0.f && (!(BWK_ABLATE & 2) || isc == 12345.f)) {   // valid key (flag 0, -inf otherwise)
             float* prow = dkv_part + ((long)wb * CFFM_NKEY_PAD + key) * 512 + h * CFFM_HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {

@@ -45,8 +45,9 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
     // (qkv / fc1 forward, the 1024-wide input gradient), 64x64 otherwise; prefetch depth beyond the listed one is neutral.
     static int sel = -1;   // tuning aid: CFFM_GEMM_SEL = 1 -> 128x64 tiles, 2 -> 64x128, 3 -> 128x128 for the small cases
     if (sel < 0) { const char* e = getenv("CFFM_GEMM_SEL"); sel = e ? atoi(e) : 0; }
-    if (b128 >= 384 || prefer_big) GEMM_GO(128, 128, 32, 1);
-    else if (sel == 1) GEMM_GO(128, 64, 32, 2);
+    if (b128 >= 384 || prefer_big) {
+        GEMM_GO(128, 128, 32, 1);   // a second K-tile in flight in registers: neutral (k-contiguous forms) or one workgroup per CU (others)
+    } else if (sel == 1) GEMM_GO(128, 64, 32, 2);
     else if (sel == 2) GEMM_GO(64, 128, 32, 2);
     else if (sel == 3) GEMM_GO(128, 128, 32, 1);
     else GEMM_GO(64, 64, 32, 3);
