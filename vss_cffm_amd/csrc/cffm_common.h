@@ -221,6 +221,30 @@ __device__ __forceinline__ f16x8 cat_f16x4(f16x4 lo, f16x4 hi) {
     return r;
 }
 
+// LDS transpose read (gfx950 `ds_read_b64_tr_b16`): every lane passes the address of 4 contiguous 16-bit elements; inside
+// each group of 16 lanes the 16 x 4 elements are transposed: lane l receives element (l & 3) of the lanes 4j + ((l & 15) >> 2),
+// j = 0..3, of its group (measured on MI355X with the lanes' quads laid end to end as a 64-element block: lane l gets block
+// elements l, l+16, l+32, l+48).  With lane i pointing at row (i >> 2), columns 4 (i & 3) .. +3 of a [4 rows][16 columns]
+// block, lane l gets column (l & 15) of the 4 rows: row-major K / V / Q / dO images feed the MFMA operands that need the
+// transposed view, so no transposed copy is ever written.  Wave-collective (all 64 lanes must call it).
+__device__ __forceinline__ f16x4 lds_tr4(const f16* p) {
+#ifdef CFFM_EMU
+    struct Quad { f16 e[4]; } mine = {{p[0], p[1], p[2], p[3]}};
+    const int lane = emu::lane_linear() & 63;
+    auto s = emu::deposit(&mine, sizeof(mine));
+    f16x4 r;
+    for (int j = 0; j < 4; ++j) r[j] = reinterpret_cast<const Quad*>(s[(lane & 48) + 4 * j + ((lane & 15) >> 2)])->e[lane & 3];
+    emu::release();
+    return r;
+#else
+    typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
+    f16x4 r;
+    __builtin_memcpy(&r, &v, 8);
+    return r;
+#endif
+}
+
 // ordering point between LDS writes and reads of *other lanes of the same wave* (wave-private LDS
 // scratch; LDS operations of one wave execute in order, this only pins the compiler / the emulator)
 __device__ __forceinline__ void wave_lds_sync() {

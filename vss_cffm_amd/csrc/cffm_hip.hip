@@ -344,8 +344,19 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
                   float* lse, void* stream) {
     PROF(ST_ATTN_FWD);
     REQUIRE(g && qkv16 && key_src && q_dst && bias && ao && lse, "attn_fwd: null");
-    CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
-                key_src, q_dst, bias, ao, lse);
+    // one workgroup per (window, head), three per CU (19.5 us at B=2); CFFM_ATTN_FWD=persistent selects the persistent form
+    // (bias tiles in registers, two-stage prefetch): 26 us -- its serialized staging costs more than the bias traffic saves
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("CFFM_ATTN_FWD"); variant = (e && e[0] == 'p') ? 1 : 0; }
+    if (variant == 0) {
+        CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
+                    key_src, q_dst, bias, ao, lse);
+    } else {
+        const int total = g->B * g->nW, want = 32 * FWP_OCC;   // 8 heads x 32 groups per occupancy slot = one workgroup per CU slot
+        const int ng0 = total < want ? total : want, per = (total + ng0 - 1) / ng0, ng = (total + per - 1) / per;
+        CFFM_LAUNCH(k_cfm_attn_fwd_p, (CFFM_HEADS, ng), (256), ATT_FWP_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16, key_src,
+                    q_dst, bias, ao, lse, per);
+    }
     CHECK_LAUNCH("attn_fwd");
     return 0;
 }

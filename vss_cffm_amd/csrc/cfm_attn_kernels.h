@@ -52,133 +52,22 @@ __device__ __forceinline__ f32x4 vflag4(const float* vflag, int o) {
     return *(const f32x4*)(vflag + o);
 #endif
 }
-#define ATT_FWD_LDS ((CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE + 64 * ATT_KS_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4)
+#define ATT_VROWS (CFFM_NKEY_PAD + 16)   // rows of an image that is read transposed 32 keys at a time: 16 zero rows past key 303
+#define ATT_FWD_LDS ((CFFM_NKEY_PAD + ATT_VROWS) * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
+// MFMA A-operand fragment of the TRANSPOSED view of a row image `img` (ATT_ROW layout): A[i = column c0 + (lane & 15)]
+// [k-slots 8 (lane >> 4) + j] = img[row r0 + 4 (lane >> 4) + j (+16 for j >= 4)][that column] -- the k-slot <-> row map of the
+// S^T / S tiles held in registers (4 (lane >> 4) + r of two consecutive 16-row tiles).  Two LDS transpose reads.
+__device__ __forceinline__ f16x8 att_tr_frag(const f16* img, int r0, int c0, int lane) {
+    const int i = lane & 15, row = r0 + 4 * (lane >> 4) + (i >> 2), col = c0 + 4 * (i & 3);
+    const f16x4 a = lds_tr4(img + ATT_ROW(row, col >> 3) + (col & 7));
+    const f16x4 b = lds_tr4(img + ATT_ROW((row + 16), col >> 3) + (col & 7));
+    return cat_f16x4(a, b);
+}
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads = 4 waves x 16 queries.
-__global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __restrict__ qkv,
-                                                       const int* __restrict__ key_src, const int* __restrict__ q_dst,
-                                                       const float* __restrict__ bias, float* __restrict__ ao,
-                                                       float* __restrict__ lse_out) {
-    CFFM_DYN_SMEM(smem);
-    f16* Ks = (f16*)smem;
-    f16* Vt = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    f16* Qs = Vt + 32 * ATT_VT_STRIDE;
-    float* vflag = (float*)(Qs + 64 * ATT_KS_STRIDE);
-
-    const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int* ksrc = key_src + w * CFFM_NKEY_PAD;
-    const h16* base = qkv + (long)b * G.RC * 768 + h * CFFM_HD;   // q|k|v as f16, bias added, q pre-scaled (GEMM epilogue)
-
-    // ---- stage: key validity, K rows, V transposed, Q rows ----
-    // Global loads are issued in three batches, each complete before anything waits on it: the key-table entries of
-    // this thread's 3 row pairs, then the 12 gathered 16-byte K/V segments + the Q segment, then (below) the wave's 19
-    // bias tiles -- the kernel pays the L2/HBM latency about three times instead of ~30 times.  A (token, head) slice
-    // is 64 B of f16 = four 16-byte chunks c4.
-    const int qcol = 16 * wave + (lane & 15), g = lane >> 4;
-    const int c4 = lane >> 4;
-    const int qdst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;   // needed only by the epilogue: requested with the first batch
-    int src0[3], src1[3];
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        const int pr = (it * 4 + wave) * 16 + (lane & 15);
-        const bool ok = pr < CFFM_NKEY_PAD / 2;
-        src0[it] = ok ? ksrc[2 * pr] : -1;
-        src1[it] = ok ? ksrc[2 * pr + 1] : -1;
-    }
-    f16x8 z8;
-    for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
-    f16x8 k0[3], k1[3], v0[3], v1[3];
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        k0[it] = k1[it] = v0[it] = v1[it] = z8;
-        if (src0[it] >= 0 && !(FWD_ABLATE & 2)) { k0[it] = ld_h8(base + (long)src0[it] * 768 + 256 + 8 * c4); v0[it] = ld_h8(base + (long)src0[it] * 768 + 512 + 8 * c4); }
-        if (src1[it] >= 0 && !(FWD_ABLATE & 2)) { k1[it] = ld_h8(base + (long)src1[it] * 768 + 256 + 8 * c4); v1[it] = ld_h8(base + (long)src1[it] * 768 + 512 + 8 * c4); }
-    }
-    const int qi = tid >> 2, qc = tid & 3;
-    f16x8 qv = z8;
-    if (qi < CFFM_WA) qv = ld_h8(base + (long)(w * CFFM_WA + qi) * 768 + 8 * qc);
-    for (int n = tid; n < CFFM_NKEY_PAD; n += 256) vflag[n] = ksrc[n] >= 0 ? 0.f : -INFINITY;
-    for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += 256)
-        Vt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        const int pr = (it * 4 + wave) * 16 + (lane & 15);
-        if (pr < CFFM_NKEY_PAD / 2) {
-            const int n0 = 2 * pr;
-            *(f16x8*)(Ks + ATT_ROW(n0, c4)) = k0[it];
-            *(f16x8*)(Ks + ATT_ROW((n0 + 1), c4)) = k1[it];
-            if (!(FWD_ABLATE & 16)) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f16x2 pv; pv[0] = v0[it][e]; pv[1] = v1[it][e];
-                *(f16x2*)(Vt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pv;
-            }
-            }
-        }
-    }
-    *(f16x8*)(Qs + ATT_ROW(qi, qc)) = qv;
-    // the wave's 19 bias tiles (L2-resident table) fly across the barrier and land in the MFMA C operands
-    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
-    f32x4 s[19];
-#pragma unroll
-    for (int t = 0; t < 19; ++t) s[t] = (FWD_ABLATE & 1) ? (f32x4){0.f, 0.f, 0.f, 0.f} : ld4(brow + 16 * t);
-    __syncthreads();
-
-    // ---- S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column -----------------
-    const f16x8 qfrag = *(const f16x8*)(Qs + ATT_ROW(qcol, g));
-    float m = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 19; ++t) {
-        const f16x8 kf = *(const f16x8*)(Ks + ATT_ROW((16 * t + (lane & 15)), g));
-        const f32x4 acc = mfma16x16x32_f16(kf, qfrag, s[t] + vflag4(vflag, 16 * t + 4 * g));   // C-in = bias + mask
-        s[t] = acc;
-        m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int t = 0; t < 19; ++t) {
-        f32x4 p;
-        if (FWD_ABLATE & 4) { p = s[t] - m; } else {
-        p[0] = fast_exp(s[t][0] - m); p[1] = fast_exp(s[t][1] - m); p[2] = fast_exp(s[t][2] - m); p[3] = fast_exp(s[t][3] - m); }
-        s[t] = p;
-        l += (p[0] + p[1]) + (p[2] + p[3]);
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-
-    // ---- O^T = V^T P^T : A = V^T[d][key-slots] from LDS, B = P^T from registers ----------------------
-    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int kt = 0; kt < 10; ++kt) {
-        const f16x4 lo = to_f16x4(s[2 * kt]);
-        const f16x4 hi = (2 * kt + 1 < 19) ? to_f16x4(s[(2 * kt + 1 < 19) ? 2 * kt + 1 : 0]) : (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        const f16x8 pf = cat_f16x4(lo, hi);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const f16* vr = Vt + (16 * mt + (lane & 15)) * ATT_VT_STRIDE + 32 * kt + 4 * g;
-            const f16x8 vf = cat_f16x4(*(const f16x4*)vr, *(const f16x4*)(vr + 16));
-            if (FWD_ABLATE & 8) { o[mt][0] += (float)vf[0] + (float)pf[0]; } else
-            o[mt] = mfma16x16x32_f16(vf, pf, o[mt]);
-        }
-    }
-
-    // ---- epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821) ------------
-    if (g == 0) lse_out[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol] = (qcol < CFFM_WA) ? m + logf(l) : 0.f;
-    {
-        const int dst = qdst;
-        if (dst >= 0) {
-            const float inv = 1.f / l;
-            float* orow = ao + ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 4 * g;
-            *(f32x4*)(orow) = o[0] * inv;
-            *(f32x4*)(orow + 16) = o[1] * inv;
-        }
-    }
-}
+// (k_cfm_attn_fwd is defined below, after the staging helpers it shares with the backward kernels)
 
 // =====================================================================================================
 // Backward: two kernels + a gather pass.
@@ -209,8 +98,8 @@ __device__ long long g_bwq_t[8 * 8];
 #ifndef BWQ_OCC
 #define BWQ_OCC 1  // workgroups per CU of the query-owner backward kernel: 1 = 512-register budget, no spills (measured faster than 2)
 #endif
-#define ATT_BWQ_LDS ((2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 32 * ATT_VT_STRIDE) * sizeof(f16) + CFFM_NKEY_PAD * 4)
-#define ATT_BWK_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE + 2 * 32 * ATT_QT_STRIDE) * sizeof(f16) + \
+#define ATT_BWQ_LDS ((CFFM_NKEY_PAD + ATT_VROWS) * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
+#define ATT_BWK_LDS ((2 * 64 * ATT_KS_STRIDE + 2 * CFFM_NKEY_PAD * ATT_KS_STRIDE) * sizeof(f16) + \
                      CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
 
 // A window's K / V rows on their way from the f16 q|k|v rows to LDS, held in registers so that the gather of window w+1
@@ -266,13 +155,11 @@ __device__ __forceinline__ void kv_load(KvRegs<NTHREADS>& r, buf_t rs_qkv, uint3
 }
 __device__ __forceinline__ buf_t qkv_rsrc(const Geo& G, const h16* qkv) { return buf_make(qkv, (uint32_t)((long)G.B * G.RC * 768 * 2)); }
 __device__ __forceinline__ uint32_t qkv_soff_k(const Geo& G, int b, int h) { return (uint32_t)(((long)b * G.RC * 768 + 256 + h * CFFM_HD) * 2); }
-template <int NTHREADS, bool WITH_KT>
-__device__ __forceinline__ void kv_store(const KvRegs<NTHREADS>& r, f16* Ks, f16* Vs, f16* Kt, float* vflag, int tid) {
+// TR: 0 = K and V rows only; 1 = K rows, V rows and K^T (packed key pairs); 2 = K rows and V^T (no V rows)
+template <int NTHREADS, int TR>
+__device__ __forceinline__ void kv_store(const KvRegs<NTHREADS>& r, f16* Ks, f16* Vs, f16* Tt, float* vflag, int tid) {
     constexpr int NW = KvRegs<NTHREADS>::NW, NIT = KvRegs<NTHREADS>::NIT;
     const int lane = tid & 63, wave = tid >> 6, c4 = lane >> 4;
-    if (WITH_KT)
-        for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += NTHREADS)
-            Kt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int prk = (it * NW + wave) * 16 + (lane & 15);
@@ -281,24 +168,35 @@ __device__ __forceinline__ void kv_store(const KvRegs<NTHREADS>& r, f16* Ks, f16
             if (c4 == 0) { vflag[n0] = r.src0[it] >= 0 ? 0.f : -INFINITY; vflag[n0 + 1] = r.src1[it] >= 0 ? 0.f : -INFINITY; }
             *(f16x8*)(Ks + ATT_ROW(n0, c4)) = r.k0[it];
             *(f16x8*)(Ks + ATT_ROW((n0 + 1), c4)) = r.k1[it];
-            *(f16x8*)(Vs + ATT_ROW(n0, c4)) = r.v0[it];
-            *(f16x8*)(Vs + ATT_ROW((n0 + 1), c4)) = r.v1[it];
-            if (WITH_KT) {
+            if (TR != 2) {
+                *(f16x8*)(Vs + ATT_ROW(n0, c4)) = r.v0[it];
+                *(f16x8*)(Vs + ATT_ROW((n0 + 1), c4)) = r.v1[it];
+            }
+            if (TR) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    f16x2 pk; pk[0] = r.k0[it][e]; pk[1] = r.k1[it][e];
-                    *(f16x2*)(Kt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pk;
+                    f16x2 pk;
+                    pk[0] = TR == 1 ? r.k0[it][e] : r.v0[it][e];
+                    pk[1] = TR == 1 ? r.k1[it][e] : r.v1[it][e];
+                    *(f16x2*)(Tt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pk;
                 }
             }
         }
     }
 }
-template <int NTHREADS, bool WITH_KT>
+// the key columns 304..327 of a transposed image are never written by kv_store: zero them once per kernel
+template <int NTHREADS>
+__device__ __forceinline__ void kt_pad_zero(f16* Tt, int tid) {
+    for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += NTHREADS)
+        Tt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
+}
+template <int NTHREADS, int TR>
 __device__ __forceinline__ void stage_kv(buf_t rs_qkv, uint32_t soff_k, const int* __restrict__ ksrc, f16* Ks, f16* Vs, f16* Kt,
                                          float* vflag, int tid) {
     KvRegs<NTHREADS> r;
     kv_load<NTHREADS>(r, rs_qkv, soff_k, ksrc, tid);
-    kv_store<NTHREADS, WITH_KT>(r, Ks, Vs, Kt, vflag, tid);
+    if (TR) kt_pad_zero<NTHREADS>(Kt, tid);
+    kv_store<NTHREADS, TR>(r, Ks, Vs, Kt, vflag, tid);
 }
 
 // the query-owner lane's own operands of one window: Q fragment, dO / O (8 channels), LSE, destination pixel
@@ -331,9 +229,8 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
                                                             float* __restrict__ dbias_part, int per_group) {
     CFFM_DYN_SMEM(smem);
     f16* Ks = (f16*)smem;
-    f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    f16* Kt = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    float* vflag = (float*)(Kt + 32 * ATT_VT_STRIDE);
+    f16* Vs = Ks + ATT_VROWS * ATT_KS_STRIDE;   // K rows are also read transposed (dQ = dS K): 16 zero rows past key 303
+    float* vflag = (float*)(Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE);
 
     const int h = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -353,6 +250,11 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
     // Software pipeline over the group's windows: while window wb is multiplied, the K/V gather and this lane's Q / dO / O
     // operands of window wb+1 are already in flight in registers (the 512-register budget of one workgroup per CU pays
     // for it), so the per-window gather latency is off the critical path.
+    if (tid < 64) {
+        f16x8 z8;
+        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
+        *(f16x8*)(Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE + 8 * tid) = z8;
+    }
     KvRegs<256> kv;
     KvTab<256> tabn;   // key-table entries / destination pixel of the window after the one whose rows are in flight
     QLaneRegs ql;
@@ -374,7 +276,7 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
     for (int wb = wb0; wb < wb1; ++wb) {
         const int w = wb % G.nW, b = wb / G.nW;
         BWQ_STAMP(0);
-        kv_store<256, true>(kv, Ks, Vs, Kt, vflag, tid);
+        kv_store<256, 0>(kv, Ks, Vs, nullptr, vflag, tid);
         BWQ_STAMP(1);
         const f16x8 qfrag = ql.qfrag;
         const f32x4 do0 = ql.do0, do1 = ql.do1, o0 = ql.o0, o1 = ql.o1;
@@ -428,8 +330,7 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
             const f16x8 dsf = cat_f16x4(dsh[0], dsh[1]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const f16* kr = Kt + (16 * mt + l15) * ATT_VT_STRIDE + 32 * kt + 4 * g;
-                const f16x8 ka = cat_f16x4(*(const f16x4*)kr, *(const f16x4*)(kr + 16));
+                const f16x8 ka = att_tr_frag(Ks, 32 * kt, 16 * mt, lane);
                 if (!(BWQ_ABLATE & 4)) dq[mt] = mfma16x16x32_f16(ka, dsf, dq[mt]);
                 else dq[mt] += (f32x4){(float)dsf[0], (float)dsf[1], (float)dsf[2], (float)dsf[3]};
             }
@@ -456,7 +357,196 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
 }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads
-__global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
+__global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __restrict__ qkv,
+                                                       const int* __restrict__ key_src, const int* __restrict__ q_dst,
+                                                       const float* __restrict__ bias, float* __restrict__ ao,
+                                                       float* __restrict__ lse_out) {
+    CFFM_DYN_SMEM(smem);
+    f16* Ks = (f16*)smem;
+    f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+    float* vflag = (float*)(Vs + ATT_VROWS * ATT_KS_STRIDE);
+
+    const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qcol = 16 * wave + (lane & 15), g = lane >> 4, l15 = lane & 15;
+
+    // ---- stage ----
+    // Global loads go out in three batches, each complete before anything waits on it: the key-table entries of this
+    // thread's 3 row pairs (+ the destination pixel the epilogue needs), then the 12 gathered 16-byte K/V segments and
+    // this lane's Q fragment (straight into the MFMA operand: Q never touches LDS), then the wave's 19 bias tiles.
+    // A (token, head) slice is 64 B of f16 = four 16-byte chunks.  K and V are both kept as ROWS: the PV step reads V
+    // through the LDS transpose read (lds_tr4), so no transposed image is written.
+    const buf_t rs_qkv = qkv_rsrc(G, qkv);
+    const int qdst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;
+    KvRegs<256> kv;
+    kv_load<256>(kv, rs_qkv, qkv_soff_k(G, b, h), key_src + w * CFFM_NKEY_PAD, tid);
+    const f16x8 qfrag = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)(w * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
+                                  (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
+    if (tid < 64) {   // the 16 rows past the last key that the last PV k-step reads: zeros (their P entries are zeros too)
+        f16x8 z8;
+        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
+        *(f16x8*)(Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE + 8 * tid) = z8;
+    }
+    kv_store<256, 0>(kv, Ks, Vs, nullptr, vflag, tid);
+    // the wave's 19 bias tiles (L2-resident table) fly across the barrier and land in the MFMA C operands
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
+    f32x4 s[19];
+#pragma unroll
+    for (int t = 0; t < 19; ++t) s[t] = ld4(brow + 16 * t);
+    __syncthreads();
+
+    // ---- S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column -----------------
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 19; ++t) {
+        const f16x8 kf = *(const f16x8*)(Ks + ATT_ROW((16 * t + l15), g));
+        const f32x4 acc = mfma16x16x32_f16(kf, qfrag, s[t] + vflag4(vflag, 16 * t + 4 * g));   // C-in = bias + mask
+        s[t] = acc;
+        m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 19; ++t) {
+        f32x4 p;
+        p[0] = fast_exp(s[t][0] - m); p[1] = fast_exp(s[t][1] - m); p[2] = fast_exp(s[t][2] - m); p[3] = fast_exp(s[t][3] - m);
+        s[t] = p;
+        l += (p[0] + p[1]) + (p[2] + p[3]);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+
+    // ---- O^T = V^T P^T : A = V^T[d][key slots] read transposed out of the V rows, B = P^T from registers ----------
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kt = 0; kt < 10; ++kt) {
+        const f16x4 lo = to_f16x4(s[2 * kt]);
+        const f16x4 hi = (2 * kt + 1 < 19) ? to_f16x4(s[(2 * kt + 1 < 19) ? 2 * kt + 1 : 0]) : (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        const f16x8 pf = cat_f16x4(lo, hi);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            o[mt] = mfma16x16x32_f16(att_tr_frag(Vs, 32 * kt, 16 * mt, lane), pf, o[mt]);
+    }
+
+    // ---- epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821) ------------
+    if (g == 0) lse_out[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol] = (qcol < CFFM_WA) ? m + logf(l) : 0.f;
+    if (qdst >= 0) {
+        const float inv = 1.f / l;
+        float* orow = ao + ((long)b * G.HW + qdst) * CFFM_C + h * CFFM_HD + 4 * g;
+        *(f32x4*)(orow) = o[0] * inv;
+        *(f32x4*)(orow + 16) = o[1] * inv;
+    }
+}
+
+// ---- forward, persistent form ------------------------------------------------------------------------------------------
+// grid (8 heads, NG window groups), FWP_OCC workgroups per CU.  The same mathematics as k_cfm_attn_fwd; what changes is where
+// the latencies go: the head's 19 bias tiles are loaded ONCE per workgroup and stay in registers (the one-shot kernel pulls
+// 78 KB of bias per (window, head) through the CU's 64 B/clk texture path -- more than the K/V gathers), the key-table
+// entries arrive two windows ahead and the K/V rows one window ahead (KvTab / KvRegs), Q comes straight from global into
+// the MFMA fragment, and with two workgroups per CU one stages (LDS writes, gather issue) while the other multiplies.
+#ifndef FWP_OCC
+#define FWP_OCC 2
+#endif
+#define ATT_FWP_LDS ATT_FWD_LDS
+__global__ void __launch_bounds__(256, FWP_OCC) k_cfm_attn_fwd_p(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
+                                                                const int* __restrict__ q_dst, const float* __restrict__ bias,
+                                                                float* __restrict__ ao, float* __restrict__ lse_out, int per_group) {
+    CFFM_DYN_SMEM(smem);
+    f16* Ks = (f16*)smem;
+    f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+    float* vflag = (float*)(Vs + ATT_VROWS * ATT_KS_STRIDE);
+    const int h = blockIdx.x, grp = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int qcol = 16 * wave + l15;
+    const int wb0 = grp * per_group;
+    const int wb1 = (wb0 + per_group < G.B * G.nW) ? wb0 + per_group : G.B * G.nW;
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
+    f32x4 bT[19];
+#pragma unroll
+    for (int t = 0; t < 19; ++t) bT[t] = ld4(brow + 16 * t);
+    if (tid < 64) {
+        f16x8 z8;
+        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
+        *(f16x8*)(Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE + 8 * tid) = z8;
+    }
+    const buf_t rs_qkv = qkv_rsrc(G, qkv);
+    KvRegs<256> kv;
+    KvTab<256> tabn;
+    f16x8 qn;          // Q fragment of the window whose rows are in flight
+    int dstc = -1, dstn = -1;
+    if (wb0 < wb1) {
+        kv_load<256>(kv, rs_qkv, qkv_soff_k(G, wb0 / G.nW, h), key_src + (wb0 % G.nW) * CFFM_NKEY_PAD, tid);
+        qn = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)((wb0 % G.nW) * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
+                       (uint32_t)(((long)(wb0 / G.nW) * G.RC * 768 + h * CFFM_HD) * 2));
+        dstc = qlane_dst(G, q_dst, wb0, qcol);
+    }
+    if (wb0 + 1 < wb1) {
+        kv_tab_load<256>(tabn, key_src + ((wb0 + 1) % G.nW) * CFFM_NKEY_PAD, tid);
+        dstn = qlane_dst(G, q_dst, wb0 + 1, qcol);
+    }
+    for (int wb = wb0; wb < wb1; ++wb) {
+        const int b = wb / G.nW;
+        kv_store<256, 0>(kv, Ks, Vs, nullptr, vflag, tid);
+        const f16x8 qfrag = qn;
+        const int dst = dstc;
+        __syncthreads();
+        if (wb + 1 < wb1) {
+            const int wn = (wb + 1) % G.nW, bn = (wb + 1) / G.nW;
+            kv_rows_load<256>(kv, tabn, rs_qkv, qkv_soff_k(G, bn, h), tid);
+            qn = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)(wn * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
+                           (uint32_t)(((long)bn * G.RC * 768 + h * CFFM_HD) * 2));
+            dstc = dstn;
+        }
+        if (wb + 2 < wb1) {
+            kv_tab_load<256>(tabn, key_src + ((wb + 2) % G.nW) * CFFM_NKEY_PAD, tid);
+            dstn = qlane_dst(G, q_dst, wb + 2, qcol);
+        }
+        // S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column
+        f32x4 s[19];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 19; ++t) {
+            const f16x8 kf = *(const f16x8*)(Ks + ATT_ROW((16 * t + l15), g));
+            s[t] = mfma16x16x32_f16(kf, qfrag, bT[t] + vflag4(vflag, 16 * t + 4 * g));
+            m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < 19; ++t) {
+            f32x4 pv;
+            pv[0] = fast_exp(s[t][0] - m); pv[1] = fast_exp(s[t][1] - m); pv[2] = fast_exp(s[t][2] - m); pv[3] = fast_exp(s[t][3] - m);
+            s[t] = pv;
+            l += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        // O^T = V^T P^T : A = V^T[d][key-slots] from LDS, B = P^T from registers
+        f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < 10; ++kt) {
+            const f16x4 lo = to_f16x4(s[2 * kt]);
+            const f16x4 hi = (2 * kt + 1 < 19) ? to_f16x4(s[(2 * kt + 1 < 19) ? 2 * kt + 1 : 0]) : (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+            const f16x8 pf = cat_f16x4(lo, hi);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) o[mt] = mfma16x16x32_f16(att_tr_frag(Vs, 32 * kt, 16 * mt, lane), pf, o[mt]);
+        }
+        // epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821)
+        if (g == 0) lse_out[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol] = (qcol < CFFM_WA) ? m + logf(l) : 0.f;
+        if (dst >= 0) {
+            const float inv = 1.f / l;
+            float* orow = ao + ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 4 * g;
+            *(f32x4*)(orow) = o[0] * inv;
+            *(f32x4*)(orow + 16) = o[1] * inv;
+        }
+        __syncthreads();   // LDS is restaged for the next window
+    }
+}
+
+__global__ void __launch_bounds__(256, 3) k_cfm_attn_bwd_kv(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
                                                              const int* __restrict__ q_dst, const float* __restrict__ biasT,
                                                              const float* __restrict__ ao, const float* __restrict__ dao,
                                                              const float* __restrict__ lse_in, float* __restrict__ dkv_part) {
@@ -465,9 +555,7 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
     f16* dOs = Qs + 64 * ATT_KS_STRIDE;
     f16* Ks = dOs + 64 * ATT_KS_STRIDE;
     f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    f16* Qt = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    f16* dOt = Qt + 32 * ATT_QT_STRIDE;
-    float* vflag = (float*)(dOt + 32 * ATT_QT_STRIDE);
+    float* vflag = (float*)(Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE);
     float* slse = vflag + CFFM_NKEY_PAD;
     float* sD = slse + 64;
     float* smax = sD + 64;
@@ -494,15 +582,10 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
     if (t0 >= 0) { const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c; r0 = ld4(dao + off); o0 = ld4(ao + off); }
     if (t1 >= 0) { const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c; r1 = ld4(dao + off); o1 = ld4(ao + off); }
     if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid];
-    stage_kv<256, false>(qkv_rsrc(G, qkv), qkv_soff_k(G, b, h), ksrc, Ks, Vs, nullptr, vflag, tid);
+    stage_kv<256, 0>(qkv_rsrc(G, qkv), qkv_soff_k(G, b, h), ksrc, Ks, Vs, nullptr, vflag, tid);
     if (tid < 128) {   // Q rows and the transposed Q image
         *(f16x8*)(Qs + ATT_ROW((2 * qp), qc)) = q0;
         *(f16x8*)(Qs + ATT_ROW((2 * qp + 1), qc)) = q1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            f16x2 pq; pq[0] = q0[e]; pq[1] = q1[e];
-            *(f16x2*)(Qt + (8 * qc + e) * ATT_QT_STRIDE + 2 * qp) = pq;
-        }
     }
     // D = rowsum(dO * O) (the 8 chunks of a query sit in 8 adjacent lanes) and the window's |dO| maximum
     float d0 = r0[0] * o0[0] + r0[1] * o0[1] + r0[2] * o0[2] + r0[3] * o0[3];
@@ -522,10 +605,6 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
     if (c == 0) { sD[i0] = d0 * sc; sD[i1] = d1 * sc; }
     *(f16x4*)(dOs + ATT_ROW(i0, c >> 1) + 4 * (c & 1)) = to_f16x4(r0);
     *(f16x4*)(dOs + ATT_ROW(i1, c >> 1) + 4 * (c & 1)) = to_f16x4(r1);
-    for (int e = 0; e < 4; ++e) {
-        f16x2 pq; pq[0] = (f16)r0[e]; pq[1] = (f16)r1[e];
-        *(f16x2*)(dOt + (4 * c + e) * ATT_QT_STRIDE + i0) = pq;
-    }
     __syncthreads();
 
     f32x4 bt[4];
@@ -563,11 +642,9 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd_kv(Geo G, const h16* __
             const f16x8 pf = cat_f16x4(ph[2 * ks], ph[2 * ks + 1]);
             const f16x8 sf = cat_f16x4(dsh[2 * ks], dsh[2 * ks + 1]);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const f16* orow = dOt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
-                const f16* qrow = Qt + (16 * dt + l15) * ATT_QT_STRIDE + 32 * ks + 4 * g;
-                dv[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)orow, *(const f16x4*)(orow + 16)), pf, dv[dt]);
-                dk[dt] = mfma16x16x32_f16(cat_f16x4(*(const f16x4*)qrow, *(const f16x4*)(qrow + 16)), sf, dk[dt]);
+            for (int dt = 0; dt < 2; ++dt) {   // dO^T / Q^T operands: transposed reads of the dO / Q rows
+                dv[dt] = mfma16x16x32_f16(att_tr_frag(dOs, 32 * ks, 16 * dt, lane), pf, dv[dt]);
+                dk[dt] = mfma16x16x32_f16(att_tr_frag(Qs, 32 * ks, 16 * dt, lane), sf, dk[dt]);
             }
         }
 #pragma unroll
