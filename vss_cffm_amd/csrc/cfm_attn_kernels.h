@@ -131,21 +131,32 @@ __device__ __forceinline__ void kv_tab_load(KvTab<NTHREADS>& t, const int* __res
 // rows named by the table entries, through a buffer resource over the whole q|k|v array: one 32-bit offset per gather, a
 // "no such key" entry (-1) becomes an out-of-range offset that reads as zeros -- no branches, no 64-bit address arithmetic.
 // soff_k = byte offset of (clip b, row 0, this head's K slice): ((b*RC)*768 + 256 + h*32) * 2; V is 512 bytes further.
+// one of the NIT row-pair batches (4 gathers): the persistent kernels spread the batches over their compute loop, so the
+// texture path works through the gathers in the background instead of stalling the wave on a full request queue
 template <int NTHREADS>
-__device__ __forceinline__ void kv_rows_load(KvRegs<NTHREADS>& r, const KvTab<NTHREADS>& t, buf_t rs_qkv, uint32_t soff_k, int tid) {
-    constexpr int NIT = KvRegs<NTHREADS>::NIT;
+__device__ __forceinline__ void kv_rows_load_half(KvRegs<NTHREADS>& r, const KvTab<NTHREADS>& t, buf_t rs_qkv, uint32_t soff_k, int tid, int it, int odd) {
     const uint32_t c16 = (uint32_t)((tid & 63) >> 4) * 16;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    if (!odd) {
         r.src0[it] = t.s0[it];
-        r.src1[it] = t.s1[it];
         const uint32_t o0 = t.s0[it] >= 0 ? (uint32_t)t.s0[it] * 1536u + c16 : BUF_OOB;
-        const uint32_t o1 = t.s1[it] >= 0 ? (uint32_t)t.s1[it] * 1536u + c16 : BUF_OOB;
         r.k0[it] = buf_ld_h8(rs_qkv, o0, soff_k);
         r.v0[it] = buf_ld_h8(rs_qkv, o0, soff_k + 512);
+    } else {
+        r.src1[it] = t.s1[it];
+        const uint32_t o1 = t.s1[it] >= 0 ? (uint32_t)t.s1[it] * 1536u + c16 : BUF_OOB;
         r.k1[it] = buf_ld_h8(rs_qkv, o1, soff_k);
         r.v1[it] = buf_ld_h8(rs_qkv, o1, soff_k + 512);
     }
+}
+template <int NTHREADS>
+__device__ __forceinline__ void kv_rows_load_it(KvRegs<NTHREADS>& r, const KvTab<NTHREADS>& t, buf_t rs_qkv, uint32_t soff_k, int tid, int it) {
+    kv_rows_load_half<NTHREADS>(r, t, rs_qkv, soff_k, tid, it, 0);
+    kv_rows_load_half<NTHREADS>(r, t, rs_qkv, soff_k, tid, it, 1);
+}
+template <int NTHREADS>
+__device__ __forceinline__ void kv_rows_load(KvRegs<NTHREADS>& r, const KvTab<NTHREADS>& t, buf_t rs_qkv, uint32_t soff_k, int tid) {
+#pragma unroll
+    for (int it = 0; it < KvRegs<NTHREADS>::NIT; ++it) kv_rows_load_it<NTHREADS>(r, t, rs_qkv, soff_k, tid, it);
 }
 template <int NTHREADS>
 __device__ __forceinline__ void kv_load(KvRegs<NTHREADS>& r, buf_t rs_qkv, uint32_t soff_k, const int* __restrict__ ksrc, int tid) {
@@ -283,14 +294,9 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
         const float lq = ql.lq;
         __syncthreads();
         BWQ_STAMP(2);
-        if (wb + 1 < wb1) {   // rows of window wb+1: their table entries arrived during the previous window
-            kv_rows_load<256>(kv, tabn, rs_qkv, qkv_soff_k(G, (wb + 1) / G.nW, h), tid);
-            qlane_load(ql, G, qsrc, dstn, wb + 1, h, qcol, g);
-        }
-        if (wb + 2 < wb1) {   // table entries of window wb+2
-            kv_tab_load<256>(tabn, key_src + ((wb + 2) % G.nW) * CFFM_NKEY_PAD, tid);
-            dstn = qlane_dst(G, q_dst, wb + 2, qcol);
-        }
+        // (the gathers of window wb+1 and the table entries of window wb+2 are issued inside the key loop below)
+        const bool pre1 = wb + 1 < wb1, pre2 = wb + 2 < wb1;
+        const uint32_t soff_n = qkv_soff_k(G, (wb + 1) / G.nW, h);
 
         float Dq = (do0[0] * o0[0] + do0[1] * o0[1]) + (do0[2] * o0[2] + do0[3] * o0[3]) + (do1[0] * o1[0] + do1[1] * o1[1]) +
                    (do1[2] * o1[2] + do1[3] * o1[3]);
@@ -311,6 +317,16 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
 #pragma unroll
         for (int kt = 0; kt < 10; ++kt) {
             f16x4 dsh[2];
+            // one slice of the next window's loads per key-tile pair (4-7 loads at a time: all 25 at once cost ~2.3 k cycles of request-queue
+            // stall per window, 2 at a time measured slower again): rows (their table entries arrived during the previous window), this lane's
+            // Q / dO / O / LSE, then the table entries of the window after
+            if (kt < 3 && pre1) kv_rows_load_it<256>(kv, tabn, rs_qkv, soff_n, tid, kt);
+            if (kt == 3 && pre1) qlane_load(ql, G, qsrc, dstn, wb + 1, h, qcol, g);
+            if (kt == 4 && pre2) {
+                kv_tab_load<256>(tabn, key_src + ((wb + 2) % G.nW) * CFFM_NKEY_PAD, tid);
+                dstn = qlane_dst(G, q_dst, wb + 2, qcol);
+            }
+            sched_fence();
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kt + u;
