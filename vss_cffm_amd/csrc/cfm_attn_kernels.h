@@ -326,7 +326,6 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
                 kv_tab_load<256>(tabn, key_src + ((wb + 2) % G.nW) * CFFM_NKEY_PAD, tid);
                 dstn = qlane_dst(G, q_dst, wb + 2, qcol);
             }
-            sched_fence();
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kt + u;
