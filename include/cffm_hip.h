@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 1
+#define CFFM_ABI_VERSION 2
 
 typedef struct cffm_geom {
     int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
@@ -59,7 +59,7 @@ typedef struct cffm_block_grads {
 
 /* float offsets of the activations one block saves for its backward (inside its slice of `saved`) */
 typedef struct cffm_block_ws {
-    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, total;
+    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, w_split, total;
 } cffm_block_ws;
 
 int cffm_abi_version(void);

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, ci, cl, cd = C.c_void_p, C.c_int, C.c_long, C.c_double
 
@@ -28,7 +28,7 @@ class BlockPtrs(C.Structure):
 
 class BlockWs(C.Structure):
     _fields_ = [(n, cl) for n in ('mean1', 'rstd1', 'M', 'zall', 'qkv', 'bias', 'biasT', 'lse', 'ao', 'x1', 'mean2',
-                                  'rstd2', 'z2', 'hraw', 'act', 'x2', 'total')]
+                                  'rstd2', 'z2', 'hraw', 'act', 'x2', 'w_split', 'total')]
 
 
 GP, BP = C.POINTER(Geom), C.POINTER(BlockPtrs)

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ M, PoolB pb,
                                                       float* __restrict__ zall, float* __restrict__ mean_out,
-                                                      float* __restrict__ rstd_out) {
+                                                      float* __restrict__ rstd_out, int split /* zall rows in split-4 storage */) {
     __shared__ float sM[9 * CFFM_WA];
     __shared__ float red[4][9][CFFM_C];
     const int w = blockIdx.x, frame = blockIdx.y, b = blockIdx.z;
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
                     rstd_out[((long)b * 4 + frame) * G.HW + pix] = rs;
                 }
             }
-            if (frame == 3) *(f32x4*)(zall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane) = z;
+            if (frame == 3) *(f32x4*)(zall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane) = split ? split4_pack(z) : z;
             if (valid) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c)
@@ -218,10 +218,19 @@ __global__ void __launch_bounds__(256) k_ln_pool_fwd(Geo G, const float* __restr
         if (c < ncell) *(f32x4*)(&red[wave][c][4 * lane]) = acc[c];
     __syncthreads();
     const float pbias = pb.b[frame_group(frame)][0];
-    for (int c = 0; c < ncell; ++c) {
-        const int ch = threadIdx.x;
-        const float s = red[0][c][ch] + red[1][c][ch] + red[2][c][ch] + red[3][c][ch] + pbias;
-        zall[((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + ch] = s;
+    if (!split) {
+        for (int c = 0; c < ncell; ++c) {
+            const int ch = threadIdx.x;
+            const float s = red[0][c][ch] + red[1][c][ch] + red[2][c][ch] + red[3][c][ch] + pbias;
+            zall[((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + ch] = s;
+        }
+    } else {   // split-4 storage packs 4 channels into one 16-byte group: one thread per group
+        for (int e = threadIdx.x; e < ncell * (CFFM_C / 4); e += 256) {
+            const int c = e / (CFFM_C / 4), c4 = 4 * (e % (CFFM_C / 4));
+            const f32x4 s = *(const f32x4*)(&red[0][c][c4]) + *(const f32x4*)(&red[1][c][c4]) + *(const f32x4*)(&red[2][c][c4]) +
+                            *(const f32x4*)(&red[3][c][c4]) + pbias;
+            *(f32x4*)(zall + ((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + c4) = split4_pack(s);
+        }
     }
 }
 

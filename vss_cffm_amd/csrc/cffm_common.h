@@ -150,6 +150,42 @@ __device__ __forceinline__ f32x4 mfma16x16x4_f32(float a, float b, f32x4 c) {
 #endif
 }
 
+// ---- bf16 hi/lo split of fp32 (operands of the Linear GEMMs) ------------------------------------------------------
+typedef __bf16 bf16;
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// "split-4" storage: 4 consecutive floats kept as the 16 bytes {bf16 hi x4, bf16 lo x4} -- exactly what split4() makes of
+// them.  Tensors that only GEMMs read (the LayerNorm / GELU outputs zall, z2, act, the MLP gradient dh) and a copy of the
+// weights are written in this format by their producers, so staging a tile of them is a plain copy: the split's VALU work
+// (the bound of these kernels) is paid once per element instead of once per tile that re-reads it.
+// (register-only bit casts: a float[4] temporary here gets "promoted" to LDS by the compiler and costs a round trip)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void unsplit4(f32x4 raw, bf16x4& hi, bf16x4& lo) {
+    hi = __builtin_bit_cast(bf16x4, (f32x2_t){raw[0], raw[1]});
+    lo = __builtin_bit_cast(bf16x4, (f32x2_t){raw[2], raw[3]});
+}
+__device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo);
+__device__ __forceinline__ f32x4 split4_pack(f32x4 x) {
+    bf16x4 h, l;
+    split4(x, h, l);
+    const f32x2_t a = __builtin_bit_cast(f32x2_t, h), b = __builtin_bit_cast(f32x2_t, l);
+    return (f32x4){a[0], a[1], b[0], b[1]};
+}
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0
+#endif
+__device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
+#if GEMM_ABLATE & 16
+    { unsplit4(x, hi, lo); return; }
+#endif
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16)x[e];
+        lo[e] = (bf16)(x[e] - (float)hi[e]);
+    }
+}
+
+
 // ---- raw buffer loads ------------------------------------------------------------------------------------------
 // A buffer resource carries the extent of an array: a load whose byte offset (per-lane VGPR part + uniform SGPR part) falls
 // outside returns zeros instead of faulting, so gathers with "no such row" entries need neither a branch nor 64-bit

@@ -139,6 +139,7 @@ int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* o) {
     o->hraw = p; p += up(B * HW * CFFM_HID);
     o->act = p; p += up(B * HW * CFFM_HID);
     o->x2 = p; p += up(B * HW * CFFM_C);
+    o->w_split = p; p += up(PREP_WFLOATS);   // qkv | proj | fc1 | fc2 weights in split-4 storage (k_param_prep)
     o->total = p;
     return 0;
 }
@@ -281,17 +282,24 @@ int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream)
     return 0;
 }
 
-int cffm_ln_pool_fwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
-                     const float* gamma, const float* beta, const float* M, const float* const pool_b[4],
-                     float* zall, float* mean, float* rstd, void* stream) {
+// `split`: the rows a GEMM is the only reader of are written in split-4 storage (cffm_common.h); the public stage
+// functions always write plain fp32, the block orchestration asks for split-4 when the hand-written GEMMs are in use
+static int ln_pool_fwd_impl(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
+                            const float* gamma, const float* beta, const float* M, const float* const pool_b[4],
+                            float* zall, float* mean, float* rstd, int split, void* stream) {
     PROF(ST_LN_POOL_FWD);
     REQUIRE(g && x_ref && x_tgt && zall, "ln_pool_fwd: null");
     PoolB pb;
     for (int i = 0; i < 4; ++i) pb.b[i] = pool_b[i];
     CFFM_LAUNCH(k_ln_pool_fwd, (g->nW, 4, g->B), (256), 0, (hipStream_t)stream, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma,
-                beta, M, pb, zall, mean, rstd);
+                beta, M, pb, zall, mean, rstd, split);
     CHECK_LAUNCH("ln_pool_fwd");
     return 0;
+}
+int cffm_ln_pool_fwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
+                     const float* gamma, const float* beta, const float* M, const float* const pool_b[4],
+                     float* zall, float* mean, float* rstd, void* stream) {
+    return ln_pool_fwd_impl(g, x_ref, ref_bs, x_tgt, tgt_bs, gamma, beta, M, pool_b, zall, mean, rstd, 0, stream);
 }
 
 int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
@@ -471,14 +479,19 @@ int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
     return 0;
 }
 
+static int residual_ln_impl(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
+                            const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,
+                            long nrows, int split, void* stream) {
+    PROF(ST_RES_LN);
+    CFFM_LAUNCH(k_residual_ln, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, xt, xt_bs, rows_per_batch, yraw, bproj,
+                gamma, beta, x1, z2, mean, rstd, nrows, split);
+    CHECK_LAUNCH("residual_ln");
+    return 0;
+}
 int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
                      const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,
                      long nrows, void* stream) {
-    PROF(ST_RES_LN);
-    CFFM_LAUNCH(k_residual_ln, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, xt, xt_bs, rows_per_batch, yraw, bproj,
-                gamma, beta, x1, z2, mean, rstd, nrows);
-    CHECK_LAUNCH("residual_ln");
-    return 0;
+    return residual_ln_impl(xt, xt_bs, rows_per_batch, yraw, bproj, gamma, beta, x1, z2, mean, rstd, nrows, 0, stream);
 }
 
 int cffm_ln_bwd_residual(const float* x1, const float* mean, const float* rstd, const float* gamma, const float* dz2,
@@ -511,7 +524,7 @@ int cffm_bias_gelu(const float* hraw, const float* b1, float* act, long rows, in
     CHECK_LAUNCH("bias_gelu");
     return 0;
 }
-int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, int cols, float* db1, void* stream) {
+static int gelu_bwd_impl(const float* hraw, const float* b1, float* dact, long rows, int cols, float* db1, int split, void* stream) {
     PROF(ST_GELU_BWD);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(cols == CFFM_HID, "gelu_bwd: cols must be %d", CFFM_HID);
@@ -522,7 +535,7 @@ int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, in
         part = red_scratch((size_t)nblk * CFFM_HID, st);
         REQUIRE(part, "gelu_bwd: scratch allocation failed");
     }
-    CFFM_LAUNCH(k_gelu_bwd, (nblk), (256), 0, st, hraw, b1, dact, part, rows, rpb);
+    CFFM_LAUNCH(k_gelu_bwd, (nblk), (256), 0, st, hraw, b1, dact, part, rows, split);
     if (db1) {
         RedSegs segs;
         segs.nseg = 0;
@@ -531,6 +544,9 @@ int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, in
     }
     CHECK_LAUNCH("gelu_bwd");
     return 0;
+}
+int cffm_gelu_bwd(const float* hraw, const float* b1, float* dact, long rows, int cols, float* db1, void* stream) {
+    return gelu_bwd_impl(hraw, b1, dact, rows, cols, db1, 0, stream);
 }
 int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float* out, long rows, void* stream) {
     PROF(ST_RES_OUT);
@@ -600,8 +616,12 @@ static int param_prep(const cffm_block_params* params, int n, float* ws0, long w
             a.t[d].own = p.rpb_own; a.t[d].ring = p.rpb_ring;
             for (int i = 0; i < 4; ++i) { a.t[d].pool[i] = p.rpb_pool[i]; a.pw[d].w[i] = p.pool_w[i]; }
             a.bias[d] = ws + L.bias; a.biasT[d] = ws + L.biasT; a.M[d] = ws + L.M;
+            a.w[d][0] = p.qkv_w; a.w[d][1] = p.proj_w; a.w[d][2] = p.fc1_w; a.w[d][3] = p.fc2_w;
+            a.w_s[d] = ws + L.w_split;
         }
-        CFFM_LAUNCH(k_param_prep, (nb + 1, nd), (256), 0, (hipStream_t)stream, a);
+        a.nbias = nb;
+        a.pack = gemm_use_lib() ? 0 : 1;
+        CFFM_LAUNCH(k_param_prep, (nb + 1 + (a.pack ? PREP_WBLOCKS : 0), nd), (256), 0, (hipStream_t)stream, a);
     }
     CHECK_LAUNCH("param_prep");
     return 0;
@@ -627,15 +647,45 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     cffm_block_ws_layout(g, &L);
     const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
     float* yraw = scratch;  // [NP,256] transient (proj output, later fc2 output)
-    TRY(cffm_ln_pool_fwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
-                         ws + L.mean1, ws + L.rstd1, stream));
-    TRY(cffm_linear_qkv_fwd(ws + L.zall, p->qkv_w, p->qkv_b, ws + L.qkv, NR, stream));
+    hipStream_t st = (hipStream_t)stream;
+    // Hand-written GEMMs: the tensors only they read (zall, z2, act) are produced in split-4 storage and the weights come
+    // from the split-4 copy k_param_prep made (ws.w_split), so no operand tile is split while it is staged -- except ao,
+    // which the attention backward also reads.  CFFM_GEMM=lib (rocBLAS cross-check) keeps everything plain fp32.
+    const int sp = gemm_use_lib() ? 0 : 1;
+    const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
+    TRY(ln_pool_fwd_impl(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
+                         ws + L.mean1, ws + L.rstd1, sp, stream));
+    if (sp) {
+        PROF(ST_GEMM);
+        REQUIRE(!gemm_nt_qkv16_split_pre(ws + L.zall, wq_s, p->qkv_b, (h16*)(ws + L.qkv), NR, 768, CFFM_C, st), "block_forward: qkv gemm failed");
+    } else {
+        TRY(cffm_linear_qkv_fwd(ws + L.zall, p->qkv_w, p->qkv_b, ws + L.qkv, NR, stream));
+    }
     TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, ws + L.bias, ws + L.ao, ws + L.lse, stream));
-    TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
-    TRY(cffm_residual_ln(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
-                         ws + L.mean2, ws + L.rstd2, NP, stream));
-    TRY(cffm_linear_gelu_fwd(ws + L.z2, p->fc1_w, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, stream));
-    TRY(cffm_linear_residual_fwd(ws + L.act, p->fc2_w, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, stream));
+    if (sp) {
+        PROF(ST_GEMM);
+        REQUIRE(!gemm_nt_split_pre<false>(ws + L.ao, wp_s, yraw, NP, CFFM_C, CFFM_C, st), "block_forward: proj gemm failed");
+    } else {
+        TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
+    }
+    TRY(residual_ln_impl(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
+                         ws + L.mean2, ws + L.rstd2, NP, sp, stream));
+    if (sp) {
+        {
+            PROF(ST_GEMM);
+            REQUIRE(!gemm_nt_gelu_split_pre(ws + L.z2, w1_s, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, st),
+                    "block_forward: fc1 gemm failed");
+        }
+        {
+            PROF(ST_GEMM);
+            REQUIRE(!gemm_nt_residual_split_pre(ws + L.act, w2_s, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, st),
+                    "block_forward: fc2 gemm failed");
+        }
+    } else {
+        TRY(cffm_linear_gelu_fwd(ws + L.z2, p->fc1_w, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, stream));
+        TRY(cffm_linear_residual_fwd(ws + L.act, p->fc2_w, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, stream));
+    }
+    CHECK_LAUNCH("block_forward");
     return 0;
 }
 
@@ -657,30 +707,50 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     float* dM = scratch + S.dM;
     float* dbiasT = scratch + S.dbiasT;
     RedScope reductions((hipStream_t)stream);   // the four parameter-gradient reductions below run as one launch (finish())
+    hipStream_t st = (hipStream_t)stream;
+    const int sp = gemm_use_lib() ? 0 : 1;   // see block_forward_impl: zall / z2 / act / weights (and dh below) in split-4 storage
+    const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
+#define DX_GEMM(PRE_DY, dy_, w_plain, w_s_, dx_, M_, N_, K_)                                                              \
+    do {                                                                                                                  \
+        if (sp) {                                                                                                         \
+            PROF(ST_GEMM);                                                                                                \
+            REQUIRE(!gemm_nn_split_pre<PRE_DY>(dy_, w_s_, dx_, M_, N_, K_, st), "block_backward: input-gradient gemm failed"); \
+        } else {                                                                                                          \
+            TRY(cffm_linear_bwd_input(dy_, w_plain, dx_, M_, N_, K_, stream));                                            \
+        }                                                                                                                 \
+    } while (0)
     // x2 = x1 + act W2^T + b2
-    TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
-    // act = gelu(hraw + b1); hraw = z2 W1^T
-    TRY(cffm_gelu_bwd(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, stream));
-    TRY(cffm_linear_bwd_input(dact, p->fc1_w, dz2, NP, CFFM_HID, CFFM_C, stream));
+    DX_GEMM(false, dout, p->fc2_w, w2_s, dact, NP, CFFM_C, CFFM_HID);
+    // act = gelu(hraw + b1); hraw = z2 W1^T   (dact becomes dh, in split-4 storage: only GEMMs read it)
+    TRY(gelu_bwd_impl(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, sp, stream));
+    DX_GEMM(true, dact, p->fc1_w, w1_s, dz2, NP, CFFM_HID, CFFM_C);
     // z2 = LN2(x1); x1 also feeds the residual
     TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1,
                              gr->fc2_b /* = colsum(dout) */, gr->proj_b /* = colsum(dx1) */, stream));
     // x1 = xt + ao Wp^T + bp
-    TRY(cffm_linear_bwd_input(dx1, p->proj_w, dao, NP, CFFM_C, CFFM_C, stream));
+    DX_GEMM(false, dx1, p->proj_w, wp_s, dao, NP, CFFM_C, CFFM_C);
     // attention
     TRY(cffm_attn_bwd(g, ws + L.qkv, key_src, q_dst, inv_ptr, inv_idx, ws + L.bias, ws + L.biasT, ws + L.ao, dao,
                       ws + L.lse, dqkv, dbiasT, scratch + S.dkvp, stream));
     TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, stream));
     // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)
     TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
-    TRY(cffm_linear_bwd_input(dqkv, p->qkv_w, dzall, NR, 768, CFFM_C, stream));
+    DX_GEMM(false, dqkv, p->qkv_w, wq_s, dzall, NR, 768, CFFM_C);
+#undef DX_GEMM
     // the four weight gradients, deferred to here (their operands dout, dact, dx1, dqkv are all still intact; ln_pool_bwd
     // below overwrites dout) and issued as one grouped launch
     const cffm_wgrad wg[4] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C},
                               {dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C},
                               {dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID},
                               {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
-    TRY(cffm_linear_bwd_weight_group(wg, 4, stream));
+    if (sp) {
+        const GemmTNPre pre[4] = {{0, 1}, {1, 1}, {0, 1}, {0, 0}};
+        PROF(ST_GEMM);
+        REQUIRE(!gemm_tn_group((const GemmTN*)wg, 4, st, pre), "block_backward: weight-gradient gemm failed");
+        CHECK_LAUNCH("block_backward weight gradients");
+    } else {
+        TRY(cffm_linear_bwd_weight_group(wg, 4, stream));
+    }
     // CFFA
     TRY(cffm_ln_pool_bwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1,
                          dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, gr->norm1_w, gr->norm1_b, dM, gr->pool_b, stream));

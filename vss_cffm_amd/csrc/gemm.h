@@ -10,7 +10,7 @@
 float* lib_scratch(size_t nfloats);   // cffm_hip.hip: library-owned device scratch (grows on demand)
 __global__ void k_sum_splits(const float* __restrict__ part, int nsplit, long n, float* __restrict__ out);
 
-template <bool A_T, bool B_T, int EPI = 0>
+template <bool A_T, bool B_T, int EPI = 0, bool A_PRE = false, bool B_PRE = false>
 static int gemm_split_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int ksplit,
                              hipStream_t st, const float* bias = nullptr, float* aux = nullptr, int prefer_big = 0) {
     int klen = ((K + ksplit - 1) / ksplit + 63) / 64 * 64;
@@ -29,7 +29,7 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
     if (GEMM_LDS(BM_, BN_, BK_) > 65536) {                                                                                    \
         static bool granted = false;                                                                                          \
         if (!granted) {                                                                                                       \
-            if (hipFuncSetAttribute((const void*)k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_>,                              \
+            if (hipFuncSetAttribute((const void*)k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_, A_PRE, B_PRE>,                              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS(BM_, BN_, BK_)) != hipSuccess)       \
                 return -1;                                                                                                    \
             granted = true;                                                                                                   \
@@ -38,7 +38,7 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
 #endif
 #define GEMM_GO(BM_, BN_, BK_, PF_) do {                                                                                               \
     GEMM_BIG_LDS(BM_, BN_, BK_, PF_)                                                                                                   \
-    CFFM_LAUNCH((k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_>), ((unsigned)(((N + BN_ - 1) / BN_) * ((M + BM_ - 1) / BM_) * ksplit)), (256), \
+    CFFM_LAUNCH((k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_, A_PRE, B_PRE>), ((unsigned)(((N + BN_ - 1) / BN_) * ((M + BM_ - 1) / BM_) * ksplit)), (256), \
                 GEMM_LDS(BM_, BN_, BK_), st, A, \
                 B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux); } while (0)
     // measured on MI355X (scripts/gemm_bench.py, CFFM-B1 shapes): 128x128 wins when it already gives >= 384 workgroups
@@ -62,24 +62,46 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
 static int gemm_nt_split(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
     return gemm_split_launch<false, false>(x, w, y, (int)M, N, K, K, K, N, 1, st);
 }
+// the same with the weight (and optionally the activation) in split-4 storage
+template <bool X_PRE>
+static int gemm_nt_split_pre(const float* x, const float* w_s, float* y, long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, false, 0, X_PRE, true>(x, w_s, y, (int)M, N, K, K, K, N, 1, st);
+}
 // hraw[M,N] = x w^T (raw, kept for backward), act = gelu(hraw + b)      (fc1 of the Mlp, cffm_transformer.py:21-22)
 static int gemm_nt_gelu_split(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K, hipStream_t st) {
     return gemm_split_launch<false, false, 1>(x, w, hraw, (int)M, N, K, K, K, N, 1, st, b, act);
+}
+// x, w and the written act all in split-4 storage
+static int gemm_nt_gelu_split_pre(const float* x_s, const float* w_s, const float* b, float* hraw, float* act_s, long M, int N, int K,
+                                  hipStream_t st) {
+    return gemm_split_launch<false, false, 5, true, true>(x_s, w_s, hraw, (int)M, N, K, K, K, N, 1, st, b, act_s);
 }
 // out[M,N] = res + x w^T + b                                             (fc2 + residual, cffm_transformer.py:824)
 static int gemm_nt_residual_split(const float* x, const float* w, const float* b, const float* res, float* out, long M, int N, int K,
                                   hipStream_t st) {
     return gemm_split_launch<false, false, 2>(x, w, out, (int)M, N, K, K, K, N, 1, st, b, const_cast<float*>(res));
 }
+static int gemm_nt_residual_split_pre(const float* x_s, const float* w_s, const float* b, const float* res, float* out, long M, int N,
+                                      int K, hipStream_t st) {
+    return gemm_split_launch<false, false, 2, true, true>(x_s, w_s, out, (int)M, N, K, K, K, N, 1, st, b, const_cast<float*>(res));
+}
 // qkv16[M,768] (f16) = (x w^T + b) with the q third pre-scaled                (qkv Linear feeding the CFM kernels)
 static int gemm_nt_qkv16_split(const float* x, const float* w, const float* b, h16* qkv16, long M, int N, int K, hipStream_t st) {
     return gemm_split_launch<false, false, 3>(x, w, nullptr, (int)M, N, K, K, K, N, 1, st, b, (float*)qkv16);
+}
+static int gemm_nt_qkv16_split_pre(const float* x_s, const float* w_s, const float* b, h16* qkv16, long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, false, 3, true, true>(x_s, w_s, nullptr, (int)M, N, K, K, K, N, 1, st, b, (float*)qkv16);
 }
 // dx[M,K] = dy[M,N] w[N,K]: output cols = K, contraction = N
 static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
     return gemm_split_launch<false, true>(dy, w, dx, (int)M, K, N, N, K, K, 1, st);
 }
+template <bool DY_PRE>
+static int gemm_nn_split_pre(const float* dy, const float* w_s, float* dx, long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, true, 0, DY_PRE, true>(dy, w_s, dx, (int)M, K, N, N, K, K, 1, st);
+}
 // dw[N,K] = dy[M,N]^T x[M,K]: output N x K, contraction = M (long) split over workgroups
+template <bool DY_PRE = false, bool X_PRE = false>
 static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
     // 128x128 tiles halve the operand re-reads through the CU load path (the bound of these kernels: see gemm_kernels.h);
     // enough contraction splits to give every CU a workgroup
@@ -89,17 +111,25 @@ static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int
     const int maxsplit = (int)((M + 127) / 128);   // at least 128 rows of the contraction per split
     if (ksplit > maxsplit) ksplit = maxsplit;
     if (ksplit < 1) ksplit = 1;
-    return gemm_split_launch<true, true>(dy, x, dw, N, K, (int)M, N, K, K, ksplit, st, nullptr, nullptr, big);
+    return gemm_split_launch<true, true, 0, DY_PRE, X_PRE>(dy, x, dw, N, K, (int)M, N, K, K, ksplit, st, nullptr, nullptr, big);
 }
 
 // ---- grouped weight gradients: dw_p[N_p,K_p] = dy_p[M_p,N_p]^T x_p[M_p,K_p], p < n <= 4, one launch (k_gemm_group_tt) --------
 struct GemmTN { const float* dy; const float* x; float* dw; long M; int N, K; };
-static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st) {
+struct GemmTNPre { int dy_pre, x_pre; };   // operand in split-4 storage
+static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const GemmTNPre* pre = nullptr) {
     bool groupable = n >= 1 && n <= GEMM_GROUP_MAX;
     for (int p = 0; p < n && groupable; ++p) groupable = pr[p].N % 128 == 0 && pr[p].K % 128 == 0 && pr[p].M >= 32;
     if (!groupable) {
-        for (int p = 0; p < n; ++p)
-            if (gemm_tn_split(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st)) return -1;
+        for (int p = 0; p < n; ++p) {
+            const int a = pre ? pre[p].dy_pre : 0, b = pre ? pre[p].x_pre : 0;
+            int rc;
+            if (a && b) rc = gemm_tn_split<true, true>(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st);
+            else if (a) rc = gemm_tn_split<true, false>(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st);
+            else if (b) rc = gemm_tn_split<false, true>(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st);
+            else rc = gemm_tn_split<false, false>(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st);
+            if (rc) return -1;
+        }
         return 0;
     }
     // one slice length for every problem: ~480 workgroups (two per CU are co-resident: 80 KB of LDS each)
@@ -121,6 +151,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st) {
     int wg = 0, blk = 0, nsum = 0;
     for (int p = 0; p < n; ++p) {
         G.A[p] = pr[p].dy; G.B[p] = pr[p].x;
+        G.a_pre[p] = pre ? pre[p].dy_pre : 0; G.b_pre[p] = pre ? pre[p].x_pre : 0;
         G.M[p] = pr[p].N; G.N[p] = pr[p].K; G.K[p] = (int)pr[p].M;
         G.C[p] = pr[p].dw;
         if (ksplit[p] > 1) {
@@ -134,7 +165,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st) {
         wg += (pr[p].N / 128) * (pr[p].K / 128) * ksplit[p];
         G.wg_end[p] = wg;
     }
-    for (int p = n; p < GEMM_GROUP_MAX; ++p) { G.A[p] = G.B[p] = nullptr; G.C[p] = nullptr; G.M[p] = G.N[p] = 128; G.K[p] = 0; G.wg_end[p] = wg; }
+    for (int p = n; p < GEMM_GROUP_MAX; ++p) { G.A[p] = G.B[p] = nullptr; G.C[p] = nullptr; G.M[p] = G.N[p] = 128; G.K[p] = 0; G.wg_end[p] = wg; G.a_pre[p] = G.b_pre[p] = 0; }
     G.klen = klen; G.n = n;
 #ifndef CFFM_EMU
     static bool granted = false;
@@ -228,10 +259,11 @@ static int gemm_nn(const float* dy, const float* w, float* dx, long M, int N, in
     return gemm_use_lib() ? gemm_nn_lib(dy, w, dx, M, N, K, st) : gemm_nn_split(dy, w, dx, M, N, K, st);
 }
 static int gemm_tn(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
-    return gemm_use_lib() ? gemm_tn_lib(dy, x, dw, M, N, K, st) : gemm_tn_split(dy, x, dw, M, N, K, st);
+    return gemm_use_lib() ? gemm_tn_lib(dy, x, dw, M, N, K, st) : gemm_tn_split<>(dy, x, dw, M, N, K, st);
 }
-static int gemm_tn_group(const GemmTN* pr, int n, hipStream_t st) {
-    if (!gemm_use_lib()) return gemm_tn_group_split(pr, n, st);
+static int gemm_tn_group(const GemmTN* pr, int n, hipStream_t st, const GemmTNPre* pre = nullptr) {
+    if (!gemm_use_lib()) return gemm_tn_group_split(pr, n, st, pre);
+    if (pre) return -1;
     for (int p = 0; p < n; ++p)
         if (gemm_tn_lib(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st)) return -1;
     return 0;

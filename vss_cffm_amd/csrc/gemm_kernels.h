@@ -30,9 +30,7 @@
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0   // profiling builds only: 1 no global loads in the K-loop, 2 no split / LDS stores, 4 no MFMAs, 8 no fast path, 16 no split arithmetic
 #endif
-typedef __bf16 bf16;
-typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// (bf16 types and the split-4 helpers: cffm_common.h)
 
 __device__ __forceinline__ f32x4 mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 #ifdef CFFM_EMU
@@ -56,17 +54,6 @@ __device__ __forceinline__ f32x4 mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) 
 #else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
-}
-
-__device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
-#if GEMM_ABLATE & 16
-    { float t[4] = {x[0], x[1], x[2], x[3]}; __builtin_memcpy(&hi, &t[0], 8); __builtin_memcpy(&lo, &t[2], 8); return; }
-#endif
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = (bf16)x[e];
-        lo[e] = (bf16)(x[e] - (float)hi[e]);
-    }
 }
 
 // LDS image of a k-contiguous operand tile: 64-byte rows (32 bf16), NO padding, the four 16-byte chunks of a row stored at
@@ -155,13 +142,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // registers -> LDS (split into hi / lo bf16 images)
 template <int ROWS, bool TR, int BK>
-__device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid) {
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid,
+                                           bool pre = false /* the registers hold split-4 data: no arithmetic */) {
     if (!TR) {
 #pragma unroll
         for (int it = 0; it < ROWS * BK / 1024; ++it) {
             const int item = tid + 256 * it;
             bf16x4 h, l;
-            split4(r.v[it], h, l);
+            if (pre) unsplit4(r.v[it], h, l);
+            else split4(r.v[it], h, l);
             const int row = item / (BK / 4), kc = 4 * (item % (BK / 4));
             const int o = row * BK + ((((kc >> 3) ^ GEMM_SWZ(row)) << 3) | (kc & 4));
             *(bf16x4*)(hi + o) = h;
@@ -173,8 +162,8 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __
             const int item = tid + 256 * it;
             const int kp = item / (ROWS / 4), row = 4 * (item % (ROWS / 4));
             bf16x4 h0, l0, h1, l1;
-            split4(r.v[2 * it], h0, l0);
-            split4(r.v[2 * it + 1], h1, l1);
+            if (pre) { unsplit4(r.v[2 * it], h0, l0); unsplit4(r.v[2 * it + 1], h1, l1); }
+            else { split4(r.v[2 * it], h0, l0); split4(r.v[2 * it + 1], h1, l1); }
             u32x4 ph, pl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ph[e] = pack_bf16(h0[e], h1[e]); pl[e] = pack_bf16(l0[e], l1[e]); }
@@ -229,7 +218,8 @@ __device__ __forceinline__ int xcd_linear_id() {
 template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF>
 __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                           int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
-                                          const float* __restrict__ bias, float* __restrict__ aux, int bx, int by, int bz) {
+                                          const float* __restrict__ bias, float* __restrict__ aux, int bx, int by, int bz,
+                                          bool a_pre = false, bool b_pre = false) {
     bf16* Ah = (bf16*)smem;
     bf16* Al = Ah + GEMM_IMG(BM, BK);
     bf16* Bh = Al + GEMM_IMG(BM, BK);
@@ -256,8 +246,8 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
     const int NKT = (kend - kbeg + BK - 1) / BK;
     tile_load<BM, A_T, BK>(ra[0], A, lda, m0, M, kbeg, kend, tid);
     tile_load<BN, B_T, BK>(rb[0], B, ldb, n0, N, kbeg, kend, tid);
-    tile_store<BM, A_T, BK>(ra[0], Ah, Al, tid);
-    tile_store<BN, B_T, BK>(rb[0], Bh, Bl, tid);
+    tile_store<BM, A_T, BK>(ra[0], Ah, Al, tid, a_pre);
+    tile_store<BN, B_T, BK>(rb[0], Bh, Bl, tid, b_pre);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {   // tile 1+u -> register set u (past kend -> zeros, never used)
         tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + (1 + u) * BK, kend, tid);
@@ -297,8 +287,8 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                         acc[i][j] = mfma16x16x32_bf16(ah, bh[j], acc[i][j]);
                     }
                 }
-                tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid);
-                tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid);
+                tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid, a_pre);
+                tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid, b_pre);
                 tile_load_fast<BM, A_T, BK>(ra[u], rsa, va, sa0 + (t + 1 + PF) * dsa, lda4);
                 tile_load_fast<BN, B_T, BK>(rb[u], rsb, vb, sb0 + (t + 1 + PF) * dsb, ldb4);
                 GEMM_INTERLEAVE(3 * MT * NT);
@@ -334,8 +324,8 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                     }
                 }
                 if (t + 1 < NKT && !(GEMM_ABLATE & 2)) {
-                    tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid);
-                    tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid);
+                    tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid, a_pre);
+                    tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid, b_pre);
                 }
                 if (t + 1 + PF < NKT && !(GEMM_ABLATE & 1)) {
                     tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + (t + 1 + PF) * BK, kend, tid);
@@ -370,11 +360,11 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
             if (row >= M) continue;
             f32x4 v = *(const f32x4*)(T + rl * GEMM_TLD + c4);
             float* dst = C + (long)bz * split_stride + (long)row * ldc + col;
-            if (EPI == 1 && col + 3 < N) {          // N % 4 == 0 for every fused use
+            if ((EPI == 1 || EPI == 5) && col + 3 < N) {          // N % 4 == 0 for every fused use
                 *(f32x4*)dst = v;
                 f32x4 a;
                 for (int e = 0; e < 4; ++e) a[e] = gelu_erf(v[e] + bv[e]);
-                *(f32x4*)(aux + (long)row * ldc + col) = a;
+                *(f32x4*)(aux + (long)row * ldc + col) = (EPI == 5) ? split4_pack(a) : a;   // 5: act in split-4 storage
                 continue;
             }
             if (EPI == 3 && col + 3 < N) {
@@ -400,7 +390,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
     }
 }
 
-template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF>
+template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF, bool A_PRE = false, bool B_PRE = false>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                                      const float* __restrict__ bias, float* __restrict__ aux) {
@@ -408,7 +398,7 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
     const int lin = xcd_linear_id();
     const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
     gemm_tile<BM, BN, BK, A_T, B_T, EPI, PF>(smem, A, B, C, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux, lin % ntn,
-                                             (lin / ntn) % ntm, lin / (ntn * ntm));
+                                             (lin / ntn) % ntm, lin / (ntn * ntm), A_PRE, B_PRE);
 }
 
 // Up to GEMM_GROUP_MAX independent weight-gradient GEMMs (dw = dy^T x, <T,T>, 128x128 tiles) in ONE launch.  The four of a
@@ -424,6 +414,7 @@ struct GemmGroup {
     int M[GEMM_GROUP_MAX], N[GEMM_GROUP_MAX], K[GEMM_GROUP_MAX];
     int wg_end[GEMM_GROUP_MAX];        // exclusive prefix of workgroups per problem (after XCD re-numbering)
     int klen, n;
+    int a_pre[GEMM_GROUP_MAX], b_pre[GEMM_GROUP_MAX];   // operand already in split-4 storage
 };
 __global__ void __launch_bounds__(256) k_gemm_group_tt(GemmGroup G) {
     CFFM_DYN_SMEM(smem);
@@ -434,5 +425,5 @@ __global__ void __launch_bounds__(256) k_gemm_group_tt(GemmGroup G) {
     if (p > 0) lin -= G.wg_end[p - 1];
     const int M = G.M[p], N = G.N[p], ntn = N / 128, ntm = M / 128;
     gemm_tile<128, 128, 32, true, true, 0, 1>(smem, G.A[p], G.B[p], G.C[p], M, N, G.K[p], M, N, N, G.klen, (long)M * N, nullptr,
-                                              nullptr, lin % ntn, (lin / ntn) % ntm, lin / (ntn * ntm));
+                                              nullptr, lin % ntn, (lin / ntn) % ntm, lin / (ntn * ntm), G.a_pre[p] != 0, G.b_pre[p] != 0);
 }

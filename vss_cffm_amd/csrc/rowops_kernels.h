@@ -65,17 +65,34 @@ __global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __re
 // Everything a layer's blocks derive from parameters alone (dense bias tiles, composed pooling matrices), for up to
 // PREP_MAXD blocks in one launch: grid (bias workgroups + 1, blocks), the last workgroup of a row builds the pooling matrix.
 #define PREP_MAXD 4
+// ... and (pack != 0) a copy of the four Linear weights in split-4 storage (qkv 768x256 | proj 256x256 | fc1 1024x256 |
+// fc2 256x1024, one after the other): the weight operand of every forward / input-gradient GEMM is then staged without
+// arithmetic -- each weight element is otherwise re-split by every row panel of the GEMM (81x for the q|k|v Linear).
+#define PREP_WFLOATS (768 * 256 + 256 * 256 + 1024 * 256 + 256 * 1024)
+#define PREP_WBLOCKS (PREP_WFLOATS / 4 / 256)
 struct PrepArgs {
     BiasTables t[PREP_MAXD];
     PoolW pw[PREP_MAXD];
     float* bias[PREP_MAXD];
     float* biasT[PREP_MAXD];
     float* M[PREP_MAXD];
+    const float* w[PREP_MAXD][4];
+    float* w_s[PREP_MAXD];
+    int nbias, pack;
 };
 __global__ void __launch_bounds__(256) k_param_prep(PrepArgs a) {
-    const int d = blockIdx.y;
-    if (blockIdx.x == gridDim.x - 1) pool_matrix_body(a.pw[d], a.M[d]);
-    else bias_assemble_body(a.t[d], a.bias[d], a.biasT[d]);
+    const int d = blockIdx.y, bx = blockIdx.x;
+    if (bx < a.nbias) { bias_assemble_body(a.t[d], a.bias[d], a.biasT[d]); return; }
+    if (bx == a.nbias) { pool_matrix_body(a.pw[d], a.M[d]); return; }
+    if (!a.pack) return;
+    long e = (long)(bx - a.nbias - 1) * 256 + threadIdx.x;   // float4 index into the concatenated weights
+    const long n4[4] = {768 * 256 / 4, 256 * 256 / 4, 1024 * 256 / 4, 256 * 1024 / 4};
+    long off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (e >= off && e < off + n4[k]) ((f32x4*)a.w_s[d])[e] = split4_pack(((const f32x4*)a.w[d][k])[e - off]);
+        off += n4[k];
+    }
 }
 
 // dbiasT [8][304][64] (key-major, as the attention backward accumulates it) -> the six tables.
@@ -133,7 +150,8 @@ __global__ void __launch_bounds__(256) k_residual_ln(const float* __restrict__ x
                                                       const float* __restrict__ yraw, const float* __restrict__ bproj,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ x1, float* __restrict__ z2,
-                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, long nrows) {
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, long nrows,
+                                                      int split /* z2 in split-4 storage */) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -146,7 +164,8 @@ __global__ void __launch_bounds__(256) k_residual_ln(const float* __restrict__ x
     const f32x4 d = v - mu;
     const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / CFFM_C);
     const float rs = 1.f / sqrtf(var + CFFM_LN_EPS);
-    *(f32x4*)(z2 + row * CFFM_C + 4 * lane) = d * rs * *(const f32x4*)(gamma + 4 * lane) + *(const f32x4*)(beta + 4 * lane);
+    const f32x4 zv = d * rs * *(const f32x4*)(gamma + 4 * lane) + *(const f32x4*)(beta + 4 * lane);
+    *(f32x4*)(z2 + row * CFFM_C + 4 * lane) = split ? split4_pack(zv) : zv;
     if (lane == 0) { mean_out[row] = mu; rstd_out[row] = rs; }
 }
 
@@ -319,7 +338,7 @@ __global__ void __launch_bounds__(256) k_bias_gelu(const float* __restrict__ hra
 #define GELU_BWD_ROWS 16   // rows per workgroup (rows_per_block of the launch must equal it), read in batches of 4
 __global__ void __launch_bounds__(256, 4) k_gelu_bwd(const float* __restrict__ hraw, const float* __restrict__ b1,
                                                       float* __restrict__ dact, float* __restrict__ part, long nrows,
-                                                      int rows_per_block) {
+                                                      int split /* result in split-4 storage */) {
     const int t = threadIdx.x;
     const f32x4 bb = ((const f32x4*)b1)[t];
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -342,7 +361,7 @@ __global__ void __launch_bounds__(256, 4) k_gelu_bwd(const float* __restrict__ h
             const f32x4 x = v[k] + bb;
             f32x4 o = d[k];
             o[0] *= gelu_erf_grad(x[0]); o[1] *= gelu_erf_grad(x[1]); o[2] *= gelu_erf_grad(x[2]); o[3] *= gelu_erf_grad(x[3]);
-            ((f32x4*)(dact + (r0 + k) * CFFM_HID))[t] = o;
+            ((f32x4*)(dact + (r0 + k) * CFFM_HID))[t] = split ? split4_pack(o) : o;
             acc += o;
             sched_fence();   // one row's arithmetic at a time: keeps the register count low
         }

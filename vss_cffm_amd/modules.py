@@ -105,8 +105,15 @@ class CffmTransformerBlock3d3(nn.Module):
         return lin
 
     def param_list(self):
-        sd = dict(self.named_parameters())
-        return [sd[k] for k, _, _ in ops.BLOCK_PARAM_KEYS]
+        """The block's 26 parameters in BLOCK_PARAM_KEYS order.  Looked up by attribute path (a walk over
+        named_parameters() per forward cost more host time than half the block's kernel launches)."""
+        out = []
+        for key, _, _ in ops.BLOCK_PARAM_KEYS:
+            obj = self
+            for part in key.split('.'):
+                obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+            out.append(obj)
+        return out
 
 
 class BasicLayer3d3(nn.Module):

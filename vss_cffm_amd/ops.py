@@ -82,6 +82,21 @@ def block_ptrs(tensors):
     return s
 
 
+_struct_cache = {}
+
+
+def block_structs(tensors, depth):
+    """(BlockPtrs * depth) for a flat tensor list; cached on the addresses (parameters do not move between steps)."""
+    key = tuple(t.data_ptr() for t in tensors)
+    st = _struct_cache.get(key)
+    if st is None:
+        if len(_struct_cache) > 64:
+            _struct_cache.clear()
+        st = (_lib.BlockPtrs * depth)(*[block_ptrs(tensors[i * NPB:(i + 1) * NPB]) for i in range(depth)])
+        _struct_cache[key] = st
+    return st
+
+
 def block_ws_layout(lib, g):
     w = _lib.BlockWs()
     _lib.check(lib.cffm_block_ws_layout(C.byref(g), C.byref(w)), lib)
@@ -104,13 +119,16 @@ class _LayerFn(torch.autograd.Function):
         assert len(params) == NPB * depth
         b, _, _, h0, w0 = x.shape
         x = x.contiguous()
-        params = [p.detach().contiguous() for p in params]
+        for p in params:
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise _lib.CffmError('cffm layer parameters must be contiguous float32')
+        params = [p.detach() for p in params]
         g = make_geom(lib, b, h0, w0)
         key_src, q_dst, inv_ptr, inv_idx = device_tables(h0, w0, x.device)
         saved = torch.empty(lib.cffm_layer_saved_floats(C.byref(g), depth), dtype=torch.float32, device=x.device)
         scratch = torch.empty(lib.cffm_layer_scratch_floats(C.byref(g)), dtype=torch.float32, device=x.device)
         y = torch.empty(b, 256, h0, w0, dtype=torch.float32, device=x.device)
-        pstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(params[i * NPB:(i + 1) * NPB]) for i in range(depth)])
+        pstructs = block_structs(params, depth)
         _lib.check(lib.cffm_layer_forward(C.byref(g), depth, pstructs, _ptr(x), _ptr(y), _ptr(key_src), _ptr(q_dst),
                                           _ptr(saved), _ptr(scratch), _stream(x)), lib)
         ctx.depth, ctx.geom_args = depth, (b, h0, w0)
@@ -126,10 +144,16 @@ class _LayerFn(torch.autograd.Function):
         b, h0, w0 = ctx.geom_args
         g = make_geom(lib, b, h0, w0)
         dy = dy.contiguous()
-        grads = [torch.empty_like(p) for p in params]
+        # one allocation for every parameter gradient (16-byte aligned slices), returned as views
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)
+        grads, off = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += n
         dx = torch.empty(b, 4, 256, h0, w0, dtype=torch.float32, device=dy.device)
-        pstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(params[i * NPB:(i + 1) * NPB]) for i in range(depth)])
-        gstructs = (_lib.BlockPtrs * depth)(*[block_ptrs(grads[i * NPB:(i + 1) * NPB]) for i in range(depth)])
+        pstructs = block_structs(params, depth)
+        gstructs = block_structs(grads, depth)
         _lib.check(lib.cffm_layer_backward(C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src),
                                            _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch),
                                            _stream(dy)), lib)

@@ -76,10 +76,13 @@ class AdamW(torch.optim.Optimizer):
             if _lib._override is None and dev.type != 'cuda':
                 raise _lib.CffmError('AdamW: parameters are on %s; the update kernel runs only on the GPU (no CPU fallback)' % dev)
             steps = set()
+            state = self.state
             for p in ps:
-                if p.device != dev:
-                    raise _lib.CffmError('AdamW: one device per parameter group')
-                st = self._moments(p)
+                st = state.get(p)
+                if not st:
+                    if p.device != dev:
+                        raise _lib.CffmError('AdamW: one device per parameter group')
+                    st = self._moments(p)
                 st['step'] += 1
                 steps.add(st['step'])
             if len(steps) != 1:   # a parameter joined late: its bias correction differs -> one launch per step count
