@@ -147,10 +147,8 @@ class _LayerFn(torch.autograd.Function):
         # one allocation for every parameter gradient (16-byte aligned slices), returned as views
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)
-        grads, off = [], 0
-        for p, n in zip(params, sizes):
-            grads.append(flat[off:off + p.numel()].view(p.shape))
-            off += n
+        grads = [c[:p.numel()].view(p.shape) if c.numel() != p.numel() else c.view(p.shape)
+                 for c, p in zip(flat.split(sizes), params)]
         dx = torch.empty(b, 4, 256, h0, w0, dtype=torch.float32, device=dy.device)
         pstructs = block_structs(params, depth)
         gstructs = block_structs(grads, depth)
