@@ -5,7 +5,8 @@ Metric (BASELINE.json): clips/s, forward + backward, CFFM-B1 480x480 T=4.  A "st
 backward pass of the hot path (`decoder_focal` of the CFFM-B1 head: [B,4,256,60,60] fp32, B = 2 clips per
 GPU as the reference's samples_per_gpu=2) over one batch of synthetic clips already resident in HBM,
 followed by the AdamW update of the hot path's parameters.  N > 1: one process per GPU (torchrun), the
-module wrapped in DistributedDataParallel on RCCL (gradient all-reduce over xGMI, overlapped with backward),
+parameters broadcast once, then ONE RCCL all-reduce of the layer's flat gradient buffer per step (xGMI; `--ddp` uses torch's
+DistributedDataParallel instead),
 clips sharded over ranks (weak scaling).
 
 Prints ONE JSON line (rank 0).  Besides the contract's fields it carries
@@ -86,7 +87,8 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='clips per GPU (reference samples_per_gpu=2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
-    ap.add_argument('--spinup-seconds', type=float, default=1.5, help='untimed device spin-up before the warmup steps')
+    ap.add_argument('--ddp', action='store_true', help='wrap in torch DistributedDataParallel instead of the one-buffer all-reduce')
+    ap.add_argument('--spinup-steps', type=int, default=1000, help='untimed device spin-up steps before the warmup steps (~1 s)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -116,10 +118,14 @@ def main():
     layer.to(dev)
     model = layer
     if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local_rank], gradient_as_bucket_view=True,
-                                                          broadcast_buffers=False)
+        if args.ddp:   # torch's reducer: 52 per-parameter hooks and bucket copies per step
+            model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local_rank], gradient_as_bucket_view=True,
+                                                              broadcast_buffers=False)
+        else:          # default: parameters broadcast once, ONE all-reduce of the layer's gradient buffer per step
+            V.distributed.broadcast_parameters(layer, 0)
     # the reference's optimizer (local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:35), as this package's one-launch kernel
-    opt = V.optim.AdamW(layer.parameters(), lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    params_list = list(layer.parameters())
+    opt = V.optim.AdamW(params_list, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
     gen = torch.Generator(device='cpu').manual_seed(1000 + rank)
     b = args.batch
     x = (torch.randn(b, T, 256, GRID, GRID, generator=gen) * 1.5).to(dev)
@@ -133,17 +139,17 @@ def main():
         opt.zero_grad(set_to_none=True)
         y = model(x)
         y.backward(gy)
+        if world > 1 and not args.ddp:
+            V.distributed.allreduce_gradients(params_list)
         opt.step()
 
-    # Device spin-up (setup, not measurement): a freshly started process on an idle GPU has been seen to run the first
-    # seconds ~15 % slower (clock ramp, first-touch of the allocator's segments); the same step is run untimed for
-    # --spinup-seconds before the W warmup steps the contract asks for.  Reported in config.spinup_s.
-    if args.spinup_seconds > 0:
-        t_end = time.perf_counter() + args.spinup_seconds
-        while time.perf_counter() < t_end:
-            for _ in range(20):
-                step()
-            torch.cuda.synchronize(dev)
+    # Device spin-up (setup, not measurement): a freshly started process on an idle GPU has been seen to run its first
+    # second or so ~15 % slower (clock ramp, first touch of the allocator's segments); the same step is run untimed
+    # --spinup-steps times before the W warmup steps the contract asks for (a step COUNT, not a duration: under DDP every
+    # rank must issue the same number of all-reduces).  Reported in config.spinup_steps.
+    for _ in range(args.spinup_steps):
+        step()
+    torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
 
@@ -223,8 +229,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f32 accumulate; MFMA operands: split-bf16 (hi+lo, ~2^-17) in the Linear GEMMs, f16 in QK^T/AV',
             'data': 'synthetic',
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
-                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_s': args.spinup_seconds,
-                       'grad_allreduce': 'RCCL (DDP)' if world > 1 else 'none'},
+                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps,
+                       'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one all-reduce of the flat gradient buffer per step') if world > 1 else 'none'},
             'roofline': roof, 'kernels': stages,
             'kernels_note': 'per-stage HIP-event times from a separate instrumented pass of %d steps after the timed region '
                             '(event records on every launch slow the step by ~25 %%, so they are kept out of `value`)' % bsteps,

@@ -86,3 +86,49 @@ def test_ddp_world_size_2_gloo(tmp_path):
     for k in g0:
         want = (per_rank[0][k] + per_rank[1][k]) / world
         assert H.rel_err(g0[k], want) < 1e-5, k
+
+
+def _worker_flat(rank, world, port, out):
+    """bench.py's default N > 1 path: broadcast_parameters once, one all-reduce of the flat gradient buffer per step."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CFFM_EMU_THREADS='2')
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tests import emu
+    import vss_cffm_amd as V
+    with emu.active():
+        m = _layer()
+        if rank == 1:   # a rank that starts from different values must end up with rank 0's
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(1.0)
+        V.distributed.broadcast_parameters(m, 0)
+        x, g = _clip(rank)
+        (m(x)[:, -1] * g).sum().backward()
+        n = V.distributed.allreduce_gradients(list(m.parameters()))
+        assert n == 1, n   # every gradient of the layer lives in one buffer -> exactly one collective
+        V.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01).step()
+    torch.save({k: p.grad.clone() for k, p in m.named_parameters()}, os.path.join(out, 'fgrad%d.pt' % rank))
+    torch.save({k: p.detach().clone() for k, p in m.named_parameters()}, os.path.join(out, 'fparam%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_flat_allreduce_world_size_2_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker_flat, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (torch.load(os.path.join(str(tmp_path), 'fgrad%d.pt' % r)) for r in range(world))
+    p0, p1 = (torch.load(os.path.join(str(tmp_path), 'fparam%d.pt' % r)) for r in range(world))
+    from tests import emu, helpers as H
+    per_rank = []
+    with emu.active():
+        for r in range(world):
+            m = _layer()
+            x, g = _clip(r)
+            (m(x)[:, -1] * g).sum().backward()
+            per_rank.append({k: p.grad for k, p in m.named_parameters()})
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+        assert torch.equal(p0[k], p1[k]), k
+        assert H.rel_err(g0[k], (per_rank[0][k] + per_rank[1][k]) / world) < 1e-5, k

@@ -6,5 +6,6 @@ from .modules import (BasicLayer3d3, BasicLayer_cluster, CffmTransformerBlock3d3
 from . import head  # noqa: F401,E402  (registers the three CFFM heads and CrossEntropyLoss)
 from .config import Config  # noqa: F401,E402
 from . import optim  # noqa: F401,E402
+from . import distributed  # noqa: F401,E402
 from .registry import (BACKBONES, HEADS, LOSSES, NECKS, SEGMENTORS, Registry, build_backbone,  # noqa: F401,E402
                        build_from_cfg, build_head, build_loss, build_neck, build_segmentor)

@@ -53,14 +53,20 @@ __device__ __forceinline__ f32x4 vflag4(const float* vflag, int o) {
 #endif
 }
 #define ATT_VROWS (CFFM_NKEY_PAD + 16)   // rows of an image that is read transposed 32 keys at a time: 16 zero rows past key 303
-#define ATT_FWD_LDS ((CFFM_NKEY_PAD + ATT_VROWS) * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
+#define ATT_FWD_LDS (2 * CFFM_NKEY_PAD * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
+#define ATT_FWP_LDS_ ((CFFM_NKEY_PAD + ATT_VROWS) * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
 // MFMA A-operand fragment of the TRANSPOSED view of a row image `img` (ATT_ROW layout): A[i = column c0 + (lane & 15)]
 // [k-slots 8 (lane >> 4) + j] = img[row r0 + 4 (lane >> 4) + j (+16 for j >= 4)][that column] -- the k-slot <-> row map of the
 // S^T / S tiles held in registers (4 (lane >> 4) + r of two consecutive 16-row tiles).  Two LDS transpose reads.
+// NROWS > 0: the image has only NROWS rows; a second-half row past it is read from NROWS - 16 + (its offset) instead -- any
+// finite data do, the other operand's entries for those slots are exact zeros (keys 304..319 of the last PV / dQ k-step).
+template <int NROWS = 0>
 __device__ __forceinline__ f16x8 att_tr_frag(const f16* img, int r0, int c0, int lane) {
     const int i = lane & 15, row = r0 + 4 * (lane >> 4) + (i >> 2), col = c0 + 4 * (i & 3);
+    int row2 = row + 16;
+    if (NROWS > 0 && row2 >= NROWS) row2 -= 16;
     const f16x4 a = lds_tr4(img + ATT_ROW(row, col >> 3) + (col & 7));
-    const f16x4 b = lds_tr4(img + ATT_ROW((row + 16), col >> 3) + (col & 7));
+    const f16x4 b = lds_tr4(img + ATT_ROW(row2, col >> 3) + (col & 7));
     return cat_f16x4(a, b);
 }
 
@@ -372,14 +378,17 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
 }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads
-__global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __restrict__ qkv,
+#ifndef FWD_OCC
+#define FWD_OCC 4   // workgroups per CU: 39.1 KB of LDS and <= 128 VGPRs each
+#endif
+__global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16* __restrict__ qkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
                                                        const float* __restrict__ bias, float* __restrict__ ao,
                                                        float* __restrict__ lse_out) {
     CFFM_DYN_SMEM(smem);
     f16* Ks = (f16*)smem;
     f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    float* vflag = (float*)(Vs + ATT_VROWS * ATT_KS_STRIDE);
+    float* vflag = (float*)(Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE);
 
     const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -397,11 +406,6 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
     kv_load<256>(kv, rs_qkv, qkv_soff_k(G, b, h), key_src + w * CFFM_NKEY_PAD, tid);
     const f16x8 qfrag = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)(w * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
                                   (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
-    if (tid < 64) {   // the 16 rows past the last key that the last PV k-step reads: zeros (their P entries are zeros too)
-        f16x8 z8;
-        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
-        *(f16x8*)(Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE + 8 * tid) = z8;
-    }
     kv_store<256, 0>(kv, Ks, Vs, nullptr, vflag, tid);
     // the wave's 19 bias tiles (L2-resident table) fly across the barrier and land in the MFMA C operands
     const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
@@ -441,7 +445,7 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
         const f16x8 pf = cat_f16x4(lo, hi);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-            o[mt] = mfma16x16x32_f16(att_tr_frag(Vs, 32 * kt, 16 * mt, lane), pf, o[mt]);
+            o[mt] = mfma16x16x32_f16(att_tr_frag<CFFM_NKEY_PAD>(Vs, 32 * kt, 16 * mt, lane), pf, o[mt]);
     }
 
     // ---- epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821) ------------
@@ -463,7 +467,7 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_fwd(Geo G, const h16* __res
 #ifndef FWP_OCC
 #define FWP_OCC 2
 #endif
-#define ATT_FWP_LDS ATT_FWD_LDS
+#define ATT_FWP_LDS ATT_FWP_LDS_
 __global__ void __launch_bounds__(256, FWP_OCC) k_cfm_attn_fwd_p(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
                                                                 const int* __restrict__ q_dst, const float* __restrict__ bias,
                                                                 float* __restrict__ ao, float* __restrict__ lse_out, int per_group) {
