@@ -97,8 +97,12 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl')  # RCCL on ROCm
+        # RCCL on ROCm.  (CFFM_BENCH_BACKEND / CFFM_BENCH_ONE_DEVICE are test hooks: they let the multi-rank control flow of
+        # this script be exercised on a one-GPU box -- every rank on cuda:0, gloo -- they are never set by the driver.)
+        dist.init_process_group(os.environ.get('CFFM_BENCH_BACKEND', 'nccl'))
     assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node %d' % args.gpus
+    if os.environ.get('CFFM_BENCH_ONE_DEVICE'):
+        local_rank = 0
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
