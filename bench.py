@@ -87,6 +87,8 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='clips per GPU (reference samples_per_gpu=2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='capture the whole step (forward + backward + AdamW) in one HIP graph and time '
+                    'replays: the step then does not depend on host speed; the roofline kernel is timed in a separate eager pass')
     ap.add_argument('--ddp', action='store_true', help='wrap in torch DistributedDataParallel instead of the one-buffer all-reduce')
     ap.add_argument('--spinup-steps', type=int, default=1000, help='untimed device spin-up steps before the warmup steps (~1 s)')
     args = ap.parse_args()
@@ -154,6 +156,20 @@ def main():
     for _ in range(args.spinup_steps):
         step()
     torch.cuda.synchronize(dev)
+    eager_step = step
+    if args.graph:
+        # One HIP graph for the whole step (the optimizer's step count lives on the device, so replays are real steps).
+        # Side-stream warm-up as torch.cuda.graph requires, then capture; `step` becomes a replay.
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eager_step()
+        step = graph.replay
     for _ in range(args.warmup):
         step()
 
@@ -169,7 +185,7 @@ def main():
     nst = lib.cffm_profile_stage_count()
     names = [lib.cffm_profile_stage_name(i).decode() for i in range(nst)]
     ms_buf, n_buf = (C.c_float * nst)(), (C.c_int * nst)()
-    if stage_timing:
+    if stage_timing and not args.graph:   # (graph replays carry no event records: --graph times the kernel afterwards)
         lib.cffm_profile_collect(ms_buf, n_buf)
         lib.cffm_profile_enable(1 << names.index('cfm_attn_fwd'))
     barrier()
@@ -180,6 +196,12 @@ def main():
     dt = time.perf_counter() - t0
     attn_ms, attn_n, all_ms, all_n, bsteps = 0.0, 0, None, None, min(args.steps, 20)
     if stage_timing:
+        if args.graph:   # eager pass of the same step right after the timed replays, only the roofline kernel timed
+            lib.cffm_profile_collect(ms_buf, n_buf)
+            lib.cffm_profile_enable(1 << names.index('cfm_attn_fwd'))
+            for _ in range(args.steps):
+                eager_step()
+            torch.cuda.synchronize(dev)
         lib.cffm_profile_enable(0)
         lib.cffm_profile_collect(ms_buf, n_buf)
         i = names.index('cfm_attn_fwd')
@@ -187,7 +209,7 @@ def main():
         # separate instrumented pass: every stage, not part of `value` (all ranks step: DDP all-reduces inside)
         lib.cffm_profile_enable(-1 if rank == 0 else 0)
         for _ in range(bsteps):
-            step()
+            eager_step()
         torch.cuda.synchronize(dev)
         lib.cffm_profile_enable(0)
         lib.cffm_profile_collect(ms_buf, n_buf)
@@ -233,7 +255,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f32 accumulate; MFMA operands: split-bf16 (hi+lo, ~2^-17) in the Linear GEMMs, f16 in QK^T/AV',
             'data': 'synthetic',
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
-                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps,
+                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': bool(args.graph),
                        'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one all-reduce of the flat gradient buffer per step') if world > 1 else 'none'},
             'roofline': roof, 'kernels': stages,
             'kernels_note': 'per-stage HIP-event times from a separate instrumented pass of %d steps after the timed region '

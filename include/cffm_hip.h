@@ -178,6 +178,12 @@ typedef struct {
 } cffm_adamw_chunk;
 int cffm_adamw_step(const cffm_adamw_chunk* chunks /* device */, int nchunks, double lr, double beta1, double beta2, double eps,
                     double weight_decay, int step /* t >= 1 */, void* stream);
+/* The same update with the step count kept ON THE DEVICE (state: 4 floats, zero-initialised by the caller: [0] = t, advanced
+ * by the call, [1], [2] = the bias-correction factors derived from it), so a training step captured in a HIP graph replays
+ * with the right t.  grad_base != NULL: every chunk's `g` is a byte offset from grad_base instead of a pointer (all the
+ * gradients of the layer live in one buffer; its address may change between steps, the table does not). */
+int cffm_adamw_step_dev(const cffm_adamw_chunk* chunks /* device */, int nchunks, const float* grad_base, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, float* state /* device [4] */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,36 @@ def test_adamw_emulated():
         run_adamw(torch.device('cpu'))
 
 
+def run_adamw_shared_buffer(device, steps=5):
+    """Gradients that alias ONE buffer (what the layer's backward produces): the table holds offsets, the buffer may move."""
+    gen = torch.Generator().manual_seed(6)
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=gen)) for s in SHAPES]
+    mine = [torch.nn.Parameter(p.detach().clone().to(device)) for p in ref]
+    kw = dict(lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    o_ref, o_mine = torch.optim.AdamW(ref, **kw), V.optim.AdamW(mine, **kw)
+    sizes = [(p.numel() + 3) // 4 * 4 for p in ref]
+    keep = []
+    for it in range(steps):
+        flat = torch.empty(sum(sizes), device=device)
+        keep.append(flat)                                          # kept alive: a different address every step
+        for p, q, c in zip(ref, mine, flat.split(sizes)):
+            g = torch.randn(p.shape, generator=gen)
+            p.grad = g.clone()
+            q.grad = c[:p.numel()].view(p.shape).detach()
+            q.grad.copy_(g)
+        o_ref.step()
+        o_mine.step()
+        assert len(o_mine._tables[0]) == 1          # one table, built once
+    assert o_mine.device_step_count() == steps
+    for p, q in zip(ref, mine):
+        torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-6 * float(p.abs().max()))
+
+
+def test_adamw_shared_gradient_buffer_emulated():
+    with emu.active():
+        run_adamw_shared_buffer(torch.device('cpu'))
+
+
 def test_adamw_skips_params_without_grad_and_rejects_cpu():
     with emu.active():
         a, b = torch.nn.Parameter(torch.ones(10)), torch.nn.Parameter(torch.ones(10))
@@ -58,3 +88,48 @@ def test_adamw_skips_params_without_grad_and_rejects_cpu():
 @pytest.mark.gpu
 def test_adamw_gpu():
     run_adamw(torch.device('cuda:0'), steps=6)
+    run_adamw_shared_buffer(torch.device('cuda:0'), steps=6)
+
+
+@pytest.mark.gpu
+def test_training_step_captured_in_a_graph_matches_eager():
+    """forward + backward + AdamW captured once in a torch.cuda.CUDAGraph: three replays == three eager steps
+    (the optimizer's step count lives on the device, so the bias correction advances inside the replays)."""
+    from oracle import recipe as R
+    dev = torch.device('cuda:0')
+    st = R.layer_state(1, seed=31)
+    x = R.synth_input('gx', (1, 4, 256, 14, 14), seed=32).to(dev)
+    gy = torch.zeros(1, 4, 256, 14, 14, device=dev)
+    gy[:, -1] = R.synth_input('gg', (1, 256, 14, 14), seed=33, scale=1e-3).to(dev)
+
+    def make():
+        m = V.BasicLayer3d3(dim=256, depth=1, num_heads=8, window_size=7, expand_size=3, pool_method='fc', focal_level=2,
+                            focal_window=5, focal_l_clips=[1, 2, 3], focal_kernel_clips=[7, 5, 3])
+        m.load_state_dict(st, strict=False)
+        m.to(dev)
+        return m, V.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+
+    def body(m, o):
+        o.zero_grad(set_to_none=True)
+        m(x).backward(gy)
+        o.step()
+
+    me, oe = make()
+    for _ in range(5):
+        body(me, oe)
+    mg, og = make()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            body(mg, og)                      # warm-up steps 1, 2 (eager, on the side stream)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body(mg, og)                          # capture only: nothing runs, step 3 happens at the first replay
+    for _ in range(3):
+        g.replay()                            # steps 3, 4, 5
+    torch.cuda.synchronize()
+    assert og.device_step_count() == 5
+    for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
+        torch.testing.assert_close(b.detach(), a.detach(), rtol=1e-5, atol=1e-7, msg=k)

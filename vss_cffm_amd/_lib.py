@@ -75,6 +75,7 @@ SIGNATURES = {
     'cffm_gtc_attn_fwd': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_gtc_attn_bwd': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_adamw_step': (ci, [vp, ci, cd, cd, cd, cd, cd, ci, vp]),
+    'cffm_adamw_step_dev': (ci, [vp, ci, vp, cd, cd, cd, cd, cd, vp, vp]),
 }
 
 

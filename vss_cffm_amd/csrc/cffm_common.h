@@ -39,8 +39,12 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
     emu::launch(dim3 grid, dim3 block, (shmem), [=]() { kernel(__VA_ARGS__); })
 #else
 #define CFFM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#ifdef CFFM_NULL_LAUNCH   // profiling builds only: no kernel is launched (host-side cost of a step without the device work)
+#define CFFM_LAUNCH(kernel, grid, block, shmem, stream, ...) (void)0
+#else
 #define CFFM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3 grid, dim3 block, (shmem), (stream), __VA_ARGS__)
+#endif
 #endif
 
 // ---- wave (64 lanes) reductions ------------------------------------------------------------------

@@ -571,6 +571,19 @@ int cffm_adamw_step(const cffm_adamw_chunk* chunks, int nchunks, double lr, doub
     return 0;
 }
 
+int cffm_adamw_step_dev(const cffm_adamw_chunk* chunks, int nchunks, const float* grad_base, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, float* state, void* stream) {
+    if (nchunks <= 0) return 0;
+    REQUIRE(chunks && state, "adamw_step_dev: null");
+    PROF(ST_ADAMW);
+    CFFM_LAUNCH(k_adamw_tick, (1), (1), 0, (hipStream_t)stream, state, lr, beta1, beta2);
+    CFFM_LAUNCH(k_adamw_dev, ((unsigned)nchunks), (256), 0, (hipStream_t)stream, (const AdamwChunk*)chunks, grad_base,
+                (float)(1.0 - lr * weight_decay), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                (const float*)state);
+    CHECK_LAUNCH("adamw_dev");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- CFFM++ (GTC) stages
 int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
                        long nrows, void* stream) {

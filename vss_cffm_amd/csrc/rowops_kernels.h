@@ -483,3 +483,40 @@ __global__ void __launch_bounds__(256) k_adamw(const AdamwChunk* __restrict__ ch
         c.p[e] = c.p[e] * decay - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
     }
 }
+
+// Graph-capturable variant: the step count and the two bias-correction factors live in device memory (state[0] = t as a
+// float, state[1] = lr / (1 - b1^t), state[2] = 1 / sqrt(1 - b2^t)); k_adamw_tick advances them on the stream, so a captured
+// training step replays with the right t every time.  `grad_base` != NULL: the chunk table's g field is a BYTE OFFSET from
+// it (the layer's gradients share one buffer whose address may change from step to step -- the table never does).
+__global__ void k_adamw_tick(float* __restrict__ state, double lr, double beta1, double beta2) {
+    const double t = (double)state[0] + 1.0;
+    state[0] = (float)t;
+    state[1] = (float)(lr / (1.0 - pow(beta1, t)));
+    state[2] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
+}
+__global__ void __launch_bounds__(256) k_adamw_dev(const AdamwChunk* __restrict__ chunks, const float* __restrict__ grad_base, float decay,
+                                                    float beta1, float beta2, float omb1, float omb2, float eps,
+                                                    const float* __restrict__ state) {
+    AdamwChunk c = chunks[blockIdx.x];
+    if (grad_base) c.g = (const float*)((const char*)grad_base + (uintptr_t)c.g);
+    const float step_size = state[1], inv_sqrt_bc2 = state[2];
+    const bool vec = (((uintptr_t)c.p | (uintptr_t)c.g | (uintptr_t)c.m | (uintptr_t)c.v) & 15) == 0;
+    const long n4 = vec ? c.n / 4 : 0;
+    for (long e = threadIdx.x; e < n4; e += 256) {
+        f32x4 p = ((const f32x4*)c.p)[e], m = ((const f32x4*)c.m)[e], v = ((const f32x4*)c.v)[e];
+        const f32x4 g = ((const f32x4*)c.g)[e];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = beta1 * m[k] + omb1 * g[k];
+            v[k] = beta2 * v[k] + omb2 * g[k] * g[k];
+            p[k] = p[k] * decay - step_size * (m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps));
+        }
+        ((f32x4*)c.p)[e] = p; ((f32x4*)c.m)[e] = m; ((f32x4*)c.v)[e] = v;
+    }
+    for (long e = 4 * n4 + threadIdx.x; e < c.n; e += 256) {
+        const float g = c.g[e];
+        const float m = beta1 * c.m[e] + omb1 * g, v = beta2 * c.v[e] + omb2 * g * g;
+        c.m[e] = m; c.v[e] = v;
+        c.p[e] = c.p[e] * decay - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    }
+}
