@@ -8,25 +8,27 @@
 // MI355X design (the reference materialises k_all/v_all (48 MB/clip) and the 37 MB attention matrix):
 //  * nothing is materialised: a workgroup owns one (clip, window, head); its 289 K/V rows are gathered
 //    straight from the q/k/v GEMM output through a host-built key table (roll / unfold / cat / masks of
-//    the reference become one int32 row index per key, -1 = unfold zero padding) as 128-B row
-//    segments (one (token, head) slice = exactly one cache line), converted to f16 and staged in LDS;
+//    the reference become one int32 row index per key, -1 = unfold zero padding) as 64-byte f16 row
+//    segments (one (token, head) slice; buffer loads: an absent key is an out-of-range offset that reads as
+//    zeros) and staged in LDS as ROWS;
 //  * blockIdx.x % 8 == head, so (as dispatched today) one XCD serves one head: its L2 holds the 64-ch
 //    slice of every token and the per-head bias table, and neighbouring windows' overlapping
 //    ring / pooled keys hit in that L2;
 //  * QK^T is computed transposed (S^T = K Q^T, one 16x16x32 f16 MFMA per 16 keys since hd = 32 is
 //    exactly one K-step) so the softmax row lives in the registers of 4 lanes: the reduction is
 //    76 in-register ops + 2 wave shuffles, and P (un-normalised, <= 1) feeds the PV MFMA as the B
-//    operand straight from registers (the k-slot <-> key bijection is shared with the V^T image
-//    in LDS), accumulating in f32.  f16 operands / f32 accumulate keep the block output within
-//    ~1e-4 of the fp32 reference (bf16 would miss the 1e-3 contract: SURVEY.md fact 10).
-//  * LDS rows are padded to 80 B (K, Q) so the 16 rows of an MFMA fragment hit 16 distinct 16-B
-//    slots (conflict-free ds_read_b128), and the transposed image has a row stride of 4*odd dwords
-//    (conflict-free ds_read_b64).
+//    operand straight from registers, accumulating in f32; the A operand V^T is read out of the V ROWS
+//    with the LDS transpose read (`ds_read_b64_tr_b16`, att_tr_frag; the k-slot <-> key bijection of P
+//    is built into its row arithmetic) -- no transposed image is written by any kernel of this file.
+//    f16 operands / f32 accumulate keep the block output within ~1e-4 of the fp32 reference (bf16
+//    would miss the 1e-3 contract: SURVEY.md fact 10).
+//  * LDS rows are 64 B with the 16-byte chunk index XOR-ed by 2*((row>>3)&1) (ATT_ROW): a ds_read_b128
+//    is served in non-contiguous 16-lane groups, which no row padding can make conflict-free.
 #pragma once
 #include "cffa_kernels.h"
 
 #ifndef FWD_ABLATE
-#define FWD_ABLATE 0  // profiling only: 1 no bias loads, 2 no K/V gathers, 4 no softmax exp, 8 no PV MFMA, 16 no V^T LDS writes
+#define FWD_ABLATE 0  // (historical: the forward's ablation switches; measured results are in DESIGN.md)
 #endif
 #define ATT_KS_STRIDE 32   // halfs per K/V/Q/dO row in LDS: 64 bytes, no padding, 16-byte chunks XOR-swizzled (ATT_ROW)
 // element offset of 16-byte chunk `chunk` (0..3) of row `row`.  A ds_read_b128 is served in four NON-contiguous groups of 16
@@ -34,8 +36,6 @@
 // padding the rows cannot make the MFMA fragment reads conflict-free (80-byte rows: 45 % of the LDS cycles were bank
 // conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE); flipping chunk bit 1 on rows 8..15 of every 16 does.
 #define ATT_ROW(row, chunk) ((row) * ATT_KS_STRIDE + 8 * ((chunk) ^ (2 * (((row) >> 3) & 1))))
-#define ATT_VT_STRIDE 328  // halfs per row of a [32][keys] transposed image (164 dwords = 4*41)
-#define ATT_QT_STRIDE 72   // halfs per row of a [32][64 queries] transposed image (36 dwords = 4*9)
 
 // the 4 key-validity flags (0 / -inf) of this lane's keys 16t + 4g .. +3
 #ifndef VFLAG_RD
@@ -110,7 +110,7 @@ __device__ long long g_bwq_t[8 * 8];
 
 // A window's K / V rows on their way from the f16 q|k|v rows to LDS, held in registers so that the gather of window w+1
 // can be in flight while window w is multiplied (kv_load: key-table entries, then the 16-byte row segments; kv_store:
-// K, V row-major (+ optionally K^T as packed key pairs) and the key-validity flags, which come from the same entries).
+// K, V rows and the key-validity flags, which come from the same entries).
 template <int NTHREADS>
 struct KvRegs {
     static constexpr int NW = NTHREADS / 64, NIT = (CFFM_NKEY_PAD / 2 + NW * 16 - 1) / (NW * 16);
@@ -172,9 +172,10 @@ __device__ __forceinline__ void kv_load(KvRegs<NTHREADS>& r, buf_t rs_qkv, uint3
 }
 __device__ __forceinline__ buf_t qkv_rsrc(const Geo& G, const h16* qkv) { return buf_make(qkv, (uint32_t)((long)G.B * G.RC * 768 * 2)); }
 __device__ __forceinline__ uint32_t qkv_soff_k(const Geo& G, int b, int h) { return (uint32_t)(((long)b * G.RC * 768 + 256 + h * CFFM_HD) * 2); }
-// TR: 0 = K and V rows only; 1 = K rows, V rows and K^T (packed key pairs); 2 = K rows and V^T (no V rows)
-template <int NTHREADS, int TR>
-__device__ __forceinline__ void kv_store(const KvRegs<NTHREADS>& r, f16* Ks, f16* Vs, f16* Tt, float* vflag, int tid) {
+// registers -> LDS: K and V rows (ATT_ROW layout) and the key-validity flags.  (No transposed image: the kernels read the
+// transposed views they need with the LDS transpose read, att_tr_frag.)
+template <int NTHREADS>
+__device__ __forceinline__ void kv_store(const KvRegs<NTHREADS>& r, f16* Ks, f16* Vs, float* vflag, int tid) {
     constexpr int NW = KvRegs<NTHREADS>::NW, NIT = KvRegs<NTHREADS>::NIT;
     const int lane = tid & 63, wave = tid >> 6, c4 = lane >> 4;
 #pragma unroll
@@ -185,35 +186,17 @@ __device__ __forceinline__ void kv_store(const KvRegs<NTHREADS>& r, f16* Ks, f16
             if (c4 == 0) { vflag[n0] = r.src0[it] >= 0 ? 0.f : -INFINITY; vflag[n0 + 1] = r.src1[it] >= 0 ? 0.f : -INFINITY; }
             *(f16x8*)(Ks + ATT_ROW(n0, c4)) = r.k0[it];
             *(f16x8*)(Ks + ATT_ROW((n0 + 1), c4)) = r.k1[it];
-            if (TR != 2) {
-                *(f16x8*)(Vs + ATT_ROW(n0, c4)) = r.v0[it];
-                *(f16x8*)(Vs + ATT_ROW((n0 + 1), c4)) = r.v1[it];
-            }
-            if (TR) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    f16x2 pk;
-                    pk[0] = TR == 1 ? r.k0[it][e] : r.v0[it][e];
-                    pk[1] = TR == 1 ? r.k1[it][e] : r.v1[it][e];
-                    *(f16x2*)(Tt + (8 * c4 + e) * ATT_VT_STRIDE + n0) = pk;
-                }
-            }
+            *(f16x8*)(Vs + ATT_ROW(n0, c4)) = r.v0[it];
+            *(f16x8*)(Vs + ATT_ROW((n0 + 1), c4)) = r.v1[it];
         }
     }
 }
-// the key columns 304..327 of a transposed image are never written by kv_store: zero them once per kernel
 template <int NTHREADS>
-__device__ __forceinline__ void kt_pad_zero(f16* Tt, int tid) {
-    for (int e = tid; e < 32 * (ATT_VT_STRIDE - CFFM_NKEY_PAD); e += NTHREADS)
-        Tt[(e / (ATT_VT_STRIDE - CFFM_NKEY_PAD)) * ATT_VT_STRIDE + CFFM_NKEY_PAD + e % (ATT_VT_STRIDE - CFFM_NKEY_PAD)] = (f16)0.f;
-}
-template <int NTHREADS, int TR>
-__device__ __forceinline__ void stage_kv(buf_t rs_qkv, uint32_t soff_k, const int* __restrict__ ksrc, f16* Ks, f16* Vs, f16* Kt,
-                                         float* vflag, int tid) {
+__device__ __forceinline__ void stage_kv(buf_t rs_qkv, uint32_t soff_k, const int* __restrict__ ksrc, f16* Ks, f16* Vs, float* vflag,
+                                         int tid) {
     KvRegs<NTHREADS> r;
     kv_load<NTHREADS>(r, rs_qkv, soff_k, ksrc, tid);
-    if (TR) kt_pad_zero<NTHREADS>(Kt, tid);
-    kv_store<NTHREADS, TR>(r, Ks, Vs, Kt, vflag, tid);
+    kv_store<NTHREADS>(r, Ks, Vs, vflag, tid);
 }
 
 // the query-owner lane's own operands of one window: Q fragment, dO / O (8 channels), LSE, destination pixel
@@ -293,7 +276,7 @@ __global__ void __launch_bounds__(256, BWQ_OCC) k_cfm_attn_bwd_q(Geo G, const h1
     for (int wb = wb0; wb < wb1; ++wb) {
         const int w = wb % G.nW, b = wb / G.nW;
         BWQ_STAMP(0);
-        kv_store<256, 0>(kv, Ks, Vs, nullptr, vflag, tid);
+        kv_store<256>(kv, Ks, Vs, vflag, tid);
         BWQ_STAMP(1);
         const f16x8 qfrag = ql.qfrag;
         const f32x4 do0 = ql.do0, do1 = ql.do1, o0 = ql.o0, o1 = ql.o1;
@@ -406,7 +389,7 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
     kv_load<256>(kv, rs_qkv, qkv_soff_k(G, b, h), key_src + w * CFFM_NKEY_PAD, tid);
     const f16x8 qfrag = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)(w * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
                                   (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
-    kv_store<256, 0>(kv, Ks, Vs, nullptr, vflag, tid);
+    kv_store<256>(kv, Ks, Vs, vflag, tid);
     // the wave's 19 bias tiles (L2-resident table) fly across the barrier and land in the MFMA C operands
     const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
     f32x4 s[19];
@@ -507,7 +490,7 @@ __global__ void __launch_bounds__(256, FWP_OCC) k_cfm_attn_fwd_p(Geo G, const h1
     }
     for (int wb = wb0; wb < wb1; ++wb) {
         const int b = wb / G.nW;
-        kv_store<256, 0>(kv, Ks, Vs, nullptr, vflag, tid);
+        kv_store<256>(kv, Ks, Vs, vflag, tid);
         const f16x8 qfrag = qn;
         const int dst = dstc;
         __syncthreads();
@@ -601,7 +584,7 @@ __global__ void __launch_bounds__(256, 3) k_cfm_attn_bwd_kv(Geo G, const h16* __
     if (t0 >= 0) { const long off = ((long)b * G.HW + t0) * CFFM_C + h * CFFM_HD + 4 * c; r0 = ld4(dao + off); o0 = ld4(ao + off); }
     if (t1 >= 0) { const long off = ((long)b * G.HW + t1) * CFFM_C + h * CFFM_HD + 4 * c; r1 = ld4(dao + off); o1 = ld4(ao + off); }
     if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid];
-    stage_kv<256, 0>(qkv_rsrc(G, qkv), qkv_soff_k(G, b, h), ksrc, Ks, Vs, nullptr, vflag, tid);
+    stage_kv<256>(qkv_rsrc(G, qkv), qkv_soff_k(G, b, h), ksrc, Ks, Vs, vflag, tid);
     if (tid < 128) {   // Q rows and the transposed Q image
         *(f16x8*)(Qs + ATT_ROW((2 * qp), qc)) = q0;
         *(f16x8*)(Qs + ATT_ROW((2 * qp + 1), qc)) = q1;
