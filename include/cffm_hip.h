@@ -160,7 +160,8 @@ int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* p
 /* dy_tgt [B,256,H0,W0] -> dx [B,4,256,H0,W0] (gradient through the hot path only; the pass-through of
  * frames 0..2 is the caller's torch.cat) and every parameter gradient of every block */
 int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
-                        const float* dy_tgt_nchw, float* dx_nchw, const int* key_src, const int* q_dst,
+                        const float* dy_tgt_nchw, long dy_bs /* elements between clips: 256*H0*W0 when dy is dense, 4x that
+                        when it is the last-frame slice of a [B,4,256,H0,W0] gradient */, float* dx_nchw, const int* key_src, const int* q_dst,
                         const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream);
 
 /* ---- parameter update of the training step (the reference trains the head with AdamW, lr 6e-5, betas (0.9, 0.999),

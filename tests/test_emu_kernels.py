@@ -158,3 +158,24 @@ def run_gtc_case(case, device):
             assert H.rel_err(pg[key[8:]].sum(0), ref) < 1e-4, key
         elif key.startswith('p/gsum1/'):
             assert H.rel_err(pg[key[8:]].sum(1), ref) < 1e-4, key
+
+
+def test_upstream_gradient_slice_is_taken_with_its_stride():
+    """backward(gradient on the whole [B,4,256,H,W] output) hands the last-frame slice over with its batch stride (no copy):
+    same results as the dense gradient the sliced-loss form produces."""
+    g = H.load_golden('layer_b2_8x8_d2')
+    b, h, w, depth, st, x, gy = H.layer_case_inputs(g)
+    outs = []
+    for strided in (False, True):
+        params = flat_params(st, depth)
+        with emu.active():
+            y = ops.cffm_layer(x, depth, params)
+            if strided:
+                full = torch.zeros_like(y)
+                full[:, -1] = gy
+                y.backward(full)
+            else:
+                (y[:, -1] * gy).sum().backward()
+        outs.append([p.grad.clone() for p in params])
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)

@@ -796,7 +796,7 @@ int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* p
 }
 
 int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
-                        const float* dy_tgt_nchw, float* dx_nchw, const int* key_src, const int* q_dst,
+                        const float* dy_tgt_nchw, long dy_bs, float* dx_nchw, const int* key_src, const int* q_dst,
                         const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream) {
     REQUIRE(g && params && grads && dy_tgt_nchw && dx_nchw && saved && scratch && depth >= 1, "layer_backward: bad arguments");
     cffm_block_ws L;
@@ -807,7 +807,8 @@ int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* 
     const float* blk0 = saved + up((long)g->B * 4 * img);
     float* dxs = scratch + S.dxs;   // NHWC gradient stack [B,4,HW,C]
     float* dcur = scratch + S.a;    // gradient of the current block's output target [B,HW,C]
-    TRY(cffm_transpose(dy_tgt_nchw, dcur, g->B, CFFM_C, (int)HW, img, img, stream));
+    REQUIRE(dy_bs >= img, "layer_backward: dy batch stride %ld < %ld", dy_bs, img);
+    TRY(cffm_transpose(dy_tgt_nchw, dcur, g->B, CFFM_C, (int)HW, dy_bs, img, stream));
     for (int i = depth - 1; i >= 0; --i) {
         const float* ws = blk0 + (long)i * L.total;
         const float* tgt = (i == 0) ? xs + 3 * img : blk0 + (long)(i - 1) * L.total + L.x2;

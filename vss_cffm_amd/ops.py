@@ -143,7 +143,13 @@ class _LayerFn(torch.autograd.Function):
         depth = ctx.depth
         b, h0, w0 = ctx.geom_args
         g = make_geom(lib, b, h0, w0)
-        dy = dy.contiguous()
+        # dy is normally the last-frame slice of the [B,4,256,H,W] upstream gradient (the torch.cat in cffm_layer): dense inside
+        # a clip, 4 images apart between clips -- handed over with its batch stride instead of being copied
+        img = 256 * h0 * w0
+        if dy.dim() == 4 and dy.stride()[1:] == (h0 * w0, w0, 1) and (b == 1 or dy.stride(0) >= img):
+            dy_bs = dy.stride(0) if b > 1 else img
+        else:
+            dy, dy_bs = dy.contiguous(), img
         # one allocation for every parameter gradient (16-byte aligned slices), returned as views
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)
@@ -152,7 +158,7 @@ class _LayerFn(torch.autograd.Function):
         dx = torch.empty(b, 4, 256, h0, w0, dtype=torch.float32, device=dy.device)
         pstructs = block_structs(params, depth)
         gstructs = block_structs(grads, depth)
-        _lib.check(lib.cffm_layer_backward(C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src),
+        _lib.check(lib.cffm_layer_backward(C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx), _ptr(key_src),
                                            _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch),
                                            _stream(dy)), lib)
         return (dx, None) + tuple(grads)
