@@ -53,9 +53,16 @@ def _require_device(t, what):
         raise _lib.CffmError('%s: fp32 expected, got %s' % (what, t.dtype))
 
 
+_geom_cache = {}
+
+
 def make_geom(lib, b, h0, w0):
-    g = _lib.Geom()
-    _lib.check(lib.cffm_geom_init(C.byref(g), b, h0, w0), lib)
+    key = (id(lib), b, h0, w0)
+    g = _geom_cache.get(key)
+    if g is None:
+        g = _lib.Geom()
+        _lib.check(lib.cffm_geom_init(C.byref(g), b, h0, w0), lib)
+        _geom_cache[key] = g
     return g
 
 
@@ -122,7 +129,6 @@ class _LayerFn(torch.autograd.Function):
         for p in params:
             if not p.is_contiguous() or p.dtype != torch.float32:
                 raise _lib.CffmError('cffm layer parameters must be contiguous float32')
-        params = [p.detach() for p in params]
         g = make_geom(lib, b, h0, w0)
         key_src, q_dst, inv_ptr, inv_idx = device_tables(h0, w0, x.device)
         saved = torch.empty(lib.cffm_layer_saved_floats(C.byref(g), depth), dtype=torch.float32, device=x.device)
