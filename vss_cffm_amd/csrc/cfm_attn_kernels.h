@@ -86,6 +86,9 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; 
 // dO is rescaled by a power of two (per wave / per window) so every f16 gradient operand sits near 1 (training-size gradients
 // of 1e-6 would otherwise flush to zero in f16); results are scaled back in f32.
 // =====================================================================================================
+#ifndef BWK_OCC
+#define BWK_OCC 3
+#endif
 #ifndef BWK_ABLATE
 #define BWK_ABLATE 0   // profiling builds only: 1 staging only (no key-tile loop), 2 no partial-row stores
 #endif
@@ -545,7 +548,7 @@ __global__ void __launch_bounds__(256, FWP_OCC) k_cfm_attn_fwd_p(Geo G, const h1
     }
 }
 
-__global__ void __launch_bounds__(256, 3) k_cfm_attn_bwd_kv(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
+__global__ void __launch_bounds__(256, BWK_OCC) k_cfm_attn_bwd_kv(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
                                                              const int* __restrict__ q_dst, const float* __restrict__ biasT,
                                                              const float* __restrict__ ao, const float* __restrict__ dao,
                                                              const float* __restrict__ lse_in, float* __restrict__ dkv_part) {
