@@ -179,3 +179,44 @@ def test_upstream_gradient_slice_is_taken_with_its_stride():
         outs.append([p.grad.clone() for p in params])
     for a, c in zip(*outs):
         assert torch.equal(a, c)
+
+
+def run_block_api_check(lib, device):
+    """The block-level entry points (cffm_block_forward / cffm_block_backward, NHWC operands, caller-owned workspaces)
+    give what the layer-level op gives for depth 1."""
+    g_ = H.load_golden('layer_b1_8x8_d1')
+    b, h, w, depth, st, x, gy = H.layer_case_inputs(g_)
+    assert depth == 1
+    x, gy = x.to(device), gy.to(device)
+    params = [p.detach().to(device).requires_grad_(True) for p in flat_params(st, 1)]
+    y = ops.cffm_layer(x, 1, params)
+    (y[:, -1] * gy).sum().backward()
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
+    g = ops.make_geom(lib, b, h, w)
+    L = ops.block_ws_layout(lib, g)
+    key_src, q_dst, inv_ptr, inv_idx = ops.device_tables(h, w, device)
+    hw, img = h * w, h * w * 256
+    xs = x.permute(0, 1, 3, 4, 2).contiguous()                       # NHWC stack [B,4,HW,C]
+    ws = torch.zeros(L.total, device=device)
+    scratch = torch.zeros(lib.cffm_layer_scratch_floats(C.byref(g)), device=device)
+    plain = [p.detach() for p in params]
+    ps = ops.block_ptrs(plain)
+    tgt = C.c_void_p(xs.data_ptr() + 3 * img * 4)
+    assert lib.cffm_block_forward(C.byref(g), C.byref(ps), P(xs), 4 * img, tgt, 4 * img, P(key_src), P(q_dst), P(ws), P(scratch), stream) == 0
+    out_rows = ws[L.x2:L.x2 + b * img].view(b, hw, 256)
+    want = y[:, -1].detach().permute(0, 2, 3, 1).reshape(b, hw, 256)
+    assert torch.equal(out_rows, want)
+    grads = [torch.zeros_like(p) for p in plain]
+    gs = ops.block_ptrs(grads)
+    dout = gy.permute(0, 2, 3, 1).reshape(b * hw, 256).contiguous()
+    dxs = torch.zeros(b, 4, hw, 256, device=device)
+    dtgt = C.c_void_p(dxs.data_ptr() + 3 * img * 4)
+    assert lib.cffm_block_backward(C.byref(g), C.byref(ps), C.byref(gs), P(xs), 4 * img, tgt, 4 * img, P(key_src), P(q_dst), P(inv_ptr),
+                                   P(inv_idx), P(ws), P(dout), P(dxs), 4 * img, 0, dtgt, 4 * img, P(scratch), stream) == 0
+    for p, gr in zip(params, grads):
+        assert torch.equal(gr, p.grad)
+
+
+def test_block_api_matches_layer_api():
+    with emu.active():
+        run_block_api_check(emu.lib(), torch.device('cpu'))

@@ -188,6 +188,12 @@ def test_wrong_frame_count_and_cpu_input_raise():
         m(torch.zeros(1, 4, 256, 8, 8))            # CPU tensor: no fallback
 
 
+def test_block_level_abi_on_device():
+    from tests.test_emu_kernels import run_block_api_check
+    from vss_cffm_amd import _lib
+    run_block_api_check(_lib.get(), dev())
+
+
 def test_stage_level_on_device():
     from tests.test_emu_kernels import run_stage_checks
     from vss_cffm_amd import _lib

@@ -133,3 +133,39 @@ def test_training_step_captured_in_a_graph_matches_eager():
     assert og.device_step_count() == 5
     for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
         torch.testing.assert_close(b.detach(), a.detach(), rtol=1e-5, atol=1e-7, msg=k)
+
+
+def run_adamw_host_step_entry(lib, device):
+    """cffm_adamw_step: the entry point with the step count on the host (absolute addresses in the table)."""
+    import ctypes as C
+    import numpy as np
+    gen = torch.Generator().manual_seed(8)
+    p0 = torch.randn(5000, generator=gen)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.clone().to(device), torch.zeros(5000, device=device), torch.zeros(5000, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
+    for t in (1, 2, 3):
+        g = torch.randn(5000, generator=gen)
+        ref.grad = g.clone()
+        opt.step()
+        gd = g.to(device)
+        off = np.arange(0, 5000, 2048, dtype=np.int64)
+        tab = np.stack([p.data_ptr() + 4 * off, gd.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off,
+                        np.minimum(2048, 5000 - off)], axis=1)
+        tabd = torch.from_numpy(tab).to(device)
+        assert lib.cffm_adamw_step(C.c_void_p(tabd.data_ptr()), tab.shape[0], 1e-2, 0.9, 0.99, 1e-8, 0.05, t, stream) == 0
+        if device.type == 'cuda':
+            torch.cuda.synchronize()
+    torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert lib.cffm_adamw_step(C.c_void_p(tabd.data_ptr()), tab.shape[0], 1e-2, 0.9, 0.99, 1e-8, 0.05, 0, stream) != 0   # t >= 1
+
+
+def test_adamw_host_step_entry_emulated():
+    with emu.active():
+        run_adamw_host_step_entry(emu.lib(), torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_adamw_host_step_entry_gpu():
+    run_adamw_host_step_entry(_lib.get(), torch.device('cuda:0'))
