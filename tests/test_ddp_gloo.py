@@ -107,6 +107,11 @@ def _worker_flat(rank, world, port, out):
         (m(x)[:, -1] * g).sum().backward()
         n = V.distributed.allreduce_gradients(list(m.parameters()))
         assert n == 1, n   # every gradient of the layer lives in one buffer -> exactly one collective
+        # a gradient that owns its storage next to the layer's: general path, two collectives
+        extra = torch.nn.Parameter(torch.ones(5))
+        extra.grad = torch.full((5,), float(rank + 1))
+        assert V.distributed.allreduce_gradients(list(m.parameters()) + [extra]) == 2
+        assert torch.allclose(extra.grad, torch.full((5,), 1.5))
         V.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01).step()
     torch.save({k: p.grad.clone() for k, p in m.named_parameters()}, os.path.join(out, 'fgrad%d.pt' % rank))
     torch.save({k: p.detach().clone() for k, p in m.named_parameters()}, os.path.join(out, 'fparam%d.pt' % rank))

@@ -26,27 +26,42 @@ def allreduce_gradients(params, average=True):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     world = dist.get_world_size()
-    # gradients that share a storage (autograd hands the layer's gradient views over as aliases of the one buffer
-    # `_LayerFn.backward` allocated) are reduced as one flat span of that storage
-    spans, singles = {}, []
-    for p in params:
-        g = p.grad
-        if g is None:
-            continue
-        if not g.is_contiguous():
-            singles.append(g)
-            continue
-        st = g.untyped_storage()
-        lo, hi = g.storage_offset(), g.storage_offset() + g.numel()
-        key = (st.data_ptr(), g.dtype)
-        if key in spans:
-            spans[key][1] = min(spans[key][1], lo)
-            spans[key][2] = max(spans[key][2], hi)
-        else:
-            spans[key] = [g, lo, hi]
-    bases = list(singles)
-    for g, lo, hi in spans.values():
-        bases.append(torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage(), lo, (hi - lo,)))
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return 0
+    bases = None
+    # fast path: every gradient is a dense slice of the FIRST one's storage (autograd hands the layer's gradient views over as
+    # aliases of the one buffer `_LayerFn.backward` allocated) -> one flat span of that storage, found with address
+    # arithmetic only
+    g0 = grads[0]
+    st = g0.untyped_storage()
+    s_lo, s_hi = st.data_ptr(), st.data_ptr() + st.nbytes()
+    lo, hi, ok = s_hi, s_lo, True
+    for g in grads:
+        a = g.data_ptr()
+        e = a + 4 * g.numel()
+        if g.dtype != torch.float32 or not g.is_contiguous() or a < s_lo or e > s_hi:
+            ok = False
+            break
+        lo, hi = min(lo, a), max(hi, e)
+    if ok:
+        bases = [torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, (lo - s_lo) // 4, ((hi - lo) // 4,))]
+    else:   # general case: group by storage, reduce each span (or each non-contiguous gradient on its own)
+        spans, bases = {}, []
+        for g in grads:
+            if not g.is_contiguous():
+                bases.append(g)
+                continue
+            gst = g.untyped_storage()
+            l, h = g.storage_offset(), g.storage_offset() + g.numel()
+            key = (gst.data_ptr(), g.dtype)
+            if key in spans:
+                spans[key][1] = min(spans[key][1], l)
+                spans[key][2] = max(spans[key][2], h)
+            else:
+                spans[key] = [g, l, h]
+        for g, l, h in spans.values():
+            bases.append(torch.empty(0, dtype=g.dtype, device=g.device).set_(g.untyped_storage(), l, (h - l,)))
     avg_op = getattr(dist.ReduceOp, 'AVG', None) if (average and dist.get_backend() == 'nccl') else None
     for t in bases:
         if avg_op is not None:
