@@ -285,6 +285,23 @@ __device__ __forceinline__ f16x4 lds_tr4(const f16* p) {
 #endif
 }
 
+// the same for bf16 data (operand images of the Linear GEMMs)
+__device__ __forceinline__ bf16x4 lds_tr4_bf16(const bf16* p) {
+#ifdef CFFM_EMU
+    struct Quad { bf16 e[4]; } mine = {{p[0], p[1], p[2], p[3]}};
+    const int lane = emu::lane_linear() & 63;
+    auto s = emu::deposit(&mine, sizeof(mine));
+    bf16x4 r;
+    for (int j = 0; j < 4; ++j) r[j] = reinterpret_cast<const Quad*>(s[(lane & 48) + 4 * j + ((lane & 15) >> 2)])->e[lane & 3];
+    emu::release();
+    return r;
+#else
+    typedef __bf16 bf16x4_t __attribute__((__vector_size__(4 * sizeof(__bf16))));
+    const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p);
+    return __builtin_bit_cast(bf16x4, v);
+#endif
+}
+
 // ordering point between LDS writes and reads of *other lanes of the same wave* (wave-private LDS
 // scratch; LDS operations of one wave execute in order, this only pins the compiler / the emulator)
 __device__ __forceinline__ void wave_lds_sync() {

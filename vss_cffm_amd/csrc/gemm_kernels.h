@@ -66,12 +66,16 @@ __device__ __forceinline__ f32x4 mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) 
 #define GEMM_TLD 68 // floats per row of the epilogue transposition tile (64 + 4 pad)
 
 // LDS image of an operand tile (ROWS x 32 k), hi and lo parts:
-//   k-contiguous operand (TR = false): [ROWS][BK + 8] bf16, fragment = one ds_read_b128 of 8 consecutive k;
-//   row-contiguous operand (TR = true): k-PAIR interleaved dwords [BK/2 k-pairs][ROWS + 4]: a thread that loaded the same
-//     4 rows at k and k+1 (two coalesced 16-B loads) packs (k, k+1) per row into one dword and writes 16 B at once;
-//     a fragment is 4 x ds_read_b32 (k = 8g + 2jj + {0,1}), 16 lanes reading 16 consecutive dwords (conflict-free,
-//     the +4 pad puts the two lane groups of a half-wave on disjoint banks).
-#define GEMM_TS(ROWS) ((ROWS) + 4)
+//   k-contiguous operand (TR = false): [ROWS][32] bf16 with swizzled chunks (above), fragment = one ds_read_b128 of 8
+//     consecutive k;
+//   row-contiguous operand (TR = true): kept as it is loaded -- 4 consecutive rows at one k are 8 contiguous bytes -- in
+//     [ROWS/16 row blocks][32 k-rows][16 rows] subtiles (1 KiB + 32 B pad each), and the fragment (8 k of row l&15) is read
+//     with two LDS transpose reads (lds_tr4_bf16: 4 k-rows x 16 rows each), no k-pair packing when the tile is stored.
+//     Inside a subtile k-row k sits at position p(k) = k with bits 2 and 3 swapped: the 32 lanes served together read
+//     k in {8g..8g+3} for g = 0, 1 (or 2, 3), whose 32-byte segments must fall on 8 different 32-byte bank groups; the
+//     32-byte pad per subtile does the same for the 8 row blocks a ds_write_b64 of one k touches.
+#define GEMM_TSUB 528   // bf16 elements per row-block subtile: 32 * 16 + 16 pad
+#define GEMM_TPOS(k) ((((k) & 3) | ((((k) >> 3) & 1) << 2) | ((((k) >> 2) & 1) << 3) | ((k) & 16)))
 template <int ROWS, int BK>
 struct TileRegs { f32x4 v[ROWS * BK / 1024]; };
 
@@ -161,14 +165,15 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __
         for (int it = 0; it < ROWS * BK / 2048; ++it) {
             const int item = tid + 256 * it;
             const int kp = item / (ROWS / 4), row = 4 * (item % (ROWS / 4));
-            bf16x4 h0, l0, h1, l1;
-            if (pre) { unsplit4(r.v[2 * it], h0, l0); unsplit4(r.v[2 * it + 1], h1, l1); }
-            else { split4(r.v[2 * it], h0, l0); split4(r.v[2 * it + 1], h1, l1); }
-            u32x4 ph, pl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { ph[e] = pack_bf16(h0[e], h1[e]); pl[e] = pack_bf16(l0[e], l1[e]); }
-            *(u32x4*)((uint32_t*)hi + kp * GEMM_TS(ROWS) + row) = ph;
-            *(u32x4*)((uint32_t*)lo + kp * GEMM_TS(ROWS) + row) = pl;
+            for (int h = 0; h < 2; ++h) {
+                bf16x4 hh, ll;
+                if (pre) unsplit4(r.v[2 * it + h], hh, ll);
+                else split4(r.v[2 * it + h], hh, ll);
+                const int o = (row >> 4) * GEMM_TSUB + GEMM_TPOS(2 * kp + h) * 16 + (row & 15);
+                *(bf16x4*)(hi + o) = hh;
+                *(bf16x4*)(lo + o) = ll;
+            }
         }
     }
 }
@@ -177,11 +182,15 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __
 template <int ROWS, bool TR, int BK>
 __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int row, int g, int kk /* 0 or 32 */) {
     if (!TR) return *(const bf16x8*)(img + row * BK + kk + 8 * (g ^ GEMM_SWZ(row)));
-    u32x4 d;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) d[jj] = ((const uint32_t*)img)[(kk / 2 + 4 * g + jj) * GEMM_TS(ROWS) + row];
+    // row = (16-row block base) + (lane & 15): this lane points at k-row 8g + (l15 >> 2) (+4 for the second read), rows
+    // 4 (l15 & 3) .. +3 of the block, and receives k = 8g .. 8g+7 of its own row l15 -- the k-slot order of the other layout
+    const int l15 = row & 15;
+    const bf16* sub = img + (row >> 4) * GEMM_TSUB + 4 * (l15 & 3);
+    const int k0 = kk + 8 * g + (l15 >> 2);
+    const bf16x4 a = lds_tr4_bf16(sub + GEMM_TPOS(k0) * 16);
+    const bf16x4 b = lds_tr4_bf16(sub + GEMM_TPOS(k0 + 4) * 16);
     bf16x8 f;
-    __builtin_memcpy(&f, &d, 16);
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
     return f;
 }
 
