@@ -733,9 +733,23 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
         }                                                                                                                 \
     } while (0)
     // x2 = x1 + act W2^T + b2
-    DX_GEMM(false, dout, p->fc2_w, w2_s, dact, NP, CFFM_C, CFFM_HID);
-    // act = gelu(hraw + b1); hraw = z2 W1^T   (dact becomes dh, in split-4 storage: only GEMMs read it)
-    TRY(gelu_bwd_impl(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, sp, stream));
+    // act = gelu(hraw + b1); hraw = z2 W1^T: the GELU backward runs in the epilogue of the fc2 input-gradient GEMM (dact is
+    // never materialised; what is stored is dh, in split-4 storage since only GEMMs read it, plus column-sum records of it)
+    if (sp) {
+        PROF(ST_GEMM);
+        const int nrec = GEMM_GELUBWD_RECORDS(NP);
+        float* part = red_scratch((size_t)nrec * CFFM_HID, st);
+        REQUIRE(part, "block_backward: scratch allocation failed");
+        REQUIRE(!gemm_nn_gelubwd_split_pre<true>(dout, w2_s, ws + L.hraw, p->fc1_b, dact, part, NP, CFFM_C, CFFM_HID, st),
+                "block_backward: fc2 input-gradient gemm failed");
+        RedSegs segs;
+        segs.nseg = 0;
+        seg_add(segs, 0, CFFM_HID, gr->fc1_b, 0);
+        reduce_records(part, nrec, CFFM_HID, CFFM_HID, segs, st);
+    } else {
+        TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
+        TRY(gelu_bwd_impl(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, 0, stream));
+    }
     DX_GEMM(true, dact, p->fc1_w, w1_s, dz2, NP, CFFM_HID, CFFM_C);
     // z2 = LN2(x1); x1 also feeds the residual
     TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1,

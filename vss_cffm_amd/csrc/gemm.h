@@ -12,7 +12,8 @@ __global__ void k_sum_splits(const float* __restrict__ part, int nsplit, long n,
 
 template <bool A_T, bool B_T, int EPI = 0, bool A_PRE = false, bool B_PRE = false>
 static int gemm_split_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int ksplit,
-                             hipStream_t st, const float* bias = nullptr, float* aux = nullptr, int prefer_big = 0) {
+                             hipStream_t st, const float* bias = nullptr, float* aux = nullptr, int prefer_big = 0,
+                             float* aux2 = nullptr) {
     int klen = ((K + ksplit - 1) / ksplit + 63) / 64 * 64;
     ksplit = (K + klen - 1) / klen;
     float* out = C;
@@ -40,7 +41,7 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
     GEMM_BIG_LDS(BM_, BN_, BK_, PF_)                                                                                                   \
     CFFM_LAUNCH((k_gemm_split<BM_, BN_, BK_, A_T, B_T, EPI, PF_, A_PRE, B_PRE>), ((unsigned)(((N + BN_ - 1) / BN_) * ((M + BM_ - 1) / BM_) * ksplit)), (256), \
                 GEMM_LDS(BM_, BN_, BK_), st, A, \
-                B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux); } while (0)
+                B, out, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux, aux2); } while (0)
     // measured on MI355X (scripts/gemm_bench.py, CFFM-B1 shapes): 128x128 wins when it already gives >= 384 workgroups
     // (qkv / fc1 forward, the 1024-wide input gradient), 64x64 otherwise; prefetch depth beyond the listed one is neutral.
     static int sel = -1;   // tuning aid: CFFM_GEMM_SEL = 1 -> 128x64 tiles, 2 -> 64x128, 3 -> 128x128 for the small cases
@@ -95,6 +96,15 @@ static int gemm_nt_qkv16_split_pre(const float* x_s, const float* w_s, const flo
 // dx[M,K] = dy[M,N] w[N,K]: output cols = K, contraction = N
 static int gemm_nn_split(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
     return gemm_split_launch<false, true>(dy, w, dx, (int)M, K, N, N, K, K, 1, st);
+}
+// dh[M,K] = (dy[M,N] w[N,K]) * gelu'(hraw + b1), in split-4 storage or plain; part[2 * ceil(M/128) * 2][K] = column-sum
+// records of dh (the bias gradient of fc1).  Always 128x128 tiles (the record layout is theirs).
+#define GEMM_GELUBWD_RECORDS(M) (4 * (((M) + 127) / 128))
+template <bool SPLIT_OUT>
+static int gemm_nn_gelubwd_split_pre(const float* dy, const float* w_s, const float* hraw, const float* b1, float* dh, float* part,
+                                     long M, int N, int K, hipStream_t st) {
+    return gemm_split_launch<false, true, SPLIT_OUT ? 7 : 6, false, true>(dy, w_s, dh, (int)M, K, N, N, K, K, 1, st, b1,
+                                                                          const_cast<float*>(hraw), 1, part);
 }
 template <bool DY_PRE>
 static int gemm_nn_split_pre(const float* dy, const float* w_s, float* dx, long M, int N, int K, hipStream_t st) {

@@ -215,6 +215,8 @@ __device__ __forceinline__ bf16x8 frag_read(const bf16* __restrict__ img, int ro
 // EPI: 0 plain (+bias) | 1 GELU: C = raw product (saved for backward), aux = gelu(raw + bias) | 2 residual: C = aux + raw + bias
 //      3 q|k|v: nothing in C; aux (h16 [M,N]) = f16(raw + bias), the q third (cols < 256) also times 32^-0.5 -- exactly the
 //        values the attention kernels used to form from the fp32 product, stored once at half the bytes
+//      5 as 1 with aux written in split-4 storage | 6 GELU backward: C = product * gelu'(aux + bias), aux2 = column-sum records
+//        of C (one per 32-row slab of a wave) | 7 as 6 with C in split-4 storage
 // XCD-aware placement (speed only): workgroup b runs on XCD b % 8, each XCD with its own 4 MiB L2.  The 1-D grid is
 // re-numbered so that every XCD owns a CONTIGUOUS run of (k-slice, row panel, column tile) triples, column tile
 // fastest: the tiles that share an A row panel / a k-slice then hit the same L2 instead of eight different ones.
@@ -228,7 +230,7 @@ template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF>
 __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                           int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                           const float* __restrict__ bias, float* __restrict__ aux, int bx, int by, int bz,
-                                          bool a_pre = false, bool b_pre = false) {
+                                          bool a_pre = false, bool b_pre = false, float* __restrict__ aux2 = nullptr) {
     bf16* Ah = (bf16*)smem;
     bf16* Al = Ah + GEMM_IMG(BM, BK);
     bf16* Bh = Al + GEMM_IMG(BM, BK);
@@ -363,6 +365,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
         const int c4 = 4 * (lane % LPR), col = n0 + wc + c4;
         f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (bias && bz == 0 && col + 3 < N) bv = *(const f32x4*)(bias + col);
+        f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f};   // EPI 6 / 7: this lane's column sums of the result over its rows
 #pragma unroll
         for (int it = 0; it < 32 * LPR / 64; ++it) {
             const int rl = lane / LPR + (64 / LPR) * it, row = m0 + wr + 32 * half + rl;
@@ -374,6 +377,14 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                 f32x4 a;
                 for (int e = 0; e < 4; ++e) a[e] = gelu_erf(v[e] + bv[e]);
                 *(f32x4*)(aux + (long)row * ldc + col) = (EPI == 5) ? split4_pack(a) : a;   // 5: act in split-4 storage
+                continue;
+            }
+            if ((EPI == 6 || EPI == 7) && col + 3 < N) {          // GELU backward: result = product * gelu'(aux + bias)
+                const f32x4 hr = *(const f32x4*)(aux + (long)row * ldc + col) + bv;
+                f32x4 o;
+                for (int e = 0; e < 4; ++e) o[e] = v[e] * gelu_erf_grad(hr[e]);
+                *(f32x4*)dst = (EPI == 7) ? split4_pack(o) : o;      // 7: split-4 storage
+                csum += o;
                 continue;
             }
             if (EPI == 3 && col + 3 < N) {
@@ -396,18 +407,27 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                     if (col + e < N) dst[e] = v[e] + ((bias && bz == 0 && col + 3 >= N) ? bias[col + e] : 0.f);
             }
         }
+        if (EPI == 6 || EPI == 7) {
+            // column sums of this wave's 32 rows (bias gradient of fc1): the LPR-lane groups of the wave hold different rows of
+            // the same columns; one record per (row tile, wave row, half): aux2[((by * 2 + (wave >> 1)) * (MT / 2) + half)][N]
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = LPR; m < 64; m <<= 1) csum[e] += __shfl_xor(csum[e], m, 64);
+            if (lane < LPR && col + 3 < N)
+                *(f32x4*)(aux2 + ((long)(by * 2 + (wave >> 1)) * (MT / 2) + half) * N + col) = csum;
+        }
     }
 }
 
 template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF, bool A_PRE = false, bool B_PRE = false>
 __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
-                                                     const float* __restrict__ bias, float* __restrict__ aux) {
+                                                     const float* __restrict__ bias, float* __restrict__ aux, float* __restrict__ aux2) {
     CFFM_DYN_SMEM(smem);
     const int lin = xcd_linear_id();
     const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
     gemm_tile<BM, BN, BK, A_T, B_T, EPI, PF>(smem, A, B, C, M, N, K, lda, ldb, ldc, klen, split_stride, bias, aux, lin % ntn,
-                                             (lin / ntn) % ntm, lin / (ntn * ntm), A_PRE, B_PRE);
+                                             (lin / ntn) % ntm, lin / (ntn * ntm), A_PRE, B_PRE, aux2);
 }
 
 // Up to GEMM_GROUP_MAX independent weight-gradient GEMMs (dw = dy^T x, <T,T>, 128x128 tiles) in ONE launch.  The four of a
