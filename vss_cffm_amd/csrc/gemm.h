@@ -145,7 +145,9 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
     // one slice length for every problem: ~480 workgroups (two per CU are co-resident: 80 KB of LDS each)
     long units = 0;
     for (int p = 0; p < n; ++p) units += (long)(pr[p].N / 128) * (pr[p].K / 128) * ((pr[p].M + 31) / 32);
-    long ksteps = (units + 479) / 480;
+    static int target = -1;   // tuning aid: CFFM_GROUP_WGS
+    if (target < 0) { const char* e = getenv("CFFM_GROUP_WGS"); target = e ? atoi(e) : 480; if (target < 1) target = 480; }
+    long ksteps = (units + target - 1) / target;
     if (ksteps < 4) ksteps = 4;
     const int klen = (int)ksteps * 32;
     GemmGroup G;

@@ -435,6 +435,9 @@ __global__ void __launch_bounds__(256) k_gemm_split(const float* __restrict__ A,
 // ~20 k-slices to occupy 256 CUs, i.e. 12 K-steps per workgroup between a prologue and a 64 KB partial-tile epilogue, and
 // its own partial-sum pass.  None of them feeds the backward chain, so they are deferred and share one grid: ~480
 // workgroups with one common slice length (2-3x longer), a third of the partial traffic and one summation launch.
+#ifndef GROUP_PF
+#define GROUP_PF 1
+#endif
 #define GEMM_GROUP_MAX 4
 struct GemmGroup {
     const float* A[GEMM_GROUP_MAX];
@@ -453,6 +456,6 @@ __global__ void __launch_bounds__(256) k_gemm_group_tt(GemmGroup G) {
         if (q + 1 < G.n && lin >= G.wg_end[q]) p = q + 1;
     if (p > 0) lin -= G.wg_end[p - 1];
     const int M = G.M[p], N = G.N[p], ntn = N / 128, ntm = M / 128;
-    gemm_tile<128, 128, 32, true, true, 0, 1>(smem, G.A[p], G.B[p], G.C[p], M, N, G.K[p], M, N, N, G.klen, (long)M * N, nullptr,
+    gemm_tile<128, 128, 32, true, true, 0, GROUP_PF>(smem, G.A[p], G.B[p], G.C[p], M, N, G.K[p], M, N, N, G.klen, (long)M * N, nullptr,
                                               nullptr, lin % ntn, (lin / ntn) % ntm, lin / (ntn * ntm), G.a_pre[p] != 0, G.b_pre[p] != 0);
 }
