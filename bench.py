@@ -87,8 +87,9 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='clips per GPU (reference samples_per_gpu=2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-timing', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='capture the whole step (forward + backward + AdamW) in one HIP graph and time '
-                    'replays: the step then does not depend on host speed; the roofline kernel is timed in a separate eager pass')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying the '
+                    'step from HIP graphs (the default): the step is then bound by host speed (0.94-1.17 ms measured vs 0.93 replayed)')
+    ap.add_argument('--graph', action='store_true', help='replay from HIP graphs without the replay-vs-eager calibration (default: calibrate)')
     ap.add_argument('--ddp', action='store_true', help='wrap in torch DistributedDataParallel instead of the one-buffer all-reduce')
     ap.add_argument('--spinup-steps', type=int, default=1000, help='untimed device spin-up steps before the warmup steps (~1 s)')
     args = ap.parse_args()
@@ -141,10 +142,13 @@ def main():
     gy[:, -1] = torch.randn(b, 256, GRID, GRID, generator=gen) / (b * 256 * GRID * GRID)
     gy = gy.to(dev)
 
-    def step():
+    def fwd_bwd():
         opt.zero_grad(set_to_none=True)
         y = model(x)
         y.backward(gy)
+
+    def eager_step():
+        fwd_bwd()
         if world > 1 and not args.ddp:
             V.distributed.allreduce_gradients(params_list)
         opt.step()
@@ -154,22 +158,89 @@ def main():
     # --spinup-steps times before the W warmup steps the contract asks for (a step COUNT, not a duration: under DDP every
     # rank must issue the same number of all-reduces).  Reported in config.spinup_steps.
     for _ in range(args.spinup_steps):
-        step()
+        eager_step()
     torch.cuda.synchronize(dev)
-    eager_step = step
-    if args.graph:
-        # One HIP graph for the whole step (the optimizer's step count lives on the device, so replays are real steps).
-        # Side-stream warm-up as torch.cuda.graph requires, then capture; `step` becomes a replay.
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                eager_step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            eager_step()
-        step = graph.replay
+
+    stage_timing = not args.no_stage_timing
+    nst = lib.cffm_profile_stage_count()
+    names = [lib.cffm_profile_stage_name(i).decode() for i in range(nst)]
+    ms_buf, n_buf = (C.c_float * nst)(), (C.c_int * nst)()
+    attn_bit = 1 << names.index('cfm_attn_fwd')
+
+    # The step is launch-bound on the host (~75 launches + autograd glue per 0.93 ms of GPU work), so by default it is
+    # replayed from HIP graphs: one graph for the whole step (the optimizer's step count lives on the device, so replays are
+    # real steps) at N = 1; for N > 1 the gradient all-reduce stays an ordinary RCCL call between two graphs (forward +
+    # backward | AdamW).  The roofline kernel's two event records per launch are captured INTO the graph (event-record
+    # nodes), so it is still timed live, inside the timed region.  --eager / --ddp run the same step launch by launch.
+    step, use_graph, graph_events, graph_note = eager_step, False, False, None
+    if not (args.eager or args.ddp):
+        def capture(with_events):
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):          # side-stream warm-up, as torch.cuda.graph requires
+                for _ in range(3):
+                    eager_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            lib.cffm_profile_collect_graph(ms_buf, n_buf, 1)
+            lib.cffm_profile_enable(attn_bit if with_events else 0)
+            try:
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    if world > 1:
+                        fwd_bwd()
+                    else:
+                        eager_step()
+                if world == 1:
+                    return ga.replay
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    opt.step()
+            finally:
+                lib.cffm_profile_enable(0)
+                lib.cffm_profile_collect(ms_buf, n_buf)
+
+            def replay_step():
+                ga.replay()
+                V.distributed.allreduce_gradients(params_list)
+                gb.replay()
+            return replay_step
+
+        for with_events in ((True, False) if stage_timing else (False,)):
+            try:
+                step = capture(with_events)
+                step()
+                torch.cuda.synchronize(dev)
+                if with_events:
+                    assert lib.cffm_profile_collect_graph(ms_buf, n_buf, 0) == 0, lib.cffm_last_error().decode()
+                    assert n_buf[names.index('cfm_attn_fwd')] == DEPTH, list(n_buf)
+                use_graph, graph_events = True, with_events
+                break
+            except Exception as e:   # noqa: BLE001  (an unsupported capture must not cost the measurement: fall back)
+                graph_note = '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
+                sys.stderr.write('bench.py: HIP graph capture (events=%s) failed, falling back: %s\n' % (with_events, graph_note))
+                step = eager_step
+                torch.cuda.synchronize(dev)
+    # Replay is only kept if it is not slower than launching from the host on THIS box (untimed calibration, every rank
+    # takes the same decision): e.g. several processes time-slicing one device have been seen to replay graphs very slowly.
+    graph_cal = None
+    if use_graph and not args.graph:
+        def cal(fn, n=20):
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(dev)
+            t = torch.tensor([(time.perf_counter() - t) / n * 1e3], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        graph_cal = {'replay_ms': round(cal(step), 4), 'eager_ms': round(cal(eager_step), 4)}
+        if graph_cal['replay_ms'] > 1.02 * graph_cal['eager_ms']:
+            step, use_graph, graph_events = eager_step, False, False
+            graph_note = 'replay slower than eager launches on this box'
     for _ in range(args.warmup):
         step()
 
@@ -181,13 +252,9 @@ def main():
 
     # Live timing of the roofline kernel only (2 launches/step -> 4 event records/step: negligible).  Timing every
     # stage costs ~190 event records per step (~25 % of a 1.5 ms step), so the full breakdown is a separate pass below.
-    stage_timing = not args.no_stage_timing
-    nst = lib.cffm_profile_stage_count()
-    names = [lib.cffm_profile_stage_name(i).decode() for i in range(nst)]
-    ms_buf, n_buf = (C.c_float * nst)(), (C.c_int * nst)()
-    if stage_timing and not args.graph:   # (graph replays carry no event records: --graph times the kernel afterwards)
+    if stage_timing and not use_graph:
         lib.cffm_profile_collect(ms_buf, n_buf)
-        lib.cffm_profile_enable(1 << names.index('cfm_attn_fwd'))
+        lib.cffm_profile_enable(attn_bit)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -195,18 +262,28 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     attn_ms, attn_n, all_ms, all_n, bsteps = 0.0, 0, None, None, min(args.steps, 20)
+    ai = names.index('cfm_attn_fwd')
     if stage_timing:
-        if args.graph:   # eager pass of the same step right after the timed replays, only the roofline kernel timed
+        if use_graph and graph_events:
+            # the graph's own event nodes: the last step of the timed region, then `bsteps` more replays read one by one
+            # (an event pair holds the latest replay only; reading needs a sync, which is why this is not done per timed step)
+            for k in range(bsteps + 1):
+                if k:
+                    step()
+                    torch.cuda.synchronize(dev)
+                assert lib.cffm_profile_collect_graph(ms_buf, n_buf, 0) == 0, lib.cffm_last_error().decode()
+                attn_ms, attn_n = attn_ms + ms_buf[ai], attn_n + n_buf[ai]
+        else:
+            if use_graph:   # no event nodes in the graph: eager pass of the same step right after the timed replays
+                lib.cffm_profile_collect(ms_buf, n_buf)
+                lib.cffm_profile_enable(attn_bit)
+                for _ in range(args.steps):
+                    eager_step()
+                torch.cuda.synchronize(dev)
+            lib.cffm_profile_enable(0)
             lib.cffm_profile_collect(ms_buf, n_buf)
-            lib.cffm_profile_enable(1 << names.index('cfm_attn_fwd'))
-            for _ in range(args.steps):
-                eager_step()
-            torch.cuda.synchronize(dev)
-        lib.cffm_profile_enable(0)
-        lib.cffm_profile_collect(ms_buf, n_buf)
-        i = names.index('cfm_attn_fwd')
-        attn_ms, attn_n = ms_buf[i], n_buf[i]
-        # separate instrumented pass: every stage, not part of `value` (all ranks step: DDP all-reduces inside)
+            attn_ms, attn_n = ms_buf[ai], n_buf[ai]
+        # separate instrumented pass: every stage, not part of `value` (all ranks step: all-reduces inside)
         lib.cffm_profile_enable(-1 if rank == 0 else 0)
         for _ in range(bsteps):
             eager_step()
@@ -245,9 +322,12 @@ def main():
                     'algorithmic_bytes_per_launch': by, 'avg_launch_us': round(avg_us, 2), 'launches_timed': attn_n,
                     'mfma_achieved_tflops': round(tf, 2), 'mfma_peak_tflops': MFMA_F16_PEAK_TF,
                     'mfma_frac': round(tf / MFMA_F16_PEAK_TF, 5),
-                    'note': 'achieved = SURVEY 8(d) algorithmic bytes (fp32 q/k/v + output: 18.37 MB per clip-block) / average '
-                            'launch time, timed live with HIP events on the launch stream inside the timed region; q/k/v are '
-                            'stored as f16, so the real minimum traffic is 11.6 MB per clip-block'}
+                    'note': ('achieved = SURVEY 8(d) algorithmic bytes (fp32 q/k/v + output: 18.37 MB per clip-block) / average '
+                            'launch time, timed live with HIP events on the launch stream (%s); q/k/v are '
+                            'stored as f16, so the real minimum traffic is 11.6 MB per clip-block') % (
+                                ('event-record nodes inside the replayed graph: last step of the timed region + %d following replays' % bsteps)
+                                if (use_graph and graph_events) else
+                                ('eager pass right after the timed graph replays' if use_graph else 'inside the timed region'))}
         out = {
             'metric': 'clips/sec (fwd+bwd) CFFM-B1 480x480 T=4 hot path (CFFA+CFM, decoder_focal depth 2)',
             'value': round(world * b * args.steps / dt, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
@@ -255,7 +335,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f32 accumulate; MFMA operands: split-bf16 (hi+lo, ~2^-17) in the Linear GEMMs, f16 in QK^T/AV',
             'data': 'synthetic',
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
-                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': bool(args.graph),
+                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if world == 1 else 'forward+backward graph | RCCL all-reduce | AdamW graph'),
                        'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one all-reduce of the flat gradient buffer per step') if world > 1 else 'none'},
             'roofline': roof, 'kernels': stages,
             'kernels_note': 'per-stage HIP-event times from a separate instrumented pass of %d steps after the timed region '

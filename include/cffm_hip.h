@@ -74,6 +74,10 @@ int cffm_profile_enable(int stage_mask); /* bit i = stage i; 0 off; -1 all (pert
 int cffm_profile_stage_count(void);
 const char* cffm_profile_stage_name(int i);
 int cffm_profile_collect(float* ms /*[stage_count]*/, int* calls /*[stage_count]*/); /* synchronises, sums, clears */
+/* Stages enabled while the caller's stream is being CAPTURED into a HIP graph put their event pairs into the graph as
+ * event-record nodes (re-recorded by every replay).  This reads, per stage, the intervals of the most recent replay;
+ * the pairs stay valid for the life of the graph; reset != 0 forgets them (before capturing another graph). */
+int cffm_profile_collect_graph(float* ms /*[stage_count]*/, int* calls /*[stage_count]*/, int reset);
 
 /* ---- stage level (each is one kernel; used by the parity tests and by the block functions) ---- */
 /* dst[n][c][r] = src[n][r][c] for n < batch (element strides src_bs / dst_bs between batches) */

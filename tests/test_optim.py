@@ -135,6 +135,52 @@ def test_training_step_captured_in_a_graph_matches_eager():
         torch.testing.assert_close(b.detach(), a.detach(), rtol=1e-5, atol=1e-7, msg=k)
 
 
+@pytest.mark.gpu
+def test_stage_events_captured_into_a_graph_are_readable_after_each_replay():
+    """cffm_profile_collect_graph: a stage enabled while the stream is being captured leaves event-record NODES in the
+    graph; after a replay the pair of every captured launch is readable (bench.py's live roofline timing under replay)."""
+    import ctypes as C
+    from oracle import recipe as R
+    from vss_cffm_amd import _lib
+    lib = _lib.get()
+    dev = torch.device('cuda:0')
+    depth = 2
+    m = V.BasicLayer3d3(dim=256, depth=depth, num_heads=8, window_size=7, expand_size=3, pool_method='fc', focal_level=2,
+                        focal_window=5, focal_l_clips=[1, 2, 3], focal_kernel_clips=[7, 5, 3])
+    m.load_state_dict(R.layer_state(depth, seed=41), strict=False)
+    m.to(dev)
+    x = R.synth_input('gx', (1, 4, 256, 14, 14), seed=42).to(dev)
+    nst = lib.cffm_profile_stage_count()
+    names = [lib.cffm_profile_stage_name(i).decode() for i in range(nst)]
+    ia = names.index('cfm_attn_fwd')
+    ms, n = (C.c_float * nst)(), (C.c_int * nst)()
+    with torch.no_grad():
+        want = m(x).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)
+        torch.cuda.current_stream().wait_stream(s)
+        assert lib.cffm_profile_collect_graph(ms, n, 1) == 0
+        lib.cffm_profile_enable(1 << ia)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                y = m(x)
+        finally:
+            lib.cffm_profile_enable(0)
+            lib.cffm_profile_collect(ms, n)
+    for _ in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        assert lib.cffm_profile_collect_graph(ms, n, 0) == 0, lib.cffm_last_error().decode()
+        assert n[ia] == depth and sum(n) == depth
+        assert 0.0 < ms[ia] < 50.0
+    torch.testing.assert_close(y, want, rtol=0, atol=0)
+    assert lib.cffm_profile_collect_graph(ms, n, 1) == 0
+    assert lib.cffm_profile_collect_graph(ms, n, 0) == 0 and sum(n) == 0
+
+
 def run_adamw_host_step_entry(lib, device):
     """cffm_adamw_step: the entry point with the step count on the host (absolute addresses in the table)."""
     import ctypes as C

@@ -45,6 +45,7 @@ SIGNATURES = {
     'cffm_profile_stage_count': (ci, []),
     'cffm_profile_stage_name': (C.c_char_p, [ci]),
     'cffm_profile_collect': (ci, [vp, vp]),
+    'cffm_profile_collect_graph': (ci, [vp, vp, ci]),
     'cffm_transpose': (ci, [vp, vp, ci, ci, ci, cl, cl, vp]),
     'cffm_pool_matrix': (ci, [P4, vp, vp]),
     'cffm_pool_matrix_bwd': (ci, [vp, P4, vp]),

@@ -57,13 +57,44 @@ static hipEvent_t prof_event() {
     (void)hipEventCreate(&e);
     return e;
 }
+// Event pairs recorded while the stream was being captured into a HIP graph: they become event-record NODES of the graph,
+// every replay re-records them, and they stay readable for the life of the graph.  The node is added explicitly
+// (capture info -> hipGraphAddEventRecordNode -> new capture dependency): the HIP 7.0 runtime PyTorch bundles rejects
+// hipEventRecordWithFlags(hipEventRecordExternal), the explicit form works on 7.0 and 7.2 (scripts/graph_bench_check.sh).
+static std::vector<ProfRec> g_prof_graph_recs;
+static bool g_prof_capture_failed = false;
+static hipEvent_t prof_capture_event(hipStream_t st) {
+    hipEvent_t ev = nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    hipGraphNode_t node;
+    bool ok = hipEventCreate(&ev) == hipSuccess
+        && hipStreamGetCaptureInfo_v2(st, &cs, &id, &graph, &deps, &ndeps) == hipSuccess
+        && hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev) == hipSuccess
+        && hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies) == hipSuccess;
+    if (!ok) { g_prof_capture_failed = true; (void)hipGetLastError(); }
+    return ev;
+}
 struct ProfScope {
-    int stage; hipStream_t st; hipEvent_t e0; bool on;
-    ProfScope(int s, void* stream) : stage(s), st((hipStream_t)stream), on((g_prof_mask >> s) & 1u) {
-        if (on) { e0 = prof_event(); (void)hipEventRecord(e0, st); }
+    int stage; hipStream_t st; hipEvent_t e0; bool on, cap;
+    ProfScope(int s, void* stream) : stage(s), st((hipStream_t)stream), on((g_prof_mask >> s) & 1u), cap(false) {
+        if (!on) return;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        cap = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+        if (cap) e0 = prof_capture_event(st);
+        else { e0 = prof_event(); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
-        if (on) { hipEvent_t e1 = prof_event(); (void)hipEventRecord(e1, st); g_prof_recs.push_back({stage, e0, e1}); }
+        if (!on) return;
+        if (cap) {
+            hipEvent_t e1 = prof_capture_event(st);
+            g_prof_graph_recs.push_back({stage, e0, e1});
+        } else {
+            hipEvent_t e1 = prof_event(); (void)hipEventRecord(e1, st); g_prof_recs.push_back({stage, e0, e1});
+        }
     }
 };
 #define PROF(stage) ProfScope prof_scope_(stage, stream)
@@ -97,6 +128,30 @@ int cffm_profile_collect(float* ms /*[count]*/, int* calls /*[count]*/) {
         g_prof_pool.push_back(r.e1);
     }
     g_prof_recs.clear();
+#endif
+    return 0;
+}
+// the event pairs captured INTO a HIP graph (stages enabled while the caller's stream was capturing): per stage, the
+// intervals of the graph's most recent replay (ms) and the number of pairs; synchronises; the pairs stay valid.
+// reset != 0 forgets them (call before capturing another graph).
+int cffm_profile_collect_graph(float* ms /*[count]*/, int* calls /*[count]*/, int reset) {
+    for (int i = 0; i < ST_COUNT; ++i) { ms[i] = 0.f; calls[i] = 0; }
+#ifndef CFFM_EMU
+    if (g_prof_capture_failed) {
+        g_prof_capture_failed = false;
+        g_prof_graph_recs.clear();
+        return fail(-2, "cffm_profile_collect_graph: the runtime refused an event-record node during the capture");
+    }
+    for (auto& r : g_prof_graph_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(-2, "cffm_profile_collect_graph: captured events are not readable (graph not replayed yet?)");
+        }
+        ms[r.stage] += t;
+        calls[r.stage] += 1;
+    }
+    if (reset) { g_prof_graph_recs.clear(); (void)hipGetLastError(); }   // (the events themselves belong to the graph's nodes: not destroyed here)
 #endif
     return 0;
 }
