@@ -94,10 +94,22 @@ def main():
     ap.add_argument('--spinup-steps', type=int, default=1000, help='untimed device spin-up steps before the warmup steps (~1 s)')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (rank 0's JSON): anything a library writes to fd 1 (RCCL prints a version banner there,
+    # flushed at process exit, i.e. after the JSON line, from every rank) is sent to stderr instead.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # CFFM_BENCH_FORCE_DIST is a test hook: the N > 1 code path (process group, parameter broadcast, gradient all-reduce between
+    # the two graphs) with a single rank, so RCCL itself can be exercised on a one-GPU box; never set by the driver.
+    multi = world > 1 or bool(os.environ.get('CFFM_BENCH_FORCE_DIST'))
+    if multi:
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # RCCL on ROCm.  (CFFM_BENCH_BACKEND / CFFM_BENCH_ONE_DEVICE are test hooks: they let the multi-rank control flow of
@@ -124,7 +136,7 @@ def main():
                 p.normal_(0, 0.5)
     layer.to(dev)
     model = layer
-    if world > 1:
+    if multi:
         if args.ddp:   # torch's reducer: 52 per-parameter hooks and bucket copies per step
             model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local_rank], gradient_as_bucket_view=True,
                                                               broadcast_buffers=False)
@@ -149,7 +161,7 @@ def main():
 
     def eager_step():
         fwd_bwd()
-        if world > 1 and not args.ddp:
+        if multi and not args.ddp:
             V.distributed.allreduce_gradients(params_list)
         opt.step()
 
@@ -187,11 +199,11 @@ def main():
             try:
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
-                    if world > 1:
+                    if multi:
                         fwd_bwd()
                     else:
                         eager_step()
-                if world == 1:
+                if not multi:
                     return ga.replay
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, pool=ga.pool()):
@@ -227,14 +239,14 @@ def main():
     if use_graph and not args.graph:
         def cal(fn, n=20):
             torch.cuda.synchronize(dev)
-            if world > 1:
+            if multi:
                 dist.barrier()
             t = time.perf_counter()
             for _ in range(n):
                 fn()
             torch.cuda.synchronize(dev)
             t = torch.tensor([(time.perf_counter() - t) / n * 1e3], dtype=torch.float64, device=dev)
-            if world > 1:
+            if multi:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         graph_cal = {'replay_ms': round(cal(step), 4), 'eager_ms': round(cal(eager_step), 4)}
@@ -246,7 +258,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -291,7 +303,7 @@ def main():
         lib.cffm_profile_enable(0)
         lib.cffm_profile_collect(ms_buf, n_buf)
         all_ms, all_n = list(ms_buf), list(n_buf)
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -335,8 +347,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f32 accumulate; MFMA operands: split-bf16 (hi+lo, ~2^-17) in the Linear GEMMs, f16 in QK^T/AV',
             'data': 'synthetic',
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
-                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if world == 1 else 'forward+backward graph | RCCL all-reduce | AdamW graph'),
-                       'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one all-reduce of the flat gradient buffer per step') if world > 1 else 'none'},
+                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else 'forward+backward graph | RCCL all-reduce | AdamW graph'),
+                       'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one all-reduce of the flat gradient buffer per step') if multi else 'none'},
             'roofline': roof, 'kernels': stages,
             'kernels_note': 'per-stage HIP-event times from a separate instrumented pass of %d steps after the timed region '
                             '(event records on every launch slow the step by ~25 %%, so they are kept out of `value`)' % bsteps,
@@ -345,8 +357,9 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         elif world == 1:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
-    if world > 1:
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
+    if multi:
         dist.destroy_process_group()
 
 

@@ -15,3 +15,12 @@ import json
 j=json.loads(open('gpurun_out/b2.log').read().strip().splitlines()[-1])
 print(j['value'], j['ms_per_step'], j['config'], j['roofline']['avg_launch_us'], j['roofline']['launches_timed'])
 PY
+echo "== RCCL itself, single rank (CFFM_BENCH_FORCE_DIST): two-graph default, torch DDP, eager"
+for v in "" "--ddp" "--eager"; do
+  CFFM_BENCH_FORCE_DIST=1 timeout 400 python bench.py --no-cpu-baseline $v > gpurun_out/br.log 2> gpurun_out/br.err; echo "rc=$? stdout lines=$(wc -l < gpurun_out/br.log)"
+  python - <<'PY'
+import json
+j=json.loads(open('gpurun_out/br.log').read())
+print(j['value'], j['ms_per_step'], j['config']['hip_graph'], j['config']['hip_graph_calibration'], j['config']['grad_allreduce'])
+PY
+done
