@@ -114,7 +114,11 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # RCCL on ROCm.  (CFFM_BENCH_BACKEND / CFFM_BENCH_ONE_DEVICE are test hooks: they let the multi-rank control flow of
         # this script be exercised on a one-GPU box -- every rank on cuda:0, gloo -- they are never set by the driver.)
-        dist.init_process_group(os.environ.get('CFFM_BENCH_BACKEND', 'nccl'))
+        backend = os.environ.get('CFFM_BENCH_BACKEND', 'nccl')
+        dev_id = 0 if os.environ.get('CFFM_BENCH_ONE_DEVICE') else local_rank
+        torch.cuda.set_device(dev_id)
+        # device_id binds the communicator to this rank's GPU up front (no guessing from the global rank at the first barrier)
+        dist.init_process_group(backend, **({'device_id': torch.device('cuda', dev_id)} if backend == 'nccl' else {}))
     assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node %d' % args.gpus
     if os.environ.get('CFFM_BENCH_ONE_DEVICE'):
         local_rank = 0
