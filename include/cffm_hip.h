@@ -145,6 +145,18 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
                       const float* dout, const float* lse, float* dq_raw, float* dkv /* overwritten */, int B, int T, int K,
                       void* stream);
 
+/* ---- SegFormer embedding in front of the hot path, without the 1024-channel concat ----
+ * Replaces cffm_head.py:102-119 (4 x `MLP` embed, 3 x bilinear resize to the 1/4 map, torch.cat, 1x1 `linear_fuse.conv`):
+ * conv(cat_i up_i(W_i c_i + b_i)) = sum_i up_i((Wf_i W_i) c_i) + sum_i Wf_i b_i.  The host embeds every scale once at its own
+ * resolution with the composed matrix (cffm_linear_fwd on token rows) and calls this for the full-resolution pass:
+ *   y [N*H*W,256] (the 1/4-scale embedding on entry) += d[256] + sum_m bilinear(z_m [N*h_m*w_m,256] -> H x W)
+ * with F.interpolate(mode='bilinear', align_corners=False) taps; nmaps <= 3, resize factors <= 16 per dimension. */
+int cffm_segfuse_fwd(float* y, const float* d, const float* const z[3], const int h[3], const int w[3], int nmaps, int N,
+                     int H, int W, void* stream);
+/* the adjoint of the three resizes: dz_m [N*h_m*w_m,256] = up_m^T g, g [N*H*W,256] (gather form, deterministic) */
+int cffm_segfuse_bwd(const float* g, float* const dz[3], const int h[3], const int w[3], int nmaps, int N, int H, int W,
+                     void* stream);
+
 /* ---- block / layer level ---- */
 /* x_ref: NHWC frames 0..2 [B,3,HW,256] (batch stride ref_bs), x_tgt NHWC target [B,HW,256] (stride tgt_bs);
  * writes the block's saved activations into `ws` (layout: cffm_block_ws_layout; ws[x2] is the output). */

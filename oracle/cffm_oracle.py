@@ -294,3 +294,42 @@ def gtc_layer_forward(x, h, w, centers, state, depth=1):
     for i in range(depth):
         x = gtc_block_forward(x, h, w, centers, split_block_params(state, i))
     return x
+
+
+# --------------------------------------------------------------------------- SegFormer embedding (SURVEY.md 8f.1)
+def bilinear_matrix(n_in, n_out, dtype=torch.float32):
+    """[n_out, n_in] matrix of F.interpolate(mode='bilinear', align_corners=False) along one dimension, restated from
+    ATen's rule (UpSample.h area_pixel_compute_source_index; the reference reaches it through mmseg.ops.resize,
+    ops/wrappers.py:8-29): scale = in/out in fp32, src = scale*(dst+0.5)-0.5 clamped at 0, i0 = floor(src),
+    i1 = i0 + (i0 < in-1), weights 1-l and l with l = src - i0."""
+    u = torch.zeros(n_out, n_in, dtype=dtype)
+    scale = np.float32(n_in) / np.float32(n_out)
+    for dst in range(n_out):
+        src = np.float32(scale * np.float32(dst + 0.5)) - np.float32(0.5)
+        src = np.float32(max(src, np.float32(0.)))
+        i0 = min(int(src), n_in - 1)
+        i1 = i0 + (1 if i0 < n_in - 1 else 0)
+        l1 = float(np.float32(src - np.float32(i0)))
+        u[dst, i0] += 1.0 - l1
+        u[dst, i1] += l1
+    return u
+
+
+def segformer_fuse(feats, lin_w, lin_b, fuse_w):
+    """Pre-BatchNorm output of the embedding in front of the hot path, cffm_head.py:102-119, in the reference's own order
+    of operations: per scale `MLP` (flatten -> Linear, :26-37), reshape to a map, bilinear resize of c4, c3, c2 to c1's
+    size (:106-113), torch.cat([_c4, _c3, _c2, _c1], dim=1) (:119), 1x1 `linear_fuse.conv` without bias.
+    feats = [c1, c2, c3, c4] NCHW; lin_w / lin_b in the same order; fuse_w [E, 4E, 1, 1]."""
+    n, _, hh, ww = feats[0].shape
+    dt = feats[0].dtype
+    maps = []
+    for i in (3, 2, 1, 0):
+        c = feats[i]
+        m = F.linear(c.flatten(2).transpose(1, 2), lin_w[i], lin_b[i])             # [N, h*w, E]
+        m = m.permute(0, 2, 1).reshape(n, -1, c.shape[2], c.shape[3])
+        if i:
+            uy, ux = bilinear_matrix(c.shape[2], hh, dt), bilinear_matrix(c.shape[3], ww, dt)
+            m = torch.einsum('yh,nchw,xw->ncyx', uy, m, ux)
+        maps.append(m)
+    cat = torch.cat(maps, dim=1)                                                     # the [N, 4E, H, W] concat
+    return torch.einsum('oc,nchw->nohw', fuse_w.reshape(fuse_w.shape[0], -1), cat)

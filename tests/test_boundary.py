@@ -101,7 +101,13 @@ def run_head_golden(device):
     assert abs(float(loss['acc_seg']) - float(g['acc_seg'])) < 1e-3
     loss['loss_seg'].backward()
     for i, f in enumerate(fg):
-        assert H.rel_err(f.grad.cpu(), g['dfeat%d' % i]) < 5e-3, i
+        # The embedding's 2^-17-level differences can flip the ReLU of a pre-activation that sits within ~1e-6 of zero
+        # (one pixel of the 1024 here); that pixel's gradient then changes by a whole term.  So: every pixel but at most 0.5 %
+        # within 1e-3 of the reference (max-abs over channels, relative to the tensor's max), and no pixel off by more than 5e-2.
+        want = torch.as_tensor(g['dfeat%d' % i]).double()
+        pix = (f.grad.cpu().double() - want).abs().amax(dim=1) / want.abs().max()
+        assert float((pix > 1e-3).double().mean()) <= 5e-3 and float(pix.max()) < 5e-2, (i, float(pix.max()))
+        assert float(pix.median()) < 1e-4, i
     assert head.conv_seg.weight.grad is None      # never used: why the reference needs find_unused_parameters
     # CFFM++
     import tempfile

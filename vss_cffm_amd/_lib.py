@@ -75,6 +75,8 @@ SIGNATURES = {
     'cffm_layer_backward': (ci, [GP, ci, BP, BP, vp, cl, vp, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_gtc_attn_fwd': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_gtc_attn_bwd': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    'cffm_segfuse_fwd': (ci, [vp, vp, vp * 3, ci * 3, ci * 3, ci, ci, ci, ci, vp]),
+    'cffm_segfuse_bwd': (ci, [vp, vp * 3, ci * 3, ci * 3, ci, ci, ci, ci, vp]),
     'cffm_adamw_step': (ci, [vp, ci, cd, cd, cd, cd, cd, ci, vp]),
     'cffm_adamw_step_dev': (ci, [vp, ci, vp, cd, cd, cd, cd, cd, vp, vp]),
 }

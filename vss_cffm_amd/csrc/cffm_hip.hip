@@ -3,6 +3,7 @@
 #include "cfm_attn_kernels.h"
 #include "rowops_kernels.h"
 #include "gtc_kernels.h"
+#include "segfuse_kernels.h"
 #include "gemm.h"
 
 #include <stdarg.h>
@@ -839,6 +840,52 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     reductions.finish();
     CHECK_LAUNCH("block_backward reductions");
     TRY(cffm_pool_matrix_bwd(dM, gr->pool_w, stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- SegFormer embedding
+static int segf_maps(SegfMaps& mp, const int* h, const int* w, int nmaps, int H, int W, const char* who) {
+    if (nmaps < 0 || nmaps > 3 || H < 1 || W < 1) return fail(-1, "%s: bad map count / size", who);
+    mp.cnt = nmaps;
+    for (int m = 0; m < 3; ++m) {
+        mp.z[m] = nullptr; mp.dz[m] = nullptr; mp.h[m] = mp.w[m] = 1; mp.blk_end[m] = 0;
+        if (m >= nmaps) continue;
+        if (h[m] < 1 || w[m] < 1 || (long)H > (long)SEGF_MAX_RATIO * h[m] || (long)W > (long)SEGF_MAX_RATIO * w[m])
+            return fail(-1, "%s: map %d is %dx%d for a %dx%d output (resize factors above %d are not supported)", who, m, h[m], w[m],
+                        H, W, SEGF_MAX_RATIO);
+        mp.h[m] = h[m]; mp.w[m] = w[m];
+    }
+    return 0;
+}
+int cffm_segfuse_fwd(float* y, const float* d, const float* const z[3], const int h[3], const int w[3], int nmaps, int N, int H,
+                     int W, void* stream) {
+    REQUIRE(y && d && N >= 0 && (nmaps == 0 || (z && h && w)), "segfuse_fwd: bad arguments");
+    SegfMaps mp;
+    TRY(segf_maps(mp, h, w, nmaps, H, W, "segfuse_fwd"));
+    for (int m = 0; m < nmaps; ++m) { REQUIRE(z[m], "segfuse_fwd: null map"); mp.z[m] = z[m]; }
+    const long rows = (long)N * H * W;
+    if (!rows) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    CFFM_LAUNCH(k_segfuse_fwd, ((unsigned)((rows + 3) / 4)), (256), 0, st, y, d, mp, N, H, W);
+    CHECK_LAUNCH("segfuse_fwd");
+    return 0;
+}
+int cffm_segfuse_bwd(const float* g, float* const dz[3], const int h[3], const int w[3], int nmaps, int N, int H, int W,
+                     void* stream) {
+    REQUIRE(g && N >= 0 && nmaps >= 1 && dz && h && w, "segfuse_bwd: bad arguments");
+    SegfMaps mp;
+    TRY(segf_maps(mp, h, w, nmaps, H, W, "segfuse_bwd"));
+    long blocks = 0;
+    for (int m = 0; m < nmaps; ++m) {
+        REQUIRE(dz[m], "segfuse_bwd: null map");
+        mp.dz[m] = dz[m];
+        blocks += ((long)N * h[m] * w[m] + 3) / 4;
+        mp.blk_end[m] = (int)blocks;
+    }
+    if (!blocks) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    CFFM_LAUNCH(k_segfuse_bwd, ((unsigned)blocks), (256), 0, st, g, mp, N, H, W);
+    CHECK_LAUNCH("segfuse_bwd");
     return 0;
 }
 

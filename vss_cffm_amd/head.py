@@ -7,8 +7,9 @@ contract and state_dict keys, around the MI355X hot path.
 * ``BaseDecodeHead_clips_flow``                     <- decode_head.py:513-835 (ctor contract, losses)
 * ``CrossEntropyLoss`` / ``accuracy``               <- losses/cross_entropy_loss.py:141, losses/accuracy.py:4
 
-Only ``decoder_focal`` / ``decoder_swin`` run in libcffm_hip.so; the SegFormer MLP decoder, the 1x1
-classifiers, the resizes and the losses around them are stock PyTorch (out of the hot path, SURVEY 8f "next").
+``decoder_focal`` / ``decoder_swin`` (the hot path) and the SegFormer embedding in front of them (``_fuse``: SURVEY 8f.1,
+``ops.segformer_fuse``) run in libcffm_hip.so; BatchNorm, the 1x1 classifiers, the remaining resizes and the losses are
+stock PyTorch (SURVEY 8f "next").
 mmcv is absent on both boxes, so ``ConvModule`` / ``resize`` are re-provided with the same parameter names.
 """
 import glob
@@ -19,6 +20,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .modules import BasicLayer3d3, BasicLayer_cluster
+from . import _lib
+from .ops import segformer_fuse
 from .registry import HEADS, LOSSES, build_loss
 
 
@@ -207,9 +210,21 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
         self.linear_pred2 = nn.Conv2d(e * 2, self.num_classes, kernel_size=1)
         self.decoder_focal = _focal_layer(e, dp['depths'])
 
+    # 'hip': the embedding + resize + concat + 1x1 conv collapse into per-scale GEMMs with composed weights and one
+    # full-resolution pass in libcffm_hip.so (ops.segformer_fuse: no 1024-channel concat) for GPU tensors -- it raises when
+    # the library is missing; 'torch': the reference's own op sequence in stock PyTorch (what CPU tensors get, like every
+    # other part of the head outside libcffm_hip.so; also the A/B partner in the tests).
+    fuse_impl = 'hip'
+
     def _fuse(self, inputs):
         """cffm_head.py:102-119: 4 x (linear embed -> resize to 1/4) -> concat -> 1x1 conv + BN + ReLU."""
         c1, c2, c3, c4 = self._transform_inputs(inputs)
+        if self.fuse_impl == 'hip' and (c1.is_cuda or _lib._override is not None):   # (CPU tensors: config 1's CPU plumbing case)
+            lins = (self.linear_c1, self.linear_c2, self.linear_c3, self.linear_c4)
+            x = segformer_fuse([c1, c2, c3, c4], [l.proj.weight for l in lins], [l.proj.bias for l in lins],
+                               self.linear_fuse.conv.weight)
+            x = self.linear_fuse.bn(x)
+            return self.linear_fuse.activate(x)
         n, size = c4.shape[0], c1.shape[2:]
         maps = []
         for lin, c in ((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2), (self.linear_c1, c1)):

@@ -177,6 +177,107 @@ def cffm_layer(x, depth, params):
     return torch.cat([x[:, :-1], y.unsqueeze(1)], dim=1)       # cffm_transformer.py:826
 
 
+# ---------------------------------------------------------------------------------------------- SegFormer embedding
+class _SegFuseFn(torch.autograd.Function):
+    """sum_i resize_i(A_i c_i) + d on token rows: features c_i [N,C_i,h_i,w_i] (c_0 at the output resolution), composed
+    matrices A_i [256,C_i], constant d [256] -> [N,256,H,W] (channels-last memory).  See csrc/segfuse_kernels.h."""
+
+    @staticmethod
+    def forward(ctx, d, *ca):
+        lib = _lib.get()
+        k = len(ca) // 2
+        feats, mats = ca[:k], [a.contiguous() for a in ca[k:]]
+        if not 1 <= k <= 4:
+            raise _lib.CffmError('segformer_fuse: 1..4 feature maps expected, got %d' % k)
+        for c in feats + tuple(mats) + (d,):
+            _require_device(c, 'segformer_fuse operand')
+        n, _, H, W = feats[0].shape
+        st, dev = _stream(feats[0]), feats[0].device
+        toks, zs = [], []
+        for c, a in zip(feats, mats):
+            if c.dim() != 4 or c.shape[0] != n or a.shape != (256, c.shape[1]):
+                raise _lib.CffmError('segformer_fuse: feature %s does not fit matrix %s' % (tuple(c.shape), tuple(a.shape)))
+            c = c.contiguous()
+            ci, p = c.shape[1], c.shape[2] * c.shape[3]
+            t = torch.empty(n * p, ci, dtype=torch.float32, device=dev)        # token rows [N*h*w, C_i]
+            z = torch.empty(n * p, 256, dtype=torch.float32, device=dev)
+            if n * p:
+                _lib.check(lib.cffm_transpose(_ptr(c), _ptr(t), n, ci, p, ci * p, ci * p, st), lib)
+                _lib.check(lib.cffm_linear_fwd(_ptr(t), _ptr(a), _ptr(z), n * p, 256, ci, st), lib)
+            toks.append(t)
+            zs.append(z)
+        hs = (C.c_int * 3)(*([c.shape[2] for c in feats[1:]] + [1] * (4 - k)))
+        ws = (C.c_int * 3)(*([c.shape[3] for c in feats[1:]] + [1] * (4 - k)))
+        zp = (C.c_void_p * 3)(*([z.data_ptr() for z in zs[1:]] + [None] * (4 - k)))
+        y = zs[0]                                                             # updated in place: nothing else needs it
+        if n * H * W:
+            _lib.check(lib.cffm_segfuse_fwd(_ptr(y), _ptr(d.contiguous()), zp, hs, ws, k - 1, n, H, W, st), lib)
+        ctx.save_for_backward(*toks, *mats)
+        ctx.shapes = [tuple(c.shape) for c in feats]
+        return y.view(n, H, W, 256).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.get()
+        shapes = ctx.shapes
+        k = len(shapes)
+        toks, mats = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        n, _, H, W = shapes[0]
+        g = g.permute(0, 2, 3, 1).contiguous()                                # [N,H,W,256] rows (no copy if channels-last)
+        st, dev = _stream(g), g.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        dd = new(256)
+        rows = n * H * W
+        if rows:
+            _lib.check(lib.cffm_colsum(_ptr(g), rows, 256, _ptr(dd), st), lib)
+        else:
+            dd.zero_()
+        dzs = [g.view(rows, 256)] + [new(n * s[2] * s[3], 256) for s in shapes[1:]]
+        if k > 1:
+            hs = (C.c_int * 3)(*([s[2] for s in shapes[1:]] + [1] * (4 - k)))
+            ws = (C.c_int * 3)(*([s[3] for s in shapes[1:]] + [1] * (4 - k)))
+            zp = (C.c_void_p * 3)(*([z.data_ptr() for z in dzs[1:]] + [None] * (4 - k)))
+            if rows:
+                _lib.check(lib.cffm_segfuse_bwd(_ptr(g), zp, hs, ws, k - 1, n, H, W, st), lib)
+        dfeats, dmats = [], []
+        for i, (s, t, a, dz) in enumerate(zip(shapes, toks, mats, dzs)):
+            ci, p = s[1], s[2] * s[3]
+            da = new(256, ci)
+            if n * p:
+                _lib.check(lib.cffm_linear_bwd_weight(_ptr(dz), _ptr(t), _ptr(da), n * p, 256, ci, st), lib)
+            else:
+                da.zero_()
+            dmats.append(da)
+            if ctx.needs_input_grad[1 + i]:
+                dt, dc = new(n * p, ci), new(*s)
+                if n * p:
+                    _lib.check(lib.cffm_linear_bwd_input(_ptr(dz), _ptr(a), _ptr(dt), n * p, 256, ci, st), lib)
+                    _lib.check(lib.cffm_transpose(_ptr(dt), _ptr(dc), n, p, ci, ci * p, ci * p, st), lib)
+                dfeats.append(dc)
+            else:
+                dfeats.append(None)
+        return (dd,) + tuple(dfeats) + tuple(dmats)
+
+
+def segformer_fuse(feats, lin_w, lin_b, fuse_w):
+    """The SegFormer embedding of the CFFM heads without the 1024-channel concat (cffm_head.py:102-119):
+    conv1x1(cat([resize(linear_c4(c4)), resize(linear_c3(c3)), resize(linear_c2(c2)), linear_c1(c1)]), fuse_w).
+
+    feats: [c1, c2, c3, c4] NCHW (c1 = the 1/4-scale map the others are resized to); lin_w / lin_b: the four `MLP.proj`
+    weights [256,C_i] / biases in the same order; fuse_w: `linear_fuse.conv.weight` [256, 4*256, 1, 1] whose input-channel
+    blocks are ordered c4, c3, c2, c1 (the reference's cat order).  Returns the pre-BatchNorm map [N,256,H,W].
+    The composed matrices Wf_i W_i and the constant sum_i Wf_i b_i are plain torch ops (a few MFLOP, autograd gives the
+    gradients of the six original tensors); everything at token scale runs in libcffm_hip.so."""
+    k = len(feats)
+    e = fuse_w.shape[0]
+    if e != 256 or fuse_w.shape[1] != k * e:
+        raise _lib.CffmError('segformer_fuse: fuse weight %s does not fit %d embeddings of 256' % (tuple(fuse_w.shape), k))
+    wf = fuse_w.reshape(e, k, e)
+    mats = [wf[:, k - 1 - i] @ lin_w[i] for i in range(k)]
+    d = sum(wf[:, k - 1 - i] @ lin_b[i] for i in range(k))
+    return _SegFuseFn.apply(d, *feats, *mats)
+
+
 # ---------------------------------------------------------------------------------------------- GTC
 GTC_PARAM_KEYS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.qkv_cluster.weight',
                   'attn.qkv_cluster.bias', 'attn.proj_cluster.weight', 'attn.proj_cluster.bias', 'norm2.weight',
