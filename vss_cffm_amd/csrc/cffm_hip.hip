@@ -3,8 +3,8 @@
 #include "cfm_attn_kernels.h"
 #include "rowops_kernels.h"
 #include "gtc_kernels.h"
-#include "segfuse_kernels.h"
 #include "gemm.h"
+#include "segfuse_kernels.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -847,8 +847,9 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
 static int segf_maps(SegfMaps& mp, const int* h, const int* w, int nmaps, int H, int W, const char* who) {
     if (nmaps < 0 || nmaps > 3 || H < 1 || W < 1) return fail(-1, "%s: bad map count / size", who);
     mp.cnt = nmaps;
+    mp.nseg = 0; mp.per_frame = 0;
     for (int m = 0; m < 3; ++m) {
-        mp.z[m] = nullptr; mp.dz[m] = nullptr; mp.h[m] = mp.w[m] = 1; mp.blk_end[m] = 0;
+        mp.z[m] = nullptr; mp.dz[m] = nullptr; mp.h[m] = mp.w[m] = 1;
         if (m >= nmaps) continue;
         if (h[m] < 1 || w[m] < 1 || (long)H > (long)SEGF_MAX_RATIO * h[m] || (long)W > (long)SEGF_MAX_RATIO * w[m])
             return fail(-1, "%s: map %d is %dx%d for a %dx%d output (resize factors above %d are not supported)", who, m, h[m], w[m],
@@ -866,7 +867,8 @@ int cffm_segfuse_fwd(float* y, const float* d, const float* const z[3], const in
     const long rows = (long)N * H * W;
     if (!rows) return 0;
     hipStream_t st = (hipStream_t)stream;
-    CFFM_LAUNCH(k_segfuse_fwd, ((unsigned)((rows + 3) / 4)), (256), 0, st, y, d, mp, N, H, W);
+    const long patches = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    CFFM_LAUNCH(k_segfuse_fwd, ((unsigned)((patches + 3) / 4)), (256), 0, st, y, d, mp, N, H, W);
     CHECK_LAUNCH("segfuse_fwd");
     return 0;
 }
@@ -875,13 +877,29 @@ int cffm_segfuse_bwd(const float* g, float* const dz[3], const int h[3], const i
     REQUIRE(g && N >= 0 && nmaps >= 1 && dz && h && w, "segfuse_bwd: bad arguments");
     SegfMaps mp;
     TRY(segf_maps(mp, h, w, nmaps, H, W, "segfuse_bwd"));
-    long blocks = 0;
-    for (int m = 0; m < nmaps; ++m) {
-        REQUIRE(dz[m], "segfuse_bwd: null map");
-        mp.dz[m] = dz[m];
-        blocks += ((long)N * h[m] * w[m] + 3) / 4;
-        mp.blk_end[m] = (int)blocks;
-    }
+    for (int m = 0; m < nmaps; ++m) { REQUIRE(dz[m], "segfuse_bwd: null map"); mp.dz[m] = dz[m]; }
+    // bands of BR output rows (BR = the largest resize factor, at most SEGF_MAX_BANDS bands); a low-resolution row belongs to
+    // the band its centre falls into
+    int BR = 1;
+    for (int m = 0; m < nmaps; ++m) BR = std::max(BR, (H + h[m] - 1) / h[m]);
+    BR = std::max(BR, (H + SEGF_MAX_BANDS - 1) / SEGF_MAX_BANDS);
+    const int nb = (H + BR - 1) / BR;
+    long items = 0;
+    int next_q[3] = {0, 0, 0};
+    for (int b = 0; b < nb; ++b)
+        for (int m = 0; m < nmaps; ++m) {
+            const int q0 = next_q[m];
+            int q = q0;
+            while (q < h[m] && (b == nb - 1 || (int)(((double)q + 0.5) * H / h[m]) / BR <= b)) ++q;
+            next_q[m] = q;
+            items += (long)(q - q0) * ((w[m] + SEGF_XQ - 1) / SEGF_XQ);
+            mp.seg_q0[b * nmaps + m] = q0;
+            mp.seg_end[b * nmaps + m] = (int)items;
+        }
+    mp.nseg = nb * nmaps;
+    mp.per_frame = (int)items;
+    const long blocks = items * N;
+    REQUIRE(blocks < (1L << 31), "segfuse_bwd: too many work items");
     if (!blocks) return 0;
     hipStream_t st = (hipStream_t)stream;
     CFFM_LAUNCH(k_segfuse_bwd, ((unsigned)blocks), (256), 0, st, g, mp, N, H, W);

@@ -10,6 +10,7 @@
 // Everything here works on token rows [N*H*W, 256] (NHWC): one wave = one row of 256 channels as 64 x f32x4.
 #pragma once
 #include "cffm_common.h"
+#include "gemm_kernels.h"   // xcd_linear_id
 
 #define SEGF_C 256
 #define SEGF_MAX_RATIO 16   // largest resize factor per dimension the adjoint's candidate window is sized for
@@ -27,104 +28,193 @@ __device__ __forceinline__ void segf_taps(int dst, int in, int out, int& i0, int
     l1 = s - (float)i0;
 }
 
+#define SEGF_MAX_BANDS 32
 struct SegfMaps {
     const float* z[3];   // low-resolution embeddings [N, h*w, 256]
     float* dz[3];        // (backward) their gradients
     int h[3], w[3];
     int cnt;             // maps in use (the SegFormer decoder: 3)
-    int blk_end[3];      // (backward) exclusive prefix of workgroups per map
+    // (backward) work order inside one frame: bands of output rows, inside a band every map's low-resolution rows whose centre
+    // falls into it -- so the items that read the same rows of g, whatever their map, are neighbours in the launch order
+    int nseg;                          // bands * cnt
+    int seg_end[SEGF_MAX_BANDS * 3];   // exclusive prefix of items (workgroups) per (band, map)
+    int seg_q0[SEGF_MAX_BANDS * 3];    // first low-resolution row of the segment
+    int per_frame;                     // items per frame
 };
 
-// y[n, p, :] += d + sum_m bilinear(z_m)[n, p, :]     (y holds the 1/4-scale embedding on entry); grid (ceil(N*H*W / 4))
+// weights of two taps (offsets oa, ob in 0..2 from the neighbourhood's first row) as a dense triple -- selects, not indexing
+#define SEGF_W3(dst, oa, va, ob, vb)                                                  \
+    do {                                                                              \
+        dst[0] = ((oa) == 0 ? (va) : 0.f) + ((ob) == 0 ? (vb) : 0.f);                  \
+        dst[1] = ((oa) == 1 ? (va) : 0.f) + ((ob) == 1 ? (vb) : 0.f);                  \
+        dst[2] = ((oa) == 2 ? (va) : 0.f) + ((ob) == 2 ? (vb) : 0.f);                  \
+    } while (0)
+// y[n, p, :] += d + sum_m bilinear(z_m)[n, p, :]     (y holds the 1/4-scale embedding on entry)
+// One wave owns a 2 x 2 patch of output pixels: their taps of a low-resolution map lie in a 3 x 3 neighbourhood (usually
+// 2 x 2), which is loaded once for the four pixels -- ~5 row loads per pixel instead of 13 (one wave per pixel was bound by
+// the per-CU L1 rate of those loads: 79 us).  Rows / columns of the neighbourhood no pixel taps are skipped (wave-uniform).
+// grid (ceil(N * ceil(H/2) * ceil(W/2) / 4)); every XCD (workgroup b runs on XCD b % 8) owns a contiguous run of patches.
 __global__ void __launch_bounds__(256) k_segfuse_fwd(float* __restrict__ y, const float* __restrict__ d, SegfMaps mp, int N, int H, int W) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;
-    if (row >= (long)N * H * W) return;
-    const int n = (int)(row / ((long)H * W)), p = (int)(row - (long)n * H * W), oy = p / W, ox = p - oy * W;
-    f32x4 acc = ((const f32x4*)(y + row * SEGF_C))[lane] + ((const f32x4*)d)[lane];
-    f32x4 t[3][4];
-    float wt[3][4];
+    const int ph = (H + 1) / 2, pw = (W + 1) / 2;
+    const long patch = (long)xcd_linear_id() * 4 + wave;
+    if (patch >= (long)N * ph * pw) return;
+    const int n = (int)(patch / ((long)ph * pw)), pr = (int)(patch - (long)n * ph * pw), oy = (pr / pw) * 2, ox = (pr - (pr / pw) * pw) * 2;
+    const bool vy = oy + 1 < H, vx = ox + 1 < W;        // second row / column of the patch inside the map
+    float* yb = y + ((long)n * H * W + (long)oy * W + ox) * SEGF_C;
+    const f32x4 dv = ((const f32x4*)d)[lane];
+    f32x4 acc[2][2];
+    acc[0][0] = ((const f32x4*)yb)[lane] + dv;
+    acc[0][1] = vx ? ((const f32x4*)(yb + SEGF_C))[lane] + dv : dv;
+    acc[1][0] = vy ? ((const f32x4*)(yb + (long)W * SEGF_C))[lane] + dv : dv;
+    acc[1][1] = (vy && vx) ? ((const f32x4*)(yb + (long)(W + 1) * SEGF_C))[lane] + dv : dv;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        if (m < mp.cnt) {
-            int y0, y1, x0, x1;
-            float ly, lx;
-            segf_taps(oy, mp.h[m], H, y0, y1, ly);
-            segf_taps(ox, mp.w[m], W, x0, x1, lx);
-            const float* base = mp.z[m] + (long)n * mp.h[m] * mp.w[m] * SEGF_C;
-            t[m][0] = ((const f32x4*)(base + ((long)y0 * mp.w[m] + x0) * SEGF_C))[lane];
-            t[m][1] = ((const f32x4*)(base + ((long)y0 * mp.w[m] + x1) * SEGF_C))[lane];
-            t[m][2] = ((const f32x4*)(base + ((long)y1 * mp.w[m] + x0) * SEGF_C))[lane];
-            t[m][3] = ((const f32x4*)(base + ((long)y1 * mp.w[m] + x1) * SEGF_C))[lane];
-            wt[m][0] = (1.f - ly) * (1.f - lx);
-            wt[m][1] = (1.f - ly) * lx;
-            wt[m][2] = ly * (1.f - lx);
-            wt[m][3] = ly * lx;
+        if (m >= mp.cnt) continue;
+        const int h = mp.h[m], w = mp.w[m];
+        // per patch row / column: weights over the neighbourhood rows ya..ya+2 / columns xa..xa+2
+        float wy[2][3], wx[2][3];
+        int ya, xa;
+        {
+            int i0, i1, o0, o1;
+            float l1;
+            segf_taps(oy, h, H, i0, i1, l1);
+            ya = i0; o1 = i1 - ya;
+            SEGF_W3(wy[0], 0, 1.f - l1, o1, l1);
+            segf_taps(vy ? oy + 1 : oy, h, H, i0, i1, l1);
+            o0 = i0 - ya; o1 = i1 - ya;
+            SEGF_W3(wy[1], o0, 1.f - l1, o1, l1);
+            segf_taps(ox, w, W, i0, i1, l1);
+            xa = i0; o1 = i1 - xa;
+            SEGF_W3(wx[0], 0, 1.f - l1, o1, l1);
+            segf_taps(vx ? ox + 1 : ox, w, W, i0, i1, l1);
+            o0 = i0 - xa; o1 = i1 - xa;
+            SEGF_W3(wx[1], o0, 1.f - l1, o1, l1);
         }
-    }
+        const float* base = mp.z[m] + (long)n * h * w * SEGF_C;
+        f32x4 t[3][3];
+        bool use[3][3];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-        if (m < mp.cnt) acc += (t[m][0] * wt[m][0] + t[m][1] * wt[m][1]) + (t[m][2] * wt[m][2] + t[m][3] * wt[m][3]);
-    ((f32x4*)(y + row * SEGF_C))[lane] = acc;
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                use[j][i] = (wy[0][j] != 0.f || wy[1][j] != 0.f) && (wx[0][i] != 0.f || wx[1][i] != 0.f);
+                const int yy = ya + j < h ? ya + j : h - 1, xx = xa + i < w ? xa + i : w - 1;
+                t[j][i] = use[j][i] ? ((const f32x4*)(base + ((long)yy * w + xx) * SEGF_C))[lane] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4 rowv = t[j][0] * wx[b][0] + t[j][1] * wx[b][1] + t[j][2] * wx[b][2];
+                    sum += rowv * wy[a][j];
+                }
+                acc[a][b] += sum;
+            }
+    }
+    ((f32x4*)yb)[lane] = acc[0][0];
+    if (vx) ((f32x4*)(yb + SEGF_C))[lane] = acc[0][1];
+    if (vy) ((f32x4*)(yb + (long)W * SEGF_C))[lane] = acc[1][0];
+    if (vy && vx) ((f32x4*)(yb + (long)(W + 1) * SEGF_C))[lane] = acc[1][1];
 }
 
 // Adjoint of the three resizes: dz_m[n, q, :] = sum over the output pixels p that tap q of weight(p, q) * g[n, p, :].
-// Gather form (deterministic, no atomics): one wave per low-resolution pixel; the candidate output rows / columns are the
-// inverse image of (q-1, q+1) under the source-index map, widened by one, and every candidate's weight is recomputed with
-// the forward's own tap rule (a candidate that does not tap q gets weight 0), so forward and adjoint cannot disagree.
-// Weights of the <= 64 candidates per dimension live in LDS per wave.  grid = total low-res pixels / 4 (per map prefix).
+// Gather form (deterministic, no atomics).  One workgroup owns SEGF_XQ consecutive low-resolution pixels of one row:
+// adjacent pixels share half of their output columns, so the union window is read once (g re-read 2.5x per map instead
+// of 4x); its four waves take the candidate output rows round-robin and their partial sums meet in LDS -- a wave per item
+// left the 8x map's waves with ~700 dependent-latency row loads each while the 2x map's had 56 (152 us, tail-bound).
+// The candidate output rows / columns are the inverse image of (q-1, q+1) under the source-index map, widened by one, and
+// every candidate's weight is recomputed with the forward's own tap rule (a candidate that does not tap q gets weight 0),
+// so forward and adjoint cannot disagree.  grid = N * sum over maps of h*ceil(w/SEGF_XQ).
+#define SEGF_XQ 4
+#define SEGF_XWIN 96   // >= (SEGF_XQ + 1) * SEGF_MAX_RATIO + 5
 __global__ void __launch_bounds__(256) k_segfuse_bwd(const float* __restrict__ g, SegfMaps mp, int N, int H, int W) {
-    __shared__ float s_w[4][2][64];
+    __shared__ float s_wy[64];
+    __shared__ f32x4 s_wx[SEGF_XWIN];
+    __shared__ f32x4 s_part[4][SEGF_XQ][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int m = 0;
-    while (m + 1 < mp.cnt && (int)blockIdx.x >= mp.blk_end[m]) ++m;
-    const int blk = (int)blockIdx.x - (m ? mp.blk_end[m - 1] : 0);
-    const int h = mp.h[m], w = mp.w[m];
-    const long q = (long)blk * 4 + wave, nq = (long)N * h * w;
-    const bool live = q < nq;
-    const int n = live ? (int)(q / ((long)h * w)) : 0, r = live ? (int)(q - (long)n * h * w) : 0, qy = r / w, qx = r - qy * w;
+    // XCD-aware order: workgroup b runs on XCD b % 8; re-numbered so that every XCD owns a contiguous run of the band-ordered
+    // items -- the items that share rows of g then meet in one 4 MB L2 instead of eight, and g comes from HBM about once
+    // (per-map raster order: 154 us; that order with contiguous XCD runs: 268 us, the 8x map's heavy items all on one XCD)
+    const int lin = xcd_linear_id();
+    const int n = lin / mp.per_frame, rem = lin - n * mp.per_frame;
+    int sg = 0;
+    while (sg + 1 < mp.nseg && rem >= mp.seg_end[sg]) ++sg;
+    const int m = sg % mp.cnt, local = rem - (sg ? mp.seg_end[sg - 1] : 0);
+    const int h = mp.h[m], w = mp.w[m], wg = (w + SEGF_XQ - 1) / SEGF_XQ;
+    const int qy = mp.seg_q0[sg] + local / wg, qx0 = (local % wg) * SEGF_XQ;
+    const int qx1 = qx0 + SEGF_XQ - 1 < w - 1 ? qx0 + SEGF_XQ - 1 : w - 1;
     // candidate windows
     const float isy = (float)H / (float)h, isx = (float)W / (float)w;
     int ylo = (int)floorf(((float)qy - 0.5f) * isy - 0.5f) - 1, yhi = (int)ceilf(((float)qy + 1.5f) * isy - 0.5f) + 1;
-    int xlo = (int)floorf(((float)qx - 0.5f) * isx - 0.5f) - 1, xhi = (int)ceilf(((float)qx + 1.5f) * isx - 0.5f) + 1;
+    int xlo = (int)floorf(((float)qx0 - 0.5f) * isx - 0.5f) - 1, xhi = (int)ceilf(((float)qx1 + 1.5f) * isx - 0.5f) + 1;
     ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
     yhi = yhi > H - 1 ? H - 1 : yhi; xhi = xhi > W - 1 ? W - 1 : xhi;
-    yhi = yhi > ylo + 63 ? ylo + 63 : yhi; xhi = xhi > xlo + 63 ? xlo + 63 : xhi;   // (ratio <= SEGF_MAX_RATIO: never binds)
+    yhi = yhi > ylo + 63 ? ylo + 63 : yhi; xhi = xhi > xlo + SEGF_XWIN - 1 ? xlo + SEGF_XWIN - 1 : xhi;   // (ratio <= 16: never binds)
     {
         int i0, i1;
         float l1;
-        float wy = 0.f, wx = 0.f;
-        if (ylo + lane <= yhi) {
-            segf_taps(ylo + lane, h, H, i0, i1, l1);
-            wy = (i0 == qy ? 1.f - l1 : 0.f) + (i1 == qy ? l1 : 0.f);
+        if (wave == 0) {
+            float wy = 0.f;
+            if (ylo + lane <= yhi) {
+                segf_taps(ylo + lane, h, H, i0, i1, l1);
+                wy = (i0 == qy ? 1.f - l1 : 0.f) + (i1 == qy ? l1 : 0.f);
+            }
+            s_wy[lane] = wy;
         }
-        if (xlo + lane <= xhi) {
-            segf_taps(xlo + lane, w, W, i0, i1, l1);
-            wx = (i0 == qx ? 1.f - l1 : 0.f) + (i1 == qx ? l1 : 0.f);
+        for (int c = threadIdx.x; c < SEGF_XWIN; c += 256) {
+            f32x4 wx = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (xlo + c <= xhi) {
+                segf_taps(xlo + c, w, W, i0, i1, l1);
+#pragma unroll
+                for (int j = 0; j < SEGF_XQ; ++j)
+                    wx[j] = (qx0 + j < w) ? (i0 == qx0 + j ? 1.f - l1 : 0.f) + (i1 == qx0 + j ? l1 : 0.f) : 0.f;
+            }
+            s_wx[c] = wx;
         }
-        s_w[wave][0][lane] = wy;
-        s_w[wave][1][lane] = wx;
     }
     __syncthreads();
-    if (!live) return;
     const float* gb = g + (long)n * H * W * SEGF_C;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int yy = ylo; yy <= yhi; ++yy) {
-        const float wy = s_w[wave][0][yy - ylo];
+    f32x4 acc[SEGF_XQ];
+#pragma unroll
+    for (int j = 0; j < SEGF_XQ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int yy = ylo + wave; yy <= yhi; yy += 4) {
+        const float wy = s_wy[yy - ylo];
         if (wy == 0.f) continue;
         const float* grow = gb + (long)yy * W * SEGF_C;
-        f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 part[SEGF_XQ];
+#pragma unroll
+        for (int j = 0; j < SEGF_XQ; ++j) part[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int xx = xlo;
-        for (; xx + 3 <= xhi; xx += 4) {          // four independent row loads in flight
-            f32x4 v0 = ((const f32x4*)(grow + (long)(xx + 0) * SEGF_C))[lane];
-            f32x4 v1 = ((const f32x4*)(grow + (long)(xx + 1) * SEGF_C))[lane];
-            f32x4 v2 = ((const f32x4*)(grow + (long)(xx + 2) * SEGF_C))[lane];
-            f32x4 v3 = ((const f32x4*)(grow + (long)(xx + 3) * SEGF_C))[lane];
-            part += (v0 * s_w[wave][1][xx - xlo] + v1 * s_w[wave][1][xx + 1 - xlo]) +
-                    (v2 * s_w[wave][1][xx + 2 - xlo] + v3 * s_w[wave][1][xx + 3 - xlo]);
+        for (; xx + 7 <= xhi; xx += 8) {          // eight independent row loads in flight
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ((const f32x4*)(grow + (long)(xx + u) * SEGF_C))[lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 wx = s_wx[xx + u - xlo];
+#pragma unroll
+                for (int j = 0; j < SEGF_XQ; ++j) part[j] += v[u] * wx[j];
+            }
         }
-        for (; xx <= xhi; ++xx) part += ((const f32x4*)(grow + (long)xx * SEGF_C))[lane] * s_w[wave][1][xx - xlo];
-        acc += part * wy;
+        for (; xx <= xhi; ++xx) {
+            const f32x4 v = ((const f32x4*)(grow + (long)xx * SEGF_C))[lane];
+            const f32x4 wx = s_wx[xx - xlo];
+#pragma unroll
+            for (int j = 0; j < SEGF_XQ; ++j) part[j] += v * wx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < SEGF_XQ; ++j) acc[j] += part[j] * wy;
     }
-    ((f32x4*)(mp.dz[m] + q * SEGF_C))[lane] = acc;
+#pragma unroll
+    for (int j = 0; j < SEGF_XQ; ++j) s_part[wave][j][lane] = acc[j];
+    __syncthreads();
+    // wave j finishes pixel qx0 + j (SEGF_XQ == number of waves)
+    if (qx0 + wave < w) {
+        const f32x4 t = (s_part[0][wave][lane] + s_part[1][wave][lane]) + (s_part[2][wave][lane] + s_part[3][wave][lane]);
+        ((f32x4*)(mp.dz[m] + ((long)n * h * w + (long)qy * w + qx0 + wave) * SEGF_C))[lane] = t;
+    }
 }
