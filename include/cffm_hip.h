@@ -157,6 +157,19 @@ int cffm_segfuse_fwd(float* y, const float* d, const float* const z[3], const in
 int cffm_segfuse_bwd(const float* g, float* const dz[3], const int h[3], const int w[3], int nmaps, int N, int H, int W,
                      void* stream);
 
+/* ---- the head's training loss without full-resolution logits ----
+ * Replaces decode_head.py:744-835's resize(seg_logit, size=label size, 'bilinear', align_corners=False) followed by
+ * F.cross_entropy(reduction='none', ignore_index) (losses/cross_entropy_loss.py:9-40) and `accuracy` (losses/accuracy.py:4):
+ * logits [M,K,h,w] fp32, labels [M,H,W] int64 (ignore_index, and anything outside [0,K), contributes 0), H <= 8h, W <= 8w, K <= 256.
+ * fwd: lse [M,H,W] (log-sum-exp of the interpolated logits, kept for bwd); part [cffm_upce_blocks(...)][2]: per-workgroup
+ *      sums of the per-pixel losses and of the pixels whose arg-max is the label (the caller adds them up and divides).
+ * bwd: dlogits [M,K,h,w] = scale * (*gscale, device scalar, or 1 when NULL) * d(sum of per-pixel losses)/dlogits. */
+long cffm_upce_blocks(int M, int H, int W);
+int cffm_upce_fwd(const float* logits, const long long* labels, float* lse, float* part, int M, int K, int h, int w, int H, int W,
+                  int ignore_index, void* stream);
+int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse, const float* gscale, float scale,
+                  float* dlogits, int M, int K, int h, int w, int H, int W, int ignore_index, void* stream);
+
 /* ---- block / layer level ---- */
 /* x_ref: NHWC frames 0..2 [B,3,HW,256] (batch stride ref_bs), x_tgt NHWC target [B,HW,256] (stride tgt_bs);
  * writes the block's saved activations into `ws` (layout: cffm_block_ws_layout; ws[x2] is the output). */

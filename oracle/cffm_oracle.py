@@ -333,3 +333,33 @@ def segformer_fuse(feats, lin_w, lin_b, fuse_w):
         maps.append(m)
     cat = torch.cat(maps, dim=1)                                                     # the [N, 4E, H, W] concat
     return torch.einsum('oc,nchw->nohw', fuse_w.reshape(fuse_w.shape[0], -1), cat)
+
+
+# --------------------------------------------------------------------------- training loss
+def resize_cross_entropy(logits, labels, ignore_index=255):
+    """(sum of per-pixel losses, number of pixels whose arg-max equals the label) for logits [M,K,h,w] resized to the
+    labels' [M,H,W] size: decode_head.py:805-835 (resize, bilinear, align_corners=False) -> cross_entropy_loss.py:9-40
+    (F.cross_entropy(reduction='none', ignore_index): 0 at ignored pixels) -> accuracy.py:4-44 (top-1 over ALL pixels).
+    Restated with the explicit resize matrices and a log-softmax."""
+    H, W = labels.shape[1:]
+    up = torch.einsum('yh,nchw,xw->ncyx', bilinear_matrix(logits.shape[2], H, logits.dtype), logits,
+                      bilinear_matrix(logits.shape[3], W, logits.dtype))
+    logp = up - torch.logsumexp(up, dim=1, keepdim=True)
+    keep = labels != ignore_index
+    safe = torch.where(keep, labels, torch.zeros_like(labels))
+    nll = -logp.gather(1, safe.unsqueeze(1)).squeeze(1)
+    loss_sum = torch.where(keep, nll, torch.zeros_like(nll)).sum()
+    hits = (up.argmax(dim=1) == labels).sum()
+    return loss_sum, hits
+
+
+def head_losses(seg_logit, seg_label, ignore_index=255, loss_weight=1.0):
+    """BaseDecodeHead_clips_flow.losses for the k+1 layout of the CFFM head (decode_head.py:744-835): 0.5 * CE(per-frame
+    logits, every frame's labels) + CE(clip-level logits, last frame's labels), each a mean over all pixels; acc over frames."""
+    b, t = seg_label.shape[:2]
+    assert seg_logit.shape[1] == t + 1
+    fl, cl = seg_logit[:, :t].flatten(0, 1), seg_logit[:, t:].flatten(0, 1)
+    flab, clab = seg_label.flatten(0, 1).squeeze(1), seg_label[:, -1].squeeze(1)
+    fs, fh = resize_cross_entropy(fl, flab, ignore_index)
+    cs, _ = resize_cross_entropy(cl, clab, ignore_index)
+    return 0.5 * loss_weight * fs / flab.numel() + loss_weight * cs / clab.numel(), fh.to(seg_logit.dtype) * (100.0 / flab.numel())

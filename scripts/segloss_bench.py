@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""The head's training loss: ops.resize_cross_entropy (fused resize + cross entropy + accuracy in
+libcffm_hip.so) against the reference's op sequence in stock PyTorch on the same GPU (F.interpolate to the label size,
+F.cross_entropy(reduction='none', ignore_index), sum, arg-max accuracy), CFFM-B1 480x480 training step: 2 clips x (4 frames + 1
+clip-level map) = 10 maps of 124 classes, 120x120 -> 480x480.  One JSON line: ms per forward+backward, peak memory."""
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vss_cffm_amd import ops  # noqa: E402
+
+
+def torch_seq(lg, labels):
+    up = F.interpolate(lg, size=labels.shape[1:], mode='bilinear', align_corners=False)
+    loss = F.cross_entropy(up, labels, reduction='none', ignore_index=255).sum()
+    hits = (up.argmax(1) == labels).sum()
+    return loss, hits
+
+
+def main():
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(0)
+    logits = (torch.randn(10, 124, 120, 120, generator=gen) * 2.0).to(dev).requires_grad_(True)
+    labels = torch.randint(0, 124, (10, 480, 480), generator=gen)
+    labels[torch.rand(10, 480, 480, generator=gen) < 0.05] = 255
+    labels = labels.to(dev)
+    out = {}
+    for name, fn in (('hip', lambda lg, lb: ops.resize_cross_entropy(lg, lb, 255)), ('torch', torch_seq)):
+        def step():
+            logits.grad = None
+            loss, hits = fn(logits, labels)
+            loss.backward()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        times = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        times.sort()
+        out[name] = {'ms_fwd_bwd': round(times[len(times) // 2], 3), 'min_ms': round(times[0], 3),
+                     'peak_mb': round((torch.cuda.max_memory_allocated(dev) - base) / 2 ** 20, 1)}
+    out['speedup'] = round(out['torch']['ms_fwd_bwd'] / out['hip']['ms_fwd_bwd'], 2)
+    out['workload'] = '10 maps x 124 classes, 120x120 -> 480x480, 5 % ignored labels'
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

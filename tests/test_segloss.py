@@ -1,0 +1,174 @@
+"""The head's training loss without full-resolution logits (decode_head.py:744-835):
+ops.resize_cross_entropy / cffm_upce_fwd / cffm_upce_bwd and head.losses against
+  * golden vectors the REFERENCE head's own `losses()` produced (tests/golden/make_golden_loss.py -> loss_b0.npz),
+  * the CPU restatement oracle/cffm_oracle.py::resize_cross_entropy / head_losses (pinned to those vectors here),
+  * the reference's op sequence in torch fp64 at ragged sizes, other class counts, ignored / out-of-range labels,
+  * at the CFFM-B1 480x480 training size on the GPU: the same comparison, determinism, peak memory.
+Tolerance: fp32 arithmetic with hardware exp/log: loss 1e-5 relative, gradient 1e-4 of its max (measured ~1e-6 / 1e-5)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cffm_oracle as O, ref_import as RI
+from tests import emu, helpers as H
+from tests.golden.make_golden_loss import CASES, case_inputs
+from vss_cffm_amd import _lib, ops
+from vss_cffm_amd.registry import build_head
+
+
+def _torch_ref(logits, labels, ignore=255):
+    """decode_head.py:805-835 in stock torch, fp64"""
+    lg = logits.double().requires_grad_(True)
+    up = F.interpolate(lg, size=labels.shape[1:], mode='bilinear', align_corners=False)
+    valid = labels.clone()
+    valid[(labels < 0) | (labels >= logits.shape[1])] = ignore       # (the reference would assert on such labels)
+    loss = F.cross_entropy(up, valid, reduction='none', ignore_index=ignore).sum()
+    loss.backward()
+    hits = (up.argmax(1) == labels).sum()
+    return float(loss), int(hits), lg.grad
+
+
+def run_ab(device, cases):
+    gen = torch.Generator().manual_seed(11)
+    for (m, k, h, w, HH, WW, p_ign) in cases:
+        logits = torch.randn(m, k, h, w, generator=gen) * 2.0
+        labels = torch.randint(0, k, (m, HH, WW), generator=gen)
+        labels[torch.rand(m, HH, WW, generator=gen) < p_ign] = 255
+        if p_ign > 0 and m:
+            labels[0, 0, 0], labels[0, -1, -1] = -3, k + 5                    # out of range: counted like ignore_index
+        want_loss, want_hits, want_grad = _torch_ref(logits, labels)
+        lg = logits.to(device).requires_grad_(True)
+        loss, hits = ops.resize_cross_entropy(lg, labels.to(device), 255)
+        (loss * 0.37).backward()
+        assert abs(float(loss) - want_loss) <= 1e-5 * max(1.0, abs(want_loss)), (m, k, h, w, float(loss), want_loss)
+        assert int(hits) == want_hits
+        assert not hits.requires_grad
+        if m:
+            scale = max(float(want_grad.abs().max()), 1e-30)
+            assert float((lg.grad.cpu().double() / 0.37 - want_grad).abs().max()) <= 1e-4 * scale + 5e-6, (m, k, h, w)   # (K = 1: exact gradient 0, fp32 lse rounding 2e-7)
+
+
+SMALL = [(2, 124, 16, 16, 64, 64, 0.05), (1, 124, 7, 15, 26, 60, 0.1), (2, 19, 7, 9, 20, 31, 0.0), (1, 150, 5, 6, 5, 6, 0.2),
+         (1, 3, 2, 3, 16, 24, 1.0), (0, 124, 4, 4, 16, 16, 0.0), (1, 256, 3, 3, 9, 11, 0.05), (1, 1, 4, 4, 8, 8, 0.1)]
+
+
+def run_errors(device):
+    lg = torch.zeros(1, 4, 2, 2, device=device)
+    with pytest.raises(_lib.CffmError):
+        ops.resize_cross_entropy(lg, torch.zeros(1, 40, 40, dtype=torch.int64, device=device))      # factor above 8
+    with pytest.raises(_lib.CffmError):
+        ops.resize_cross_entropy(lg, torch.zeros(1, 1, 2, dtype=torch.int64, device=device))        # downsizing
+    with pytest.raises(_lib.CffmError):
+        ops.resize_cross_entropy(lg, torch.zeros(1, 4, 4, dtype=torch.int32, device=device))        # label dtype
+    with pytest.raises(_lib.CffmError):
+        ops.resize_cross_entropy(torch.zeros(1, 300, 2, 2, device=device), torch.zeros(1, 4, 4, dtype=torch.int64, device=device))
+
+
+def _check_head_losses_against_golden(fn, device, tol_loss, tol_grad):
+    g = H.load_golden('loss_b0')
+    for name in CASES:
+        logits, lab = case_inputs(name)
+        lg = logits.to(device).requires_grad_(True)
+        loss, acc = fn(lg, lab.to(device))
+        loss.backward()
+        assert abs(float(loss) - float(g[name + '/loss_seg'])) <= tol_loss * float(g[name + '/loss_seg']), name
+        assert abs(float(acc) - float(g[name + '/acc_seg'][0])) < 1e-4, name
+        assert H.rel_err(lg.grad, g[name + '/dlogits']) < tol_grad, name
+
+
+def _my_head_losses(device):
+    head = build_head(RI.head_cfg()).to(device)
+
+    def fn(lg, lab):
+        out = head.losses(lg, lab)
+        return out['loss_seg'], out['acc_seg']
+    return head, fn
+
+
+# ------------------------------------------------------------------------------------------------ oracle (CPU)
+def test_oracle_losses_against_reference_golden():
+    _check_head_losses_against_golden(lambda lg, lab: O.head_losses(lg, lab), torch.device('cpu'), 1e-6, 1e-5)
+
+
+def test_torch_path_of_head_losses_against_reference_golden():
+    head, fn = _my_head_losses(torch.device('cpu'))
+    assert not head._fused_loss_ok(torch.zeros(1))                 # CPU tensors: the reference's op sequence
+    _check_head_losses_against_golden(fn, torch.device('cpu'), 1e-6, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ kernels, emulated (CPU)
+def test_upce_emulated_against_reference_golden():
+    with emu.active():
+        head, fn = _my_head_losses(torch.device('cpu'))
+        assert head._fused_loss_ok(torch.zeros(1))
+        _check_head_losses_against_golden(fn, torch.device('cpu'), 1e-5, 1e-4)
+
+
+def test_upce_emulated_against_torch_fp64():
+    with emu.active():
+        run_ab(torch.device('cpu'), SMALL)
+        run_errors(torch.device('cpu'))
+
+
+def test_fused_loss_is_gated_on_the_configured_loss():
+    with emu.active():
+        cfg = RI.head_cfg()
+        cfg['loss_decode'] = dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.4, class_weight=[1.0] * 124)
+        head = build_head(cfg)
+        assert not head._fused_loss_ok(torch.zeros(1))             # class weights: torch path
+        cfg['loss_decode'] = dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.4)
+        head = build_head(cfg)
+        assert head._fused_loss_ok(torch.zeros(1))
+        logits, lab = case_inputs('sq')
+        a = head.losses(logits, lab)
+        head.loss_impl = 'torch'
+        b = head.losses(logits, lab)
+        assert abs(float(a['loss_seg']) - float(b['loss_seg'])) < 1e-5 * float(b['loss_seg'])     # loss_weight honoured
+        assert abs(float(a['acc_seg']) - float(b['acc_seg'])) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_upce_gpu_against_reference_golden():
+    head, fn = _my_head_losses(torch.device('cuda:0'))
+    assert head._fused_loss_ok(torch.zeros(1, device='cuda:0'))
+    _check_head_losses_against_golden(fn, torch.device('cuda:0'), 1e-5, 1e-4)
+
+
+@pytest.mark.gpu
+def test_upce_gpu_against_torch_fp64():
+    run_ab(torch.device('cuda:0'), SMALL + [(3, 124, 30, 30, 120, 120, 0.05), (1, 124, 15, 20, 120, 160, 0.05)])
+    run_errors(torch.device('cuda:0'))
+
+
+@pytest.mark.gpu
+def test_upce_gpu_training_size():
+    """2 clips x (4 frames + 1 clip-level map), 124 classes, 120x120 -> 480x480: against torch on the same GPU (fp32 logits
+    resized in fp64: 2.3 GB -- the tensor the kernels never build), bit-identical repeats, peak memory of the fused op."""
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(12)
+    logits = (torch.randn(10, 124, 120, 120, generator=gen) * 2.0).to(dev)
+    labels = torch.randint(0, 124, (10, 480, 480), generator=gen)
+    labels[torch.rand(10, 480, 480, generator=gen) < 0.05] = 255
+    labels = labels.to(dev)
+    torch.cuda.synchronize(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    lg = logits.clone().requires_grad_(True)
+    loss, hits = ops.resize_cross_entropy(lg, labels, 255)
+    loss.backward()
+    torch.cuda.synchronize(dev)
+    peak = torch.cuda.max_memory_allocated(dev) - base
+    assert peak < 256 * 2 ** 20, peak                      # logits copy + gradient + lse + records; the resize alone is 1.14 GB
+    lg2 = logits.clone().requires_grad_(True)
+    loss2, hits2 = ops.resize_cross_entropy(lg2, labels, 255)
+    loss2.backward()
+    assert torch.equal(loss, loss2) and torch.equal(hits, hits2) and torch.equal(lg.grad, lg2.grad)
+    ld = logits.double().requires_grad_(True)
+    up = F.interpolate(ld, size=(480, 480), mode='bilinear', align_corners=False)
+    want = F.cross_entropy(up, labels, reduction='none', ignore_index=255).sum()
+    want.backward()
+    assert abs(float(loss) - float(want)) < 1e-5 * float(want)
+    assert int(hits) == int((up.argmax(1) == labels).sum())
+    assert H.rel_err(lg.grad, ld.grad) < 1e-4

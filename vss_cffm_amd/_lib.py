@@ -77,6 +77,9 @@ SIGNATURES = {
     'cffm_gtc_attn_bwd': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_segfuse_fwd': (ci, [vp, vp, vp * 3, ci * 3, ci * 3, ci, ci, ci, ci, vp]),
     'cffm_segfuse_bwd': (ci, [vp, vp * 3, ci * 3, ci * 3, ci, ci, ci, ci, vp]),
+    'cffm_upce_blocks': (cl, [ci, ci, ci]),
+    'cffm_upce_fwd': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    'cffm_upce_bwd': (ci, [vp, vp, vp, vp, C.c_float, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     'cffm_adamw_step': (ci, [vp, ci, cd, cd, cd, cd, cd, ci, vp]),
     'cffm_adamw_step_dev': (ci, [vp, ci, vp, cd, cd, cd, cd, cd, vp, vp]),
 }

@@ -5,6 +5,7 @@
 #include "gtc_kernels.h"
 #include "gemm.h"
 #include "segfuse_kernels.h"
+#include "segloss_kernels.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -904,6 +905,77 @@ int cffm_segfuse_bwd(const float* g, float* const dz[3], const int h[3], const i
     hipStream_t st = (hipStream_t)stream;
     CFFM_LAUNCH(k_segfuse_bwd, ((unsigned)blocks), (256), 0, st, g, mp, N, H, W);
     CHECK_LAUNCH("segfuse_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- resize + cross entropy
+static int upce_geom(UpceGeom& G, int M, int K, int h, int w, int H, int W, int ignore, const char* who) {
+    if (M < 0 || K < 1 || K > 256 || h < 1 || w < 1 || H < h || W < w || (long)H > (long)UPCE_MAX_RATIO * h ||
+        (long)W > (long)UPCE_MAX_RATIO * w)
+        return fail(-1, "%s: unsupported sizes (K=%d, %dx%d -> %dx%d; 1 <= K <= 256, resize factor 1..%d)", who, K, h, w, H, W,
+                    UPCE_MAX_RATIO);
+    G.M = M; G.K = K; G.h = h; G.w = w; G.H = H; G.W = W; G.ignore = ignore; G.rn = G.cn = 0;
+    return 0;
+}
+// host restatement of segf_taps (the LDS tile of the forward pass has to cover first tap .. last tap of a 16-pixel span)
+static void host_taps(int dst, int in, int out, int& i0, int& i1) {
+    const float scale = (float)in / (float)out;
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = std::min((int)s, in - 1);
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+}
+static int span_taps(int in, int out) {
+    int need = 1;
+    for (int t = 0; t < out; t += UPCE_TILE) {
+        int a0, a1, b0, b1;
+        host_taps(t, in, out, a0, a1);
+        host_taps(std::min(t + UPCE_TILE, out) - 1, in, out, b0, b1);
+        need = std::max(need, b1 - a0 + 1);
+    }
+    return need;
+}
+static int upce_lds(const void* kernel, size_t bytes, const char* who) {
+    if (bytes > 160 * 1024) return fail(-1, "%s: the low-resolution tile needs %zu bytes of LDS", who, bytes);
+#ifndef CFFM_EMU
+    if (bytes > 65536 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return fail(-2, "%s: cannot reserve %zu bytes of LDS", who, bytes);
+#endif
+    return 0;
+}
+long cffm_upce_blocks(int M, int H, int W) {
+    return (long)M * ((H + UPCE_TILE - 1) / UPCE_TILE) * ((W + UPCE_TILE - 1) / UPCE_TILE);
+}
+int cffm_upce_fwd(const float* logits, const long long* labels, float* lse, float* part, int M, int K, int h, int w, int H, int W,
+                  int ignore_index, void* stream) {
+    UpceGeom G;
+    TRY(upce_geom(G, M, K, h, w, H, W, ignore_index, "upce_fwd"));
+    if (!M) return 0;
+    REQUIRE(logits && labels && lse && part, "upce_fwd: null");
+    G.rn = span_taps(h, H);
+    G.cn = span_taps(w, W);
+    const size_t lds = (size_t)G.rn * G.cn * (K + 1) * sizeof(float);
+    TRY(upce_lds((const void*)k_upce_fwd, lds, "upce_fwd"));
+    hipStream_t st = (hipStream_t)stream;
+    CFFM_LAUNCH(k_upce_fwd, ((unsigned)((W + UPCE_TILE - 1) / UPCE_TILE), (unsigned)((H + UPCE_TILE - 1) / UPCE_TILE), (unsigned)M),
+                (256), lds, st, logits, labels, lse, part, G);
+    CHECK_LAUNCH("upce_fwd");
+    return 0;
+}
+int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse, const float* gscale, float scale,
+                  float* dlogits, int M, int K, int h, int w, int H, int W, int ignore_index, void* stream) {
+    UpceGeom G;
+    TRY(upce_geom(G, M, K, h, w, H, W, ignore_index, "upce_bwd"));
+    if (!M) return 0;
+    REQUIRE(logits && labels && lse && dlogits, "upce_bwd: null");
+    G.rn = std::min(h, UPCE_QT + 2);
+    G.cn = std::min(w, UPCE_QT + 2);
+    const size_t lds = ((size_t)G.rn * G.cn * K + 2 * UPCE_FOOT * UPCE_FOOT) * sizeof(float);
+    TRY(upce_lds((const void*)k_upce_bwd, lds, "upce_bwd"));
+    hipStream_t st = (hipStream_t)stream;
+    CFFM_LAUNCH(k_upce_bwd, ((unsigned)((w + UPCE_QT - 1) / UPCE_QT), (unsigned)((h + UPCE_QT - 1) / UPCE_QT), (unsigned)M), (256), lds,
+                st, logits, labels, lse, gscale, scale, dlogits, G);
+    CHECK_LAUNCH("upce_bwd");
     return 0;
 }
 

@@ -1,0 +1,198 @@
+// segloss_kernels.h -- the head's training loss without the full-resolution logits.
+// Reference (decode_head.py:744-835 -> losses/cross_entropy_loss.py:9-40): the [M,K,h,w] logits of every frame are resized
+// to the label resolution (bilinear, align_corners=False: 120 -> 480, [M,K,H,W] = 114 MB per frame for K = 124), then
+// F.cross_entropy(reduction='none', ignore_index) and a mean over ALL pixels; accuracy = top-1 over all pixels.
+// Here the resized logits only ever exist in registers: the forward pass interpolates the K logits of an output pixel from
+// an LDS tile of the low-resolution map, runs an online softmax over them and keeps one float per pixel (the log-sum-exp);
+// the backward pass is the adjoint in gather form (deterministic): a low-resolution pixel sums, over the output pixels that
+// tap it, weight * (softmax - onehot), recomputing each interpolated logit from the same LDS tile.
+#pragma once
+#include "cffm_common.h"
+#include "segfuse_kernels.h"   // segf_taps: the bilinear tap rule
+
+#define UPCE_TILE 16            // output pixels per workgroup side (forward)
+#define UPCE_QT 4               // low-resolution pixels per workgroup side (backward)
+#define UPCE_MAX_RATIO 8
+#define UPCE_FOOT ((UPCE_QT + 2) * UPCE_MAX_RATIO + 4)   // side of the largest output footprint of a backward tile
+
+struct UpceGeom {
+    int M, K, h, w, H, W;
+    int ignore;                 // ignore_index (labels outside [0,K) are treated the same way)
+    int rn, cn;                 // rows / columns of the low-resolution LDS tile
+};
+
+// stage rows r0.. / columns c0.. (rn x cn, clamped to the map) of all K channels of map m: s_l[k][r * cn + c]
+__device__ __forceinline__ void upce_stage(float* s_l, const float* __restrict__ logits, const UpceGeom& G, int m, int r0, int c0) {
+    const int cells = G.rn * G.cn;
+    const float* base = logits + (long)m * G.K * G.h * G.w;
+    for (int e = threadIdx.x; e < G.K * cells; e += 256) {
+        const int k = e / cells, rc = e - k * cells, r = rc / G.cn, c = rc - r * G.cn;
+        const int rr = r0 + r < G.h ? r0 + r : G.h - 1, cc = c0 + c < G.w ? c0 + c : G.w - 1;
+        s_l[e] = base[((long)k * G.h + rr) * G.w + cc];
+    }
+}
+// s_l[K][cell] = max over k of s_l[k][cell] (after upce_stage + barrier; needs another barrier)
+__device__ __forceinline__ void upce_cell_max(float* s_l, const UpceGeom& G) {
+    const int cells = G.rn * G.cn;
+    for (int e = threadIdx.x; e < cells; e += 256) {
+        float mx = s_l[e];
+        for (int k = 1; k < G.K; ++k) mx = fmaxf(mx, s_l[k * cells + e]);
+        s_l[G.K * cells + e] = mx;
+    }
+}
+
+// grid (ceil(W/16), ceil(H/16), M), 256 threads = 16 x 16 output pixels; dynamic LDS rn*cn*(K+1) floats.
+// lse[m][y][x]; part[block][0] = sum of per-pixel losses, part[block][1] = number of pixels whose argmax is the label.
+__global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                   float* __restrict__ lse, float* __restrict__ part, UpceGeom G) {
+    CFFM_DYN_SMEM(smem);
+    float* s_l = (float*)smem;
+    __shared__ float s_red[2][4];
+    const int m = blockIdx.z, ty = blockIdx.y * UPCE_TILE, tx = blockIdx.x * UPCE_TILE;
+    int r0, c0, t1;
+    float tl;
+    segf_taps(ty, G.h, G.H, r0, t1, tl);
+    segf_taps(tx, G.w, G.W, c0, t1, tl);
+    upce_stage(s_l, logits, G, m, r0, c0);
+    __syncthreads();
+    upce_cell_max(s_l, G);
+    __syncthreads();
+    const int oy = ty + (threadIdx.x >> 4), ox = tx + (threadIdx.x & 15);
+    float loss = 0.f, hit = 0.f;
+    if (oy < G.H && ox < G.W) {
+        int y0, y1, x0, x1;
+        float ly, lx;
+        segf_taps(oy, G.h, G.H, y0, y1, ly);
+        segf_taps(ox, G.w, G.W, x0, x1, lx);
+        const int a = (y0 - r0) * G.cn + (x0 - c0), b = (y0 - r0) * G.cn + (x1 - c0), c = (y1 - r0) * G.cn + (x0 - c0),
+                  d = (y1 - r0) * G.cn + (x1 - c0), cells = G.rn * G.cn;
+        const float hx0 = 1.f - lx, hy0 = 1.f - ly;
+        const long long lab = labels[((long)m * G.H + oy) * G.W + ox];
+        const bool counted = lab != G.ignore && lab >= 0 && lab < G.K;
+        // an interpolated logit is a convex combination of its four taps, so the largest tap value over all classes bounds every
+        // one of them: exponentials relative to that bound need no running rescale (s_l[K * cells + cell] = max over k).
+        const float* tm = s_l + G.K * cells;
+        const float bound = fmaxf(fmaxf(tm[a], tm[b]), fmaxf(tm[c], tm[d]));
+        float sum0 = 0.f, sum1 = 0.f, best = -3.0e38f;
+        int arg = -1;
+        int k = 0;
+        for (; k + 1 < G.K; k += 2) {
+            const float* t = s_l + k * cells;
+            const float v0 = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);   // ATen's order of operations
+            const float v1 = hy0 * (hx0 * t[cells + a] + lx * t[cells + b]) + ly * (hx0 * t[cells + c] + lx * t[cells + d]);
+            sum0 += fast_exp(v0 - bound);
+            sum1 += fast_exp(v1 - bound);
+            if (v0 > best) { best = v0; arg = k; }
+            if (v1 > best) { best = v1; arg = k + 1; }
+        }
+        if (k < G.K) {
+            const float* t = s_l + k * cells;
+            const float v0 = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);
+            sum0 += fast_exp(v0 - bound);
+            if (v0 > best) { best = v0; arg = k; }
+        }
+        float sum = sum0 + sum1, mx = bound;
+        if (!(sum > 1e-30f)) {      // taps disagreeing by more than ~70 in some class: the bound is too far above; running maximum
+            mx = best; sum = 0.f;
+            for (k = 0; k < G.K; ++k) {
+                const float* t = s_l + k * cells;
+                sum += fast_exp(hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]) - mx);
+            }
+        }
+        float at_label = 0.f;
+        if (counted) {
+            const float* t = s_l + (int)lab * cells;
+            at_label = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);
+        }
+        const float l = mx + logf(sum);
+        lse[((long)m * G.H + oy) * G.W + ox] = l;
+        loss = counted ? l - at_label : 0.f;
+        hit = (counted && arg == (int)lab) ? 1.f : 0.f;
+    }
+    loss = wave_sum(loss);
+    hit = wave_sum(hit);
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = loss; s_red[1][threadIdx.x >> 6] = hit; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[blk * 2 + threadIdx.x] = (s_red[threadIdx.x][0] + s_red[threadIdx.x][1]) + (s_red[threadIdx.x][2] + s_red[threadIdx.x][3]);
+    }
+}
+
+// dlogits[m][k][qy][qx] = scale * (*gscale) * sum over output pixels p tapping q (labels counted) of w(p,q) * (softmax_k(p) - [k == label_p])
+// grid (ceil(w/4), ceil(h/4), M); 256 threads = 16 low-resolution pixels x 16 class lanes; dynamic LDS: rn*cn*K floats (the
+// tile's pixels and one ring around them: every tap of every output pixel that taps a tile pixel) + the footprint's lse / labels.
+__global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                   const float* __restrict__ lse, const float* __restrict__ gscale, float scale,
+                                                   float* __restrict__ dlogits, UpceGeom G) {
+    CFFM_DYN_SMEM(smem);
+    float* s_l = (float*)smem;
+    const int m = blockIdx.z, q0y = blockIdx.y * UPCE_QT, q0x = blockIdx.x * UPCE_QT;
+    const int r0 = q0y > 0 ? q0y - 1 : 0, c0 = q0x > 0 ? q0x - 1 : 0;
+    upce_stage(s_l, logits, G, m, r0, c0);
+    // the tile's footprint in the output: log-sum-exp and label of every pixel that can tap a tile pixel, staged once
+    // (read straight from global inside the loops they were two dependent loads per visited pixel: 914 us)
+    const float isy = (float)G.H / (float)G.h, isx = (float)G.W / (float)G.w;
+    const int q1y = q0y + UPCE_QT - 1 < G.h - 1 ? q0y + UPCE_QT - 1 : G.h - 1, q1x = q0x + UPCE_QT - 1 < G.w - 1 ? q0x + UPCE_QT - 1 : G.w - 1;
+    int fy0 = (int)floorf(((float)q0y - 0.5f) * isy - 0.5f) - 1, fy1 = (int)ceilf(((float)q1y + 1.5f) * isy - 0.5f) + 1;
+    int fx0 = (int)floorf(((float)q0x - 0.5f) * isx - 0.5f) - 1, fx1 = (int)ceilf(((float)q1x + 1.5f) * isx - 0.5f) + 1;
+    fy0 = fy0 < 0 ? 0 : fy0; fx0 = fx0 < 0 ? 0 : fx0;
+    fy1 = fy1 > G.H - 1 ? G.H - 1 : fy1; fx1 = fx1 > G.W - 1 ? G.W - 1 : fx1;
+    const int fw = fx1 - fx0 + 1, fn = (fy1 - fy0 + 1) * fw;
+    float* s_lse = s_l + G.K * G.rn * G.cn;
+    int* s_lab = (int*)(s_lse + UPCE_FOOT * UPCE_FOOT);
+    for (int e = threadIdx.x; e < fn; e += 256) {
+        const int fy = e / fw, fx = e - fy * fw;
+        const long pix = ((long)m * G.H + fy0 + fy) * G.W + fx0 + fx;
+        const long long lab = labels[pix];
+        s_lse[e] = lse[pix];
+        s_lab[e] = (lab == G.ignore || lab < 0 || lab >= G.K) ? -1 : (int)lab;
+    }
+    __syncthreads();
+    const int q = threadIdx.x >> 4, cl = threadIdx.x & 15, qy = q0y + (q >> 2), qx = q0x + (q & 3);
+    if (qy >= G.h || qx >= G.w) return;
+    int ylo = (int)floorf(((float)qy - 0.5f) * isy - 0.5f) - 1, yhi = (int)ceilf(((float)qy + 1.5f) * isy - 0.5f) + 1;
+    int xlo = (int)floorf(((float)qx - 0.5f) * isx - 0.5f) - 1, xhi = (int)ceilf(((float)qx + 1.5f) * isx - 0.5f) + 1;
+    ylo = ylo < fy0 ? fy0 : ylo; xlo = xlo < fx0 ? fx0 : xlo;
+    yhi = yhi > fy1 ? fy1 : yhi; xhi = xhi > fx1 ? fx1 : xhi;
+    const int cells = G.rn * G.cn;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int yy = ylo; yy <= yhi; ++yy) {
+        int y0, y1;
+        float ly;
+        segf_taps(yy, G.h, G.H, y0, y1, ly);
+        const float wy = (y0 == qy ? 1.f - ly : 0.f) + (y1 == qy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int xx = xlo; xx <= xhi; ++xx) {
+            int x0, x1;
+            float lx;
+            segf_taps(xx, G.w, G.W, x0, x1, lx);
+            const float wq = wy * ((x0 == qx ? 1.f - lx : 0.f) + (x1 == qx ? lx : 0.f));
+            if (wq == 0.f) continue;
+            const int fe = (yy - fy0) * fw + (xx - fx0);
+            const int lab = s_lab[fe];
+            if (lab < 0) continue;
+            const float l = s_lse[fe];
+            const int a = (y0 - r0) * G.cn + (x0 - c0), b = (y0 - r0) * G.cn + (x1 - c0), c = (y1 - r0) * G.cn + (x0 - c0),
+                      d = (y1 - r0) * G.cn + (x1 - c0);
+            const float hx0 = 1.f - lx, hy0 = 1.f - ly;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = cl + 16 * i;
+                if (k < G.K) {
+                    const float* t = s_l + k * cells;
+                    const float v = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);
+                    acc[i] += wq * (fast_exp(v - l) - (k == lab ? 1.f : 0.f));
+                }
+            }
+        }
+    }
+    const float sc = scale * (gscale ? *gscale : 1.f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = cl + 16 * i;
+        if (k < G.K) dlogits[(((long)m * G.K + k) * G.h + qy) * G.w + qx] = sc * acc[i];
+    }
+}

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .modules import BasicLayer3d3, BasicLayer_cluster
 from . import _lib
-from .ops import segformer_fuse
+from .ops import resize_cross_entropy, segformer_fuse
 from .registry import HEADS, LOSSES, build_loss
 
 
@@ -149,6 +149,17 @@ class BaseDecodeHead_clips_flow(nn.Module):
     def cls_seg(self, feat):
         return self.conv_seg(self.dropout(feat) if self.dropout is not None else feat)
 
+    # 'hip': resize + cross entropy + accuracy fused (ops.resize_cross_entropy) for GPU tensors when the configured loss is the
+    # plain softmax cross entropy of every CFFM config (mean reduction, no class weights, align_corners False); 'torch': the
+    # reference's op sequence (what CPU tensors and other loss settings get).
+    loss_impl = 'hip'
+
+    def _fused_loss_ok(self, seg_logit):
+        ld = self.loss_decode
+        return (self.loss_impl == 'hip' and (seg_logit.is_cuda or _lib._override is not None)
+                and type(ld) is CrossEntropyLoss and ld.class_weight is None and ld.reduction == 'mean'
+                and not self.align_corners and seg_logit.dtype == torch.float32)
+
     def losses(self, seg_logit, seg_label):
         """0.5 * CE(per-frame logits, all frames) + CE(clip-level logits, last frame)  (decode_head.py:744-835).
         seg_logit [B, T+e, K, h, w] with e extra clip-level maps, seg_label [B, T, 1, H, W]."""
@@ -166,6 +177,13 @@ class BaseDecodeHead_clips_flow(nn.Module):
         frame_labels = frame_labels.flatten(0, 1).squeeze(1)
         clip_labels = seg_label[:, -1:].expand(-1, e, -1, -1, -1).flatten(0, 1).squeeze(1)
         size = seg_label.shape[3:]
+        if self._fused_loss_ok(seg_logit):
+            # resize + cross entropy + accuracy in libcffm_hip.so: the [M,K,H,W] resized logits are never materialised
+            w = self.loss_decode.loss_weight
+            fsum, fhits = resize_cross_entropy(frame_logits, frame_labels, self.ignore_index)
+            csum, _ = resize_cross_entropy(clip_logits, clip_labels, self.ignore_index)
+            loss = 0.5 * w * fsum / frame_labels.numel() + w * csum / clip_labels.numel()
+            return dict(loss_seg=loss, acc_seg=(fhits * (100.0 / frame_labels.numel())).reshape(1))
         frame_logits = resize(frame_logits, size=size, mode='bilinear', align_corners=self.align_corners)
         clip_logits = resize(clip_logits, size=size, mode='bilinear', align_corners=self.align_corners)
         loss = 0.5 * self.loss_decode(frame_logits, frame_labels, weight=None, ignore_index=self.ignore_index) \

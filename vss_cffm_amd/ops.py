@@ -278,6 +278,55 @@ def segformer_fuse(feats, lin_w, lin_b, fuse_w):
     return _SegFuseFn.apply(d, *feats, *mats)
 
 
+# ---------------------------------------------------------------------------------------------- resize + cross entropy
+class _UpceFn(torch.autograd.Function):
+    """sum over pixels of CE(resize(logits)[pixel], label[pixel]) and the number of pixels whose arg-max is the label,
+    without the [M,K,H,W] resized logits (csrc/segloss_kernels.h)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        lib = _lib.get()
+        _require_device(logits, 'resize_cross_entropy logits')
+        if logits.dim() != 4 or labels.dim() != 3 or labels.shape[0] != logits.shape[0] or labels.dtype != torch.int64:
+            raise _lib.CffmError('resize_cross_entropy: logits [M,K,h,w] fp32 and labels [M,H,W] int64 expected, got %s %s / %s %s'
+                                 % (tuple(logits.shape), logits.dtype, tuple(labels.shape), labels.dtype))
+        if labels.device != logits.device:
+            raise _lib.CffmError('resize_cross_entropy: labels on %s, logits on %s' % (labels.device, logits.device))
+        logits, labels = logits.contiguous(), labels.contiguous()
+        m, k, h, w = logits.shape
+        H, W = labels.shape[1:]
+        lse = torch.empty(m, H, W, dtype=torch.float32, device=logits.device)
+        part = torch.empty(lib.cffm_upce_blocks(m, H, W), 2, dtype=torch.float32, device=logits.device)
+        _lib.check(lib.cffm_upce_fwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(part), m, k, h, w, H, W, int(ignore_index),
+                                     _stream(logits)), lib)
+        sums = part.double().sum(0).float()          # [loss sum, hits]: a plain deterministic reduction of the workgroup records
+        ctx.save_for_backward(logits, labels, lse)
+        ctx.ignore_index = int(ignore_index)
+        hits = sums[1].clone()
+        ctx.mark_non_differentiable(hits)
+        return sums[0].clone(), hits
+
+    @staticmethod
+    def backward(ctx, gloss, _ghits):
+        lib = _lib.get()
+        logits, labels, lse = ctx.saved_tensors
+        m, k, h, w = logits.shape
+        H, W = labels.shape[1:]
+        gs = gloss.to(torch.float32).contiguous()    # device scalar: read by the kernel, never by the host
+        dlogits = torch.empty_like(logits)
+        _lib.check(lib.cffm_upce_bwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(gs), 1.0, _ptr(dlogits), m, k, h, w, H, W,
+                                     ctx.ignore_index, _stream(logits)), lib)
+        return dlogits, None, None
+
+
+def resize_cross_entropy(logits, labels, ignore_index=255):
+    """(sum of per-pixel cross entropies, number of correctly classified pixels) of `logits` [M,K,h,w] resized bilinearly
+    (align_corners=False) to the labels' [M,H,W] resolution -- what decode_head.py:744-835 computes through a materialised
+    [M,K,H,W] tensor (resize -> F.cross_entropy(reduction='none', ignore_index) -> sum; accuracy's arg-max == label count).
+    Ignored pixels add 0 to both, as in the reference; divide by labels.numel() for its `mean` / percentage."""
+    return _UpceFn.apply(logits, labels, ignore_index)
+
+
 # ---------------------------------------------------------------------------------------------- GTC
 GTC_PARAM_KEYS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.qkv_cluster.weight',
                   'attn.qkv_cluster.bias', 'attn.proj_cluster.weight', 'attn.proj_cluster.bias', 'norm2.weight',
