@@ -108,6 +108,8 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
                   float* dbiasT /*[8,304,64], overwritten*/, float* dkv_part, void* stream);
 /* y[M,N] = x[M,K] w[N,K]^T ;  dx[M,K] = dy[M,N] w[N,K] ;  dw[N,K] = dy[M,N]^T x[M,K]   (row-major, no bias) */
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream);
+/* y[M,N] = x[M,K] w[N,K]^T + b[N]   (a 1x1 convolution on channels-last token rows: the head's classifiers, cffm_head.py:121,147) */
+int cffm_linear_bias_fwd(const float* x, const float* w, const float* b, float* y, long M, int N, int K, void* stream);
 int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream);
 int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream);
 /* n <= 4 independent weight gradients (dw_i[N_i,K_i] = dy_i[M_i,N_i]^T x_i[M_i,K_i]) in one launch: the four Linear layers of a
@@ -119,7 +121,7 @@ int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* 
                          void* stream);
 int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, const float* res, float* out, long M, int N,
                              int K, void* stream);
-int cffm_colsum(const float* a, long rows, int cols, float* out /* overwritten */, void* stream);
+int cffm_colsum(const float* a, long rows, int cols /* multiple of 4 */, float* out /* overwritten */, void* stream);
 int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
                      const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,
                      long nrows, void* stream);

@@ -69,3 +69,44 @@ def test_linear_gpu():
     lib = _lib.get()
     shapes = [(70, 96, 40), (1000, 256, 256), (7200, 1024, 256), (7200, 256, 1024), (10368, 768, 256), (6480, 256, 256), (3969, 768, 256)]
     run_linear_checks(lib, torch.device('cuda:0'), shapes, [(10368, 7200), (200, 136), (12960, 12960), (3969, 3600)])
+
+
+# ---- the head's 1x1 classifiers as a GEMM on token rows (ops.conv1x1; cffm_head.py:121,147,524) ----------------------------
+def run_conv1x1_checks(device):
+    import torch.nn.functional as F
+    from vss_cffm_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    for (n, c, o, h, w, channels_last, strided_dy) in [(2, 40, 124, 5, 7, True, False), (3, 256, 124, 6, 6, False, True),
+                                                       (1, 64, 8, 3, 9, True, True), (0, 32, 124, 4, 4, False, False)]:
+        x = torch.randn(n, c, h, w, generator=gen)
+        wt, b = torch.randn(o, c, 1, 1, generator=gen) * 0.1, torch.randn(o, generator=gen)
+        dy = torch.randn(n, o + 3, h, w, generator=gen)[:, 1:o + 1] if strided_dy else torch.randn(n, o, h, w, generator=gen)
+        xr, wr, br = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+        F.conv2d(xr, wr, br).backward(dy.double())
+        xd = x.to(device)
+        if channels_last:
+            xd = xd.contiguous(memory_format=torch.channels_last)
+        xd = xd.requires_grad_(True)
+        wd, bd = wt.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+        y = ops.conv1x1(xd, wd, bd)
+        assert y.shape == (n, o, h, w)
+        y.backward(dy.to(device))
+        if n:
+            assert rel(y.detach(), F.conv2d(x.double(), wt.double(), b.double())) < TOL
+            assert rel(xd.grad, xr.grad) < TOL and rel(wd.grad, wr.grad) < TOL and rel(bd.grad, br.grad) < TOL
+        else:
+            assert float(wd.grad.abs().sum()) == 0.0 and float(bd.grad.abs().sum()) == 0.0
+
+
+    with pytest.raises(_lib.CffmError):           # 19 classes: rows of 76 bytes -- the head keeps nn.Conv2d for such sizes
+        ops.conv1x1(torch.zeros(1, 32, 2, 2, device=device), torch.zeros(19, 32, 1, 1, device=device), torch.zeros(19, device=device))
+
+
+def test_conv1x1_emulated():
+    with emu.active():
+        run_conv1x1_checks(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_conv1x1_gpu():
+    run_conv1x1_checks(torch.device('cuda:0'))

@@ -57,6 +57,7 @@ SIGNATURES = {
     'cffm_attn_fwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_attn_bwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_linear_fwd': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_bias_fwd': (ci, [vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_input': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight_group': (ci, [vp, ci, vp]),

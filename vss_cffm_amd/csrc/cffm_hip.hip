@@ -462,6 +462,18 @@ int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int
     PROF(ST_GEMM);
     return gemm_nt(x, w, y, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_fwd: gemm failed") : 0;
 }
+int cffm_linear_bias_fwd(const float* x, const float* w, const float* b, float* y, long M, int N, int K, void* stream) {
+    REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && K >= 1, "linear_bias_fwd: bad sizes (N must be a multiple of 4)");
+    if (!M) return 0;
+    REQUIRE(x && w && b && y, "linear_bias_fwd: null");
+    PROF(ST_GEMM);
+    if (gemm_use_lib()) {
+        if (gemm_nt_lib(x, w, y, M, N, K, (hipStream_t)stream)) return fail(-3, "linear_bias_fwd: gemm failed");
+        CFFM_LAUNCH(k_add_bias_rows, ((unsigned)((M * N + 255) / 256)), (256), 0, (hipStream_t)stream, y, b, M, N);
+        return 0;
+    }
+    return gemm_split_launch<false, false>(x, w, y, (int)M, N, K, K, K, N, 1, (hipStream_t)stream, b) ? fail(-3, "linear_bias_fwd: gemm failed") : 0;
+}
 int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream) {
     PROF(ST_GEMM);
     return gemm_nn(dy, w, dx, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_input: gemm failed") : 0;
@@ -523,7 +535,7 @@ int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, con
 int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
     PROF(ST_COLSUM);
     hipStream_t st = (hipStream_t)stream;
-    REQUIRE(cols % 256 == 0, "colsum: cols must be a multiple of 256");
+    REQUIRE(a && out && cols >= 4 && cols % 4 == 0, "colsum: cols must be a multiple of 4");
     const int slices = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
     float* part = red_scratch((size_t)slices * cols, st);
     REQUIRE(part, "colsum: scratch allocation failed");

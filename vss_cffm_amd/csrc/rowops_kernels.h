@@ -395,6 +395,12 @@ __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict_
     }
 }
 
+// y[r][c] += b[c]   (library-GEMM cross-check path of cffm_linear_bias_fwd)
+__global__ void __launch_bounds__(256) k_add_bias_rows(float* __restrict__ y, const float* __restrict__ b, long M, int N) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < M * N) y[e] += b[e % N];
+}
+
 // a += b (f32x4)
 __global__ void __launch_bounds__(256) k_add_inplace(float* __restrict__ a, const float* __restrict__ b, long n4) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256)

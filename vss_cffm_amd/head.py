@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .modules import BasicLayer3d3, BasicLayer_cluster
 from . import _lib
-from .ops import resize_cross_entropy, segformer_fuse
+from .ops import conv1x1, resize_cross_entropy, segformer_fuse
 from .registry import HEADS, LOSSES, build_loss
 
 
@@ -250,8 +250,15 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
             maps.append(m if c is c1 else resize(m, size=size, mode='bilinear', align_corners=False))
         return self.linear_fuse(torch.cat(maps, dim=1))
 
+    def _classify(self, conv, feat):
+        """a 1x1 classifier (`linear_pred*`): libcffm_hip.so's GEMM on token rows for GPU tensors, nn.Conv2d otherwise"""
+        if (self.fuse_impl == 'hip' and (feat.is_cuda or _lib._override is not None) and feat.dtype == torch.float32
+                and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0):      # 16-byte token rows (e.g. not 19 classes)
+            return conv1x1(feat, conv.weight, conv.bias)
+        return conv(feat)
+
     def _frame_logits(self, fused, batch_size, num_clips):
-        x = self.linear_pred(self.dropout(fused) if self.dropout is not None else fused)
+        x = self._classify(self.linear_pred, self.dropout(fused) if self.dropout is not None else fused)
         return x.reshape(batch_size, num_clips, -1, fused.shape[2], fused.shape[3])
 
     def _clip_features(self, fused, batch_size, num_clips):
@@ -265,7 +272,7 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
 
     def _clip_logits(self, stack, mined, size):
         feat = torch.cat([stack[:, -1], mined[:, -1]], 1)
-        x2 = self.linear_pred2(self.dropout(feat) if self.dropout is not None else feat)
+        x2 = self._classify(self.linear_pred2, self.dropout(feat) if self.dropout is not None else feat)
         return resize(x2, size=size, mode='bilinear', align_corners=False).unsqueeze(1)
 
 
@@ -382,7 +389,7 @@ class CFFMHead_clips_resize1_8_finetune_w_prototype3(_CffmHeadBase):
         tokens = stack[:, -1].permute(0, 2, 3, 1).reshape(b, h2 * w2, c)
         ctx = self.decoder_swin(tokens, h2, w2, centers)[0]
         ctx = ctx.reshape(b, h2, w2, c).permute(0, 3, 1, 2)
-        x3 = resize(self.linear_pred3(self.dropout3(ctx)), size=fused.shape[2:], mode='bilinear', align_corners=False)
+        x3 = resize(self._classify(self.linear_pred3, self.dropout3(ctx)), size=fused.shape[2:], mode='bilinear', align_corners=False)
         x3 = x3.unsqueeze(1)
         if not self.training:
             return x2.squeeze(1) + 0.5 * x3.squeeze(1)

@@ -177,6 +177,19 @@ def cffm_layer(x, depth, params):
     return torch.cat([x[:, :-1], y.unsqueeze(1)], dim=1)       # cffm_transformer.py:826
 
 
+# ---------------------------------------------------------------------------------------------- NCHW <-> token rows
+def _to_rows(lib, x):
+    """[N,C,H,W] (any strides) -> contiguous token rows [N,H,W,C].  Plain NCHW goes through the library's tiled transpose,
+    channels-last memory is already rows.  (The operators RETURN channels-last views: handing BatchNorm / ReLU / dropout plain
+    NCHW instead made the whole head step slower, 5.3 -> 6.4 ms.)"""
+    n, c, h, w = x.shape
+    if x.is_contiguous() and x.numel() and c > 1 and h * w > 1:
+        rows = torch.empty(n, h, w, c, dtype=torch.float32, device=x.device)
+        _lib.check(lib.cffm_transpose(_ptr(x), _ptr(rows), n, c, h * w, c * h * w, c * h * w, _stream(x)), lib)
+        return rows
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
 # ---------------------------------------------------------------------------------------------- SegFormer embedding
 class _SegFuseFn(torch.autograd.Function):
     """sum_i resize_i(A_i c_i) + d on token rows: features c_i [N,C_i,h_i,w_i] (c_0 at the output resolution), composed
@@ -214,7 +227,7 @@ class _SegFuseFn(torch.autograd.Function):
             _lib.check(lib.cffm_segfuse_fwd(_ptr(y), _ptr(d.contiguous()), zp, hs, ws, k - 1, n, H, W, st), lib)
         ctx.save_for_backward(*toks, *mats)
         ctx.shapes = [tuple(c.shape) for c in feats]
-        return y.view(n, H, W, 256).permute(0, 3, 1, 2)
+        return y.view(n, H, W, 256).permute(0, 3, 1, 2)       # channels-last memory: BatchNorm / ReLU / dropout run on it natively
 
     @staticmethod
     def backward(ctx, g):
@@ -223,7 +236,7 @@ class _SegFuseFn(torch.autograd.Function):
         k = len(shapes)
         toks, mats = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
         n, _, H, W = shapes[0]
-        g = g.permute(0, 2, 3, 1).contiguous()                                # [N,H,W,256] rows (no copy if channels-last)
+        g = _to_rows(lib, g)                                                  # [N,H,W,256] rows
         st, dev = _stream(g), g.device
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         dd = new(256)
@@ -276,6 +289,62 @@ def segformer_fuse(feats, lin_w, lin_b, fuse_w):
     mats = [wf[:, k - 1 - i] @ lin_w[i] for i in range(k)]
     d = sum(wf[:, k - 1 - i] @ lin_b[i] for i in range(k))
     return _SegFuseFn.apply(d, *feats, *mats)
+
+
+# ---------------------------------------------------------------------------------------------- 1x1 classifiers
+class _Conv1x1Fn(torch.autograd.Function):
+    """A 1x1 convolution as a Linear GEMM on channels-last token rows: x [N,C,H,W] (any strides; channels-last costs no copy),
+    weight [O,C,1,1], bias [O] -> [N,O,H,W] in channels-last memory."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.get()
+        for t in (x, weight, bias):
+            _require_device(t, 'conv1x1 operand')
+        if x.dim() != 4 or weight.dim() != 4 or tuple(weight.shape[1:]) != (x.shape[1], 1, 1) or bias.shape != (weight.shape[0],):
+            raise _lib.CffmError('conv1x1: x %s, weight %s, bias %s do not fit a 1x1 convolution'
+                                 % (tuple(x.shape), tuple(weight.shape), tuple(bias.shape)))
+        n, c, h, w = x.shape
+        o = weight.shape[0]
+        if c % 4 or o % 4:
+            raise _lib.CffmError('conv1x1: channel counts must be multiples of 4 (16-byte token rows), got %d -> %d' % (c, o))
+        rows = _to_rows(lib, x)                                   # [N,H,W,C] token rows
+        wm, b = weight.reshape(o, c).contiguous(), bias.contiguous()
+        y = torch.empty(n, h, w, o, dtype=torch.float32, device=x.device)
+        _lib.check(lib.cffm_linear_bias_fwd(_ptr(rows), _ptr(wm), _ptr(b), _ptr(y), n * h * w, o, c, _stream(x)), lib)
+        ctx.save_for_backward(rows, wm)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.get()
+        rows, wm = ctx.saved_tensors
+        n, h, w, c = rows.shape
+        o = wm.shape[0]
+        m, st = n * h * w, _stream(rows)
+        dyr = _to_rows(lib, dy)
+        dx = dwm = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dy.device)
+            if m:
+                _lib.check(lib.cffm_linear_bwd_input(_ptr(dyr), _ptr(wm), _ptr(dx), m, o, c, st), lib)
+            dx = dx.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dwm = torch.zeros(o, c, dtype=torch.float32, device=dy.device)
+            if m:
+                _lib.check(lib.cffm_linear_bwd_weight(_ptr(dyr), _ptr(rows), _ptr(dwm), m, o, c, st), lib)
+            dwm = dwm.view(o, c, 1, 1)
+        if ctx.needs_input_grad[2]:
+            db = torch.zeros(o, dtype=torch.float32, device=dy.device)
+            if m:
+                _lib.check(lib.cffm_colsum(_ptr(dyr), m, o, _ptr(db), st), lib)
+        return dx, dwm, db
+
+
+def conv1x1(x, weight, bias):
+    """nn.Conv2d(C, O, kernel_size=1)(x) (the head's classifiers `linear_pred*`, cffm_head.py:121,147,524) as a split-bf16 MFMA
+    GEMM on token rows; returns [N,O,H,W] in channels-last memory."""
+    return _Conv1x1Fn.apply(x, weight, bias)
 
 
 # ---------------------------------------------------------------------------------------------- resize + cross entropy
