@@ -72,6 +72,7 @@ long cffm_layer_scratch_floats(const cffm_geom* g);
 /* ---- optional per-stage HIP-event timing on the caller's stream (bench.py's live roofline numbers) ---- */
 int cffm_profile_enable(int stage_mask); /* bit i = stage i; 0 off; -1 all (perturbs: two event records per launch) */
 int cffm_profile_stage_count(void);
+int cffm_profile_null_pair(void* stream); /* stage "event_pair_null": two event records with nothing between (the interval's own cost) */
 const char* cffm_profile_stage_name(int i);
 int cffm_profile_collect(float* ms /*[stage_count]*/, int* calls /*[stage_count]*/); /* synchronises, sums, clears */
 /* Stages enabled while the caller's stream is being CAPTURED into a HIP graph put their event pairs into the graph as
