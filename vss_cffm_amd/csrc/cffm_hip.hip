@@ -976,7 +976,7 @@ int cffm_upce_fwd(const float* logits, const long long* labels, float* lse, floa
     REQUIRE(logits && labels && lse && part, "upce_fwd: null");
     G.rn = span_taps(h, H);
     G.cn = span_taps(w, W);
-    const size_t lds = (size_t)G.rn * G.cn * (K + 1) * sizeof(float);
+    const size_t lds = (size_t)G.rn * G.cn * (UPCE_KP(K) + 1) * sizeof(float);
     TRY(upce_lds((const void*)k_upce_fwd, lds, "upce_fwd"));
     hipStream_t st = (hipStream_t)stream;
     CFFM_LAUNCH(k_upce_fwd, ((unsigned)((W + UPCE_TILE - 1) / UPCE_TILE), (unsigned)((H + UPCE_TILE - 1) / UPCE_TILE), (unsigned)M),
@@ -992,7 +992,7 @@ int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse
     REQUIRE(logits && labels && lse && dlogits, "upce_bwd: null");
     G.rn = std::min(h, UPCE_QT + 2);
     G.cn = std::min(w, UPCE_QT + 2);
-    const size_t lds = ((size_t)G.rn * G.cn * K + 2 * UPCE_FOOT * UPCE_FOOT) * sizeof(float);
+    const size_t lds = ((size_t)G.rn * G.cn * UPCE_KP(K) + 2 * UPCE_FOOT * UPCE_FOOT) * sizeof(float);
     TRY(upce_lds((const void*)k_upce_bwd, lds, "upce_bwd"));
     hipStream_t st = (hipStream_t)stream;
     CFFM_LAUNCH(k_upce_bwd, ((unsigned)((w + UPCE_QT - 1) / UPCE_QT), (unsigned)((h + UPCE_QT - 1) / UPCE_QT), (unsigned)M), (256), lds,

@@ -21,27 +21,48 @@ struct UpceGeom {
     int rn, cn;                 // rows / columns of the low-resolution LDS tile
 };
 
-// stage rows r0.. / columns c0.. (rn x cn, clamped to the map) of all K channels of map m: s_l[k][r * cn + c]
+#ifndef UPCE_ABLATE
+#define UPCE_ABLATE 0
+#endif
+#if UPCE_ABLATE & 1          // timing experiments only: no exponential
+#define UPCE_EXP(x) (x)
+#else
+#define UPCE_EXP(x) fast_exp(x)
+#endif
+#define UPCE_KP(K) (((K) + 3) & ~3)       // classes padded to whole 16-byte groups (padding logits = -1e30: exp -> 0, never the arg-max)
+
+// stage rows r0.. / columns c0.. (rn x cn, clamped to the map) of all K channels of map m as s_l[cell][KP]: a thread reads
+// four classes of a tap with one ds_read_b128 and interpolates them with packed fp32 math
 __device__ __forceinline__ void upce_stage(float* s_l, const float* __restrict__ logits, const UpceGeom& G, int m, int r0, int c0) {
-    const int cells = G.rn * G.cn;
+    const int cells = G.rn * G.cn, KP = UPCE_KP(G.K);
     const float* base = logits + (long)m * G.K * G.h * G.w;
-    for (int e = threadIdx.x; e < G.K * cells; e += 256) {
+    for (int e = threadIdx.x; e < KP * cells; e += 256) {
         const int k = e / cells, rc = e - k * cells, r = rc / G.cn, c = rc - r * G.cn;
         const int rr = r0 + r < G.h ? r0 + r : G.h - 1, cc = c0 + c < G.w ? c0 + c : G.w - 1;
-        s_l[e] = base[((long)k * G.h + rr) * G.w + cc];
+        s_l[rc * KP + k] = k < G.K ? base[((long)k * G.h + rr) * G.w + cc] : -1.0e30f;
     }
 }
-// s_l[K][cell] = max over k of s_l[k][cell] (after upce_stage + barrier; needs another barrier)
+// s_l[cells * KP + cell] = max over k of s_l[cell][k] (after upce_stage + barrier; needs another barrier)
 __device__ __forceinline__ void upce_cell_max(float* s_l, const UpceGeom& G) {
-    const int cells = G.rn * G.cn;
+    const int cells = G.rn * G.cn, KP = UPCE_KP(G.K);
     for (int e = threadIdx.x; e < cells; e += 256) {
-        float mx = s_l[e];
-        for (int k = 1; k < G.K; ++k) mx = fmaxf(mx, s_l[k * cells + e]);
-        s_l[G.K * cells + e] = mx;
+        float mx = s_l[e * KP];
+        for (int k = 1; k < G.K; ++k) mx = fmaxf(mx, s_l[e * KP + k]);
+        s_l[cells * KP + e] = mx;
     }
+}
+__device__ __forceinline__ f32x4 upce_interp4(const float* s_l, int a, int b, int c, int d, int k4, float hx0, float lx, float hy0, float ly) {
+#if UPCE_ABLATE & 2          // timing experiments only: one LDS read instead of four
+    const f32x4 ta = ((const f32x4*)(s_l + a))[k4], tb = ta * 1.5f, tc = ta * 0.5f, td = ta * 0.25f;
+    (void)b; (void)c; (void)d;
+#else
+    const f32x4 ta = ((const f32x4*)(s_l + a))[k4], tb = ((const f32x4*)(s_l + b))[k4];
+    const f32x4 tc = ((const f32x4*)(s_l + c))[k4], td = ((const f32x4*)(s_l + d))[k4];
+#endif
+    return (ta * hx0 + tb * lx) * hy0 + (tc * hx0 + td * lx) * ly;      // ATen's order of operations
 }
 
-// grid (ceil(W/16), ceil(H/16), M), 256 threads = 16 x 16 output pixels; dynamic LDS rn*cn*(K+1) floats.
+// grid (ceil(W/16), ceil(H/16), M), 256 threads = 16 x 16 output pixels; dynamic LDS rn*cn*(KP+1) floats.
 // lse[m][y][x]; part[block][0] = sum of per-pixel losses, part[block][1] = number of pixels whose argmax is the label.
 __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                    float* __restrict__ lse, float* __restrict__ part, UpceGeom G) {
@@ -64,45 +85,40 @@ __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logi
         float ly, lx;
         segf_taps(oy, G.h, G.H, y0, y1, ly);
         segf_taps(ox, G.w, G.W, x0, x1, lx);
-        const int a = (y0 - r0) * G.cn + (x0 - c0), b = (y0 - r0) * G.cn + (x1 - c0), c = (y1 - r0) * G.cn + (x0 - c0),
-                  d = (y1 - r0) * G.cn + (x1 - c0), cells = G.rn * G.cn;
+        const int KP = UPCE_KP(G.K), cells = G.rn * G.cn;
+        const int ca = (y0 - r0) * G.cn + (x0 - c0), cb = (y0 - r0) * G.cn + (x1 - c0), cc = (y1 - r0) * G.cn + (x0 - c0),
+                  cd = (y1 - r0) * G.cn + (x1 - c0);
+        const int a = ca * KP, b = cb * KP, c = cc * KP, d = cd * KP;
         const float hx0 = 1.f - lx, hy0 = 1.f - ly;
         const long long lab = labels[((long)m * G.H + oy) * G.W + ox];
         const bool counted = lab != G.ignore && lab >= 0 && lab < G.K;
         // an interpolated logit is a convex combination of its four taps, so the largest tap value over all classes bounds every
-        // one of them: exponentials relative to that bound need no running rescale (s_l[K * cells + cell] = max over k).
-        const float* tm = s_l + G.K * cells;
-        const float bound = fmaxf(fmaxf(tm[a], tm[b]), fmaxf(tm[c], tm[d]));
-        float sum0 = 0.f, sum1 = 0.f, best = -3.0e38f;
+        // one of them: exponentials relative to that bound need no running rescale
+        const float* tm = s_l + cells * KP;
+        const float bound = fmaxf(fmaxf(tm[ca], tm[cb]), fmaxf(tm[cc], tm[cd]));
+        f32x4 sum4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float best = -3.0e38f;
         int arg = -1;
-        int k = 0;
-        for (; k + 1 < G.K; k += 2) {
-            const float* t = s_l + k * cells;
-            const float v0 = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);   // ATen's order of operations
-            const float v1 = hy0 * (hx0 * t[cells + a] + lx * t[cells + b]) + ly * (hx0 * t[cells + c] + lx * t[cells + d]);
-            sum0 += fast_exp(v0 - bound);
-            sum1 += fast_exp(v1 - bound);
-            if (v0 > best) { best = v0; arg = k; }
-            if (v1 > best) { best = v1; arg = k + 1; }
+        for (int k4 = 0; k4 < KP / 4; ++k4) {
+            const f32x4 v = upce_interp4(s_l, a, b, c, d, k4, hx0, lx, hy0, ly);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sum4[j] += fast_exp(v[j] - bound);
+                if (v[j] > best) { best = v[j]; arg = 4 * k4 + j; }
+            }
         }
-        if (k < G.K) {
-            const float* t = s_l + k * cells;
-            const float v0 = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);
-            sum0 += fast_exp(v0 - bound);
-            if (v0 > best) { best = v0; arg = k; }
-        }
-        float sum = sum0 + sum1, mx = bound;
-        if (!(sum > 1e-30f)) {      // taps disagreeing by more than ~70 in some class: the bound is too far above; running maximum
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]), mx = bound;
+        if (!(sum > 1e-30f)) {      // taps disagreeing by more than ~70 in some class: the bound is too far above; use the maximum
             mx = best; sum = 0.f;
-            for (k = 0; k < G.K; ++k) {
-                const float* t = s_l + k * cells;
-                sum += fast_exp(hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]) - mx);
+            for (int k4 = 0; k4 < KP / 4; ++k4) {
+                const f32x4 v = upce_interp4(s_l, a, b, c, d, k4, hx0, lx, hy0, ly);
+                for (int j = 0; j < 4; ++j) sum += fast_exp(v[j] - mx);
             }
         }
         float at_label = 0.f;
         if (counted) {
-            const float* t = s_l + (int)lab * cells;
-            at_label = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);
+            const int kl = (int)lab;
+            at_label = hy0 * (hx0 * s_l[a + kl] + lx * s_l[b + kl]) + ly * (hx0 * s_l[c + kl] + lx * s_l[d + kl]);
         }
         const float l = mx + logf(sum);
         lse[((long)m * G.H + oy) * G.W + ox] = l;
@@ -120,18 +136,19 @@ __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logi
 }
 
 // dlogits[m][k][qy][qx] = scale * (*gscale) * sum over output pixels p tapping q (labels counted) of w(p,q) * (softmax_k(p) - [k == label_p])
-// grid (ceil(w/4), ceil(h/4), M); 256 threads = 16 low-resolution pixels x 16 class lanes; dynamic LDS: rn*cn*K floats (the
-// tile's pixels and one ring around them: every tap of every output pixel that taps a tile pixel) + the footprint's lse / labels.
+// grid (ceil(w/4), ceil(h/4), M); 256 threads = 16 low-resolution pixels x 16 class lanes, a lane owning the f32x4 class groups
+// cl, cl + 16, cl + 32, cl + 48 (K <= 256); dynamic LDS: rn*cn*KP floats (the tile's pixels and one ring around them: every tap of
+// every output pixel that taps a tile pixel) + the footprint's lse / labels.
 __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                    const float* __restrict__ lse, const float* __restrict__ gscale, float scale,
                                                    float* __restrict__ dlogits, UpceGeom G) {
     CFFM_DYN_SMEM(smem);
     float* s_l = (float*)smem;
+    const int KP = UPCE_KP(G.K);
     const int m = blockIdx.z, q0y = blockIdx.y * UPCE_QT, q0x = blockIdx.x * UPCE_QT;
     const int r0 = q0y > 0 ? q0y - 1 : 0, c0 = q0x > 0 ? q0x - 1 : 0;
     upce_stage(s_l, logits, G, m, r0, c0);
     // the tile's footprint in the output: log-sum-exp and label of every pixel that can tap a tile pixel, staged once
-    // (read straight from global inside the loops they were two dependent loads per visited pixel: 914 us)
     const float isy = (float)G.H / (float)G.h, isx = (float)G.W / (float)G.w;
     const int q1y = q0y + UPCE_QT - 1 < G.h - 1 ? q0y + UPCE_QT - 1 : G.h - 1, q1x = q0x + UPCE_QT - 1 < G.w - 1 ? q0x + UPCE_QT - 1 : G.w - 1;
     int fy0 = (int)floorf(((float)q0y - 0.5f) * isy - 0.5f) - 1, fy1 = (int)ceilf(((float)q1y + 1.5f) * isy - 0.5f) + 1;
@@ -139,7 +156,7 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
     fy0 = fy0 < 0 ? 0 : fy0; fx0 = fx0 < 0 ? 0 : fx0;
     fy1 = fy1 > G.H - 1 ? G.H - 1 : fy1; fx1 = fx1 > G.W - 1 ? G.W - 1 : fx1;
     const int fw = fx1 - fx0 + 1, fn = (fy1 - fy0 + 1) * fw;
-    float* s_lse = s_l + G.K * G.rn * G.cn;
+    float* s_lse = s_l + KP * G.rn * G.cn;
     int* s_lab = (int*)(s_lse + UPCE_FOOT * UPCE_FOOT);
     for (int e = threadIdx.x; e < fn; e += 256) {
         const int fy = e / fw, fx = e - fy * fw;
@@ -149,16 +166,18 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
         s_lab[e] = (lab == G.ignore || lab < 0 || lab >= G.K) ? -1 : (int)lab;
     }
     __syncthreads();
+    // one thread per (low-resolution pixel, class lane).  (A wave per pixel with the window's rows split over four lane groups,
+    // so that all lanes walk the same columns, was slower: 1000 us vs 754 -- the windows are too short to split.)
     const int q = threadIdx.x >> 4, cl = threadIdx.x & 15, qy = q0y + (q >> 2), qx = q0x + (q & 3);
     if (qy >= G.h || qx >= G.w) return;
     int ylo = (int)floorf(((float)qy - 0.5f) * isy - 0.5f) - 1, yhi = (int)ceilf(((float)qy + 1.5f) * isy - 0.5f) + 1;
     int xlo = (int)floorf(((float)qx - 0.5f) * isx - 0.5f) - 1, xhi = (int)ceilf(((float)qx + 1.5f) * isx - 0.5f) + 1;
     ylo = ylo < fy0 ? fy0 : ylo; xlo = xlo < fx0 ? fx0 : xlo;
     yhi = yhi > fy1 ? fy1 : yhi; xhi = xhi > fx1 ? fx1 : xhi;
-    const int cells = G.rn * G.cn;
-    float acc[16];
+    const int ng = KP / 4;                      // 16-byte class groups; this lane owns groups cl, cl + 16, cl + 32, cl + 48
+    f32x4 acc[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int yy = ylo; yy <= yhi; ++yy) {
         int y0, y1;
         float ly;
@@ -175,24 +194,28 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
             const int lab = s_lab[fe];
             if (lab < 0) continue;
             const float l = s_lse[fe];
-            const int a = (y0 - r0) * G.cn + (x0 - c0), b = (y0 - r0) * G.cn + (x1 - c0), c = (y1 - r0) * G.cn + (x0 - c0),
-                      d = (y1 - r0) * G.cn + (x1 - c0);
+            const int a = ((y0 - r0) * G.cn + (x0 - c0)) * KP, b = ((y0 - r0) * G.cn + (x1 - c0)) * KP,
+                      c = ((y1 - r0) * G.cn + (x0 - c0)) * KP, d = ((y1 - r0) * G.cn + (x1 - c0)) * KP;
             const float hx0 = 1.f - lx, hy0 = 1.f - ly;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int k = cl + 16 * i;
-                if (k < G.K) {
-                    const float* t = s_l + k * cells;
-                    const float v = hy0 * (hx0 * t[a] + lx * t[b]) + ly * (hx0 * t[c] + lx * t[d]);
-                    acc[i] += wq * (fast_exp(v - l) - (k == lab ? 1.f : 0.f));
+            for (int i = 0; i < 4; ++i) {
+                const int k4 = cl + 16 * i;
+                if (k4 < ng) {
+                    const f32x4 v = upce_interp4(s_l, a, b, c, d, k4, hx0, lx, hy0, ly);
+                    f32x4 p;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p[j] = UPCE_EXP(v[j] - l) - (4 * k4 + j == lab ? 1.f : 0.f);
+                    acc[i] += p * wq;
                 }
             }
         }
     }
     const float sc = scale * (gscale ? *gscale : 1.f);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int k = cl + 16 * i;
-        if (k < G.K) dlogits[(((long)m * G.K + k) * G.h + qy) * G.w + qx] = sc * acc[i];
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * (cl + 16 * i) + j;
+            if (k < G.K) dlogits[(((long)m * G.K + k) * G.h + qy) * G.w + qx] = sc * acc[i][j];
+        }
 }
