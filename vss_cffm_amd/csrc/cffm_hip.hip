@@ -936,7 +936,7 @@ static int upce_geom(UpceGeom& G, int M, int K, int h, int w, int H, int W, int 
         (long)W > (long)UPCE_MAX_RATIO * w)
         return fail(-1, "%s: unsupported sizes (K=%d, %dx%d -> %dx%d; 1 <= K <= 256, resize factor 1..%d)", who, K, h, w, H, W,
                     UPCE_MAX_RATIO);
-    G.M = M; G.K = K; G.h = h; G.w = w; G.H = H; G.W = W; G.ignore = ignore; G.rn = G.cn = 0;
+    G.M = M; G.K = K; G.h = h; G.w = w; G.H = H; G.W = W; G.ignore = ignore; G.rn = G.cn = 0; G.foot = G.win = 0;
     return 0;
 }
 // host restatement of segf_taps (the LDS tile of the forward pass has to cover first tap .. last tap of a 16-pixel span)
@@ -992,7 +992,22 @@ int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse
     REQUIRE(logits && labels && lse && dlogits, "upce_bwd: null");
     G.rn = std::min(h, UPCE_QT + 2);
     G.cn = std::min(w, UPCE_QT + 2);
-    const size_t lds = ((size_t)G.rn * G.cn * UPCE_KP(K) + 2 * UPCE_FOOT * UPCE_FOOT) * sizeof(float);
+    // LDS capacities for this resize factor, from the kernel's own formulas (the same float expressions): the largest output
+    // footprint of a 4 x 4 tile along each dimension and the largest candidate window of one pixel
+    auto span = [](int q0, int q1, int in, int out) {     // candidate range of low-resolution indices q0..q1, clamped
+        const float is = (float)out / (float)in;
+        int lo = (int)floorf(((float)q0 - 0.5f) * is - 0.5f) - 1, hi = (int)ceilf(((float)q1 + 1.5f) * is - 0.5f) + 1;
+        lo = std::max(lo, 0); hi = std::min(hi, out - 1);
+        return hi - lo + 1;
+    };
+    int fy = 1, fx = 1, win = 1;
+    for (int q0 = 0; q0 < h; q0 += UPCE_QT) fy = std::max(fy, span(q0, std::min(q0 + UPCE_QT - 1, h - 1), h, H));
+    for (int q0 = 0; q0 < w; q0 += UPCE_QT) fx = std::max(fx, span(q0, std::min(q0 + UPCE_QT - 1, w - 1), w, W));
+    for (int q = 0; q < h; ++q) win = std::max(win, span(q, q, h, H));
+    for (int q = 0; q < w; ++q) win = std::max(win, span(q, q, w, W));
+    G.foot = (fy * fx + 1) & ~1;      // even: the tap tables behind the two footprint arrays stay 16-byte aligned
+    G.win = win;
+    const size_t lds = ((size_t)G.rn * G.cn * UPCE_KP(K) + 2 * (size_t)G.foot + 2 * 16 * G.win * 4) * sizeof(float);
     TRY(upce_lds((const void*)k_upce_bwd, lds, "upce_bwd"));
     hipStream_t st = (hipStream_t)stream;
     CFFM_LAUNCH(k_upce_bwd, ((unsigned)((w + UPCE_QT - 1) / UPCE_QT), (unsigned)((h + UPCE_QT - 1) / UPCE_QT), (unsigned)M), (256), lds,

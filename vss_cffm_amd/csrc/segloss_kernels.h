@@ -13,12 +13,12 @@
 #define UPCE_TILE 16            // output pixels per workgroup side (forward)
 #define UPCE_QT 4               // low-resolution pixels per workgroup side (backward)
 #define UPCE_MAX_RATIO 8
-#define UPCE_FOOT ((UPCE_QT + 2) * UPCE_MAX_RATIO + 4)   // side of the largest output footprint of a backward tile
 
 struct UpceGeom {
     int M, K, h, w, H, W;
     int ignore;                 // ignore_index (labels outside [0,K) are treated the same way)
     int rn, cn;                 // rows / columns of the low-resolution LDS tile
+    int foot, win;              // (backward) LDS capacity: footprint pixels of a tile, candidate rows / columns of a window
 };
 
 #ifndef UPCE_ABLATE
@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logi
 // dlogits[m][k][qy][qx] = scale * (*gscale) * sum over output pixels p tapping q (labels counted) of w(p,q) * (softmax_k(p) - [k == label_p])
 // grid (ceil(w/4), ceil(h/4), M); 256 threads = 16 low-resolution pixels x 16 class lanes, a lane owning the f32x4 class groups
 // cl, cl + 16, cl + 32, cl + 48 (K <= 256); dynamic LDS: rn*cn*KP floats (the tile's pixels and one ring around them: every tap of
-// every output pixel that taps a tile pixel) + the footprint's lse / labels.
+// every output pixel that taps a tile pixel) + the footprint's lse / labels + the tap tables (16 pixels x 2 x win x 16 B); foot / win are
+// sized by the host for the actual resize factor (a worst-case size left three workgroups per CU).
 __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                    const float* __restrict__ lse, const float* __restrict__ gscale, float scale,
                                                    float* __restrict__ dlogits, UpceGeom G) {
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
     fy1 = fy1 > G.H - 1 ? G.H - 1 : fy1; fx1 = fx1 > G.W - 1 ? G.W - 1 : fx1;
     const int fw = fx1 - fx0 + 1, fn = (fy1 - fy0 + 1) * fw;
     float* s_lse = s_l + KP * G.rn * G.cn;
-    int* s_lab = (int*)(s_lse + UPCE_FOOT * UPCE_FOOT);
+    int* s_lab = (int*)(s_lse + G.foot);
     for (int e = threadIdx.x; e < fn; e += 256) {
         const int fy = e / fw, fx = e - fy * fw;
         const long pix = ((long)m * G.H + fy0 + fy) * G.W + fx0 + fx;
@@ -168,40 +169,73 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
     __syncthreads();
     // one thread per (low-resolution pixel, class lane).  (A wave per pixel with the window's rows split over four lane groups,
     // so that all lanes walk the same columns, was slower: 1000 us vs 754 -- the windows are too short to split.)
+    // The tap rule of every candidate row / column of a pixel's window is evaluated ONCE, by the pixel's 16 lanes, into LDS
+    // tables {index << 1 | second-tap flag, LDS offset of the first tap, lambda, weight}; the loops below only read them
+    // (evaluating the rule per thread and visited pixel, and skipping zero-weight candidates after it, was ~80 % of the kernel).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4* s_ty = (i32x4*)(s_lab + G.foot);
+    i32x4* s_tx = s_ty + 16 * G.win;
     const int q = threadIdx.x >> 4, cl = threadIdx.x & 15, qy = q0y + (q >> 2), qx = q0x + (q & 3);
-    if (qy >= G.h || qx >= G.w) return;
+    const bool live = qy < G.h && qx < G.w;
     int ylo = (int)floorf(((float)qy - 0.5f) * isy - 0.5f) - 1, yhi = (int)ceilf(((float)qy + 1.5f) * isy - 0.5f) + 1;
     int xlo = (int)floorf(((float)qx - 0.5f) * isx - 0.5f) - 1, xhi = (int)ceilf(((float)qx + 1.5f) * isx - 0.5f) + 1;
     ylo = ylo < fy0 ? fy0 : ylo; xlo = xlo < fx0 ? fx0 : xlo;
     yhi = yhi > fy1 ? fy1 : yhi; xhi = xhi > fx1 ? fx1 : xhi;
+    yhi = yhi > ylo + G.win - 1 ? ylo + G.win - 1 : yhi; xhi = xhi > xlo + G.win - 1 ? xlo + G.win - 1 : xhi;   // (never binds)
+    for (int e = cl; e < G.win; e += 16) {
+        i32x4 ty = (i32x4){0, 0, 0, 0}, tx = ty;
+        if (live && ylo + e <= yhi) {
+            int i0, i1;
+            float l1;
+            segf_taps(ylo + e, G.h, G.H, i0, i1, l1);
+            const float wgt = (i0 == qy ? 1.f - l1 : 0.f) + (i1 == qy ? l1 : 0.f);
+            ty = (i32x4){((ylo + e - fy0) << 1) | (i1 != i0), (i0 - r0) * G.cn * KP, __builtin_bit_cast(int, l1), __builtin_bit_cast(int, wgt)};
+        }
+        if (live && xlo + e <= xhi) {
+            int i0, i1;
+            float l1;
+            segf_taps(xlo + e, G.w, G.W, i0, i1, l1);
+            const float wgt = (i0 == qx ? 1.f - l1 : 0.f) + (i1 == qx ? l1 : 0.f);
+            tx = (i32x4){((xlo + e - fx0) << 1) | (i1 != i0), (i0 - c0) * KP, __builtin_bit_cast(int, l1), __builtin_bit_cast(int, wgt)};
+        }
+        s_ty[q * G.win + e] = ty;
+        s_tx[q * G.win + e] = tx;
+    }
+    __syncthreads();
+    if (!live) return;
+    const int rstep = G.cn * KP;
+    // the tapping candidates are a contiguous run of the window: trim the zero-weight ends, so that the four pixels that share a
+    // wave run the same number of iterations, all of them useful (their runs start at different candidates)
+    int jy0 = 0, jy1 = yhi - ylo + 1, jx0 = 0, jx1 = xhi - xlo + 1;
+    while (jy0 < jy1 && s_ty[q * G.win + jy0][3] == 0) ++jy0;
+    while (jy1 > jy0 && s_ty[q * G.win + jy1 - 1][3] == 0) --jy1;
+    while (jx0 < jx1 && s_tx[q * G.win + jx0][3] == 0) ++jx0;
+    while (jx1 > jx0 && s_tx[q * G.win + jx1 - 1][3] == 0) --jx1;
     const int ng = KP / 4;                      // 16-byte class groups; this lane owns groups cl, cl + 16, cl + 32, cl + 48
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int yy = ylo; yy <= yhi; ++yy) {
-        int y0, y1;
-        float ly;
-        segf_taps(yy, G.h, G.H, y0, y1, ly);
-        const float wy = (y0 == qy ? 1.f - ly : 0.f) + (y1 == qy ? ly : 0.f);
+    for (int jy = jy0; jy < jy1; ++jy) {
+        const i32x4 ty = s_ty[q * G.win + jy];
+        const float wy = __builtin_bit_cast(float, (int)ty[3]);
         if (wy == 0.f) continue;
-        for (int xx = xlo; xx <= xhi; ++xx) {
-            int x0, x1;
-            float lx;
-            segf_taps(xx, G.w, G.W, x0, x1, lx);
-            const float wq = wy * ((x0 == qx ? 1.f - lx : 0.f) + (x1 == qx ? lx : 0.f));
+        const float ly = __builtin_bit_cast(float, (int)ty[2]), hy0 = 1.f - ly;
+        const int ra = ty[1], rb = ra + ((ty[0] & 1) ? rstep : 0), fer = (ty[0] >> 1) * fw;
+        for (int jx = jx0; jx < jx1; ++jx) {
+            const i32x4 tx = s_tx[q * G.win + jx];
+            const float wq = wy * __builtin_bit_cast(float, (int)tx[3]);
             if (wq == 0.f) continue;
-            const int fe = (yy - fy0) * fw + (xx - fx0);
+            const int fe = fer + (tx[0] >> 1);
             const int lab = s_lab[fe];
             if (lab < 0) continue;
             const float l = s_lse[fe];
-            const int a = ((y0 - r0) * G.cn + (x0 - c0)) * KP, b = ((y0 - r0) * G.cn + (x1 - c0)) * KP,
-                      c = ((y1 - r0) * G.cn + (x0 - c0)) * KP, d = ((y1 - r0) * G.cn + (x1 - c0)) * KP;
-            const float hx0 = 1.f - lx, hy0 = 1.f - ly;
+            const float lx = __builtin_bit_cast(float, (int)tx[2]), hx0 = 1.f - lx;
+            const int xa = tx[1], xb = xa + ((tx[0] & 1) ? KP : 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k4 = cl + 16 * i;
                 if (k4 < ng) {
-                    const f32x4 v = upce_interp4(s_l, a, b, c, d, k4, hx0, lx, hy0, ly);
+                    const f32x4 v = upce_interp4(s_l, ra + xa, ra + xb, rb + xa, rb + xb, k4, hx0, lx, hy0, ly);
                     f32x4 p;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) p[j] = UPCE_EXP(v[j] - l) - (4 * k4 + j == lab ? 1.f : 0.f);
