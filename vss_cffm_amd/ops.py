@@ -272,6 +272,46 @@ class _SegFuseFn(torch.autograd.Function):
         return (dd,) + tuple(dfeats) + tuple(dmats)
 
 
+class _ComposeFn(torch.autograd.Function):
+    """A_i = Wf_i W_i for every scale (Wf_i = the i-th [256,256] input-channel block of the fuse weight, cat order c_k..c_1) with
+    the library's GEMMs.  (As torch matmuls these 70-MFLOP products and their backward took 0.4 ms per step: rocBLAS runs each
+    on one 256x256 workgroup tile.)"""
+
+    @staticmethod
+    def forward(ctx, fuse_w2d, *lin_w):
+        lib = _lib.get()
+        k, e = len(lin_w), fuse_w2d.shape[0]
+        st = _stream(fuse_w2d)
+        blocks = [fuse_w2d[:, (k - 1 - i) * e:(k - i) * e].contiguous() for i in range(k)]
+        lin_w = [w.contiguous() for w in lin_w]
+        mats = []
+        for wf, w in zip(blocks, lin_w):
+            a = torch.empty(e, w.shape[1], dtype=torch.float32, device=w.device)
+            _lib.check(lib.cffm_linear_bwd_input(_ptr(wf), _ptr(w), _ptr(a), e, e, w.shape[1], st), lib)      # Wf_i @ W_i
+            mats.append(a)
+        ctx.save_for_backward(*blocks, *lin_w)
+        return tuple(mats)
+
+    @staticmethod
+    def backward(ctx, *dmats):
+        lib = _lib.get()
+        k = len(dmats)
+        blocks, lin_w = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        e = blocks[0].shape[0]
+        st = _stream(blocks[0])
+        dfw = torch.empty(e, k * e, dtype=torch.float32, device=blocks[0].device)
+        dws = []
+        for i, (wf, w, da) in enumerate(zip(blocks, lin_w, dmats)):
+            da = da.contiguous()
+            c = w.shape[1]
+            dwf, dw = torch.empty_like(wf), torch.empty_like(w)
+            _lib.check(lib.cffm_linear_fwd(_ptr(da), _ptr(w), _ptr(dwf), e, e, c, st), lib)                    # dA W_i^T
+            _lib.check(lib.cffm_linear_bwd_weight(_ptr(wf), _ptr(da), _ptr(dw), e, e, c, st), lib)             # Wf_i^T dA
+            dfw[:, (k - 1 - i) * e:(k - i) * e].copy_(dwf)
+            dws.append(dw)
+        return (dfw,) + tuple(dws)
+
+
 def segformer_fuse(feats, lin_w, lin_b, fuse_w):
     """The SegFormer embedding of the CFFM heads without the 1024-channel concat (cffm_head.py:102-119):
     conv1x1(cat([resize(linear_c4(c4)), resize(linear_c3(c3)), resize(linear_c2(c2)), linear_c1(c1)]), fuse_w).
@@ -279,15 +319,19 @@ def segformer_fuse(feats, lin_w, lin_b, fuse_w):
     feats: [c1, c2, c3, c4] NCHW (c1 = the 1/4-scale map the others are resized to); lin_w / lin_b: the four `MLP.proj`
     weights [256,C_i] / biases in the same order; fuse_w: `linear_fuse.conv.weight` [256, 4*256, 1, 1] whose input-channel
     blocks are ordered c4, c3, c2, c1 (the reference's cat order).  Returns the pre-BatchNorm map [N,256,H,W].
-    The composed matrices Wf_i W_i and the constant sum_i Wf_i b_i are plain torch ops (a few MFLOP, autograd gives the
-    gradients of the six original tensors); everything at token scale runs in libcffm_hip.so."""
+    The composed matrices Wf_i W_i come from the library's GEMMs too (_ComposeFn), the constant sum_i Wf_i b_i is one torch
+    matrix-vector product; autograd returns the gradients of the nine original tensors."""
     k = len(feats)
     e = fuse_w.shape[0]
     if e != 256 or fuse_w.shape[1] != k * e:
         raise _lib.CffmError('segformer_fuse: fuse weight %s does not fit %d embeddings of 256' % (tuple(fuse_w.shape), k))
-    wf = fuse_w.reshape(e, k, e)
-    mats = [wf[:, k - 1 - i] @ lin_w[i] for i in range(k)]
-    d = sum(wf[:, k - 1 - i] @ lin_b[i] for i in range(k))
+    for w in lin_w:
+        _require_device(w, 'segformer_fuse weight')
+        if w.shape[0] != e or w.shape[1] % 4:
+            raise _lib.CffmError('segformer_fuse: embedding weight %s (rows of 16-byte multiples expected)' % (tuple(w.shape),))
+    w2d = fuse_w.reshape(e, k * e)
+    mats = _ComposeFn.apply(w2d, *lin_w)
+    d = w2d @ torch.cat([lin_b[k - 1 - j] for j in range(k)])          # sum_i Wf_i b_i: one matrix-vector product
     return _SegFuseFn.apply(d, *feats, *mats)
 
 
