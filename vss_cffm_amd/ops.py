@@ -227,7 +227,8 @@ class _SegFuseFn(torch.autograd.Function):
             _lib.check(lib.cffm_segfuse_fwd(_ptr(y), _ptr(d.contiguous()), zp, hs, ws, k - 1, n, H, W, st), lib)
         ctx.save_for_backward(*toks, *mats)
         ctx.shapes = [tuple(c.shape) for c in feats]
-        return y.view(n, H, W, 256).permute(0, 3, 1, 2)       # channels-last memory: BatchNorm / ReLU / dropout run on it natively
+        # channels-last memory: torch's BatchNorm runs faster on it than on plain NCHW (head step 4.6 vs 5.8 ms)
+        return y.view(n, H, W, 256).permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, g):
@@ -357,6 +358,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         y = torch.empty(n, h, w, o, dtype=torch.float32, device=x.device)
         _lib.check(lib.cffm_linear_bias_fwd(_ptr(rows), _ptr(wm), _ptr(b), _ptr(y), n * h * w, o, c, _stream(x)), lib)
         ctx.save_for_backward(rows, wm)
+        ctx.x_plain = x.is_contiguous()            # hand the input gradient back in the input's own memory layout
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -372,7 +374,12 @@ class _Conv1x1Fn(torch.autograd.Function):
             dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dy.device)
             if m:
                 _lib.check(lib.cffm_linear_bwd_input(_ptr(dyr), _ptr(wm), _ptr(dx), m, o, c, st), lib)
-            dx = dx.permute(0, 3, 1, 2)
+            if ctx.x_plain and m:
+                dxp = torch.empty(n, c, h, w, dtype=torch.float32, device=dy.device)
+                _lib.check(lib.cffm_transpose(_ptr(dx), _ptr(dxp), n, h * w, c, c * h * w, c * h * w, st), lib)
+                dx = dxp
+            else:
+                dx = dx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dwm = torch.zeros(o, c, dtype=torch.float32, device=dy.device)
             if m:
