@@ -421,9 +421,14 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     REQUIRE(g && qkv16 && key_src && q_dst && bias && ao && lse, "attn_fwd: null");
     // one workgroup per (window, head), three per CU (19.5 us at B=2); CFFM_ATTN_FWD=persistent selects the persistent form
     // (bias tiles in registers, two-stage prefetch): 26 us -- its serialized staging costs more than the bias traffic saves
+    // CFFM_ATTN_FWD=split: the key slots in two halves through a half-size LDS buffer + online softmax (six workgroups per CU,
+    // the whole grid resident): 28-34 us -- also slower (see k_cfm_attn_fwd_s)
     static int variant = -1;
-    if (variant < 0) { const char* e = getenv("CFFM_ATTN_FWD"); variant = (e && e[0] == 'p') ? 1 : 0; }
-    if (variant == 0) {
+    if (variant < 0) { const char* e = getenv("CFFM_ATTN_FWD"); variant = (e && e[0] == 'p') ? 1 : (e && e[0] == 's') ? 2 : 0; }
+    if (variant == 2) {
+        CFFM_LAUNCH(k_cfm_attn_fwd_s, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWS_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
+                    key_src, q_dst, bias, ao, lse);
+    } else if (variant == 0) {
         CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
                     key_src, q_dst, bias, ao, lse);
     } else {

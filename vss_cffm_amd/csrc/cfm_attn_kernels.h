@@ -441,6 +441,131 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
     }
 }
 
+// ---- forward, split-key form ------------------------------------------------------------------------------------------
+// The same mathematics with the 304 key slots taken in two halves (160 + 144) through ONE half-size LDS buffer and a
+// running (online) softmax: 21 KB of LDS and ~1/3 fewer registers than k_cfm_attn_fwd (which keeps all 19 S^T tiles of a
+// query column in registers for a two-pass softmax), so FWS_OCC = 6 workgroups fit on a CU and the whole grid of a
+// 2-clip batch (1296 workgroups) is resident at once instead of running as 1024 + 272.  The second half's gathers are in
+// flight while the first half is multiplied.  CFFM_ATTN_FWD=split selects it.
+// MEASURED SLOWER (kept selectable, parity-tested): 34.3 us at FWS_OCC 6 (80 VGPRs, 120 B of scratch), 28.3 us at 5 (96 VGPRs,
+// 56 B of scratch) against 22.6 us for k_cfm_attn_fwd (event intervals, B = 2): the barrier / store / barrier between the
+// halves serialises every workgroup once more, the running softmax adds 20 cross-lane maxima, and the compiler still needs
+// ~105 registers for the software-pipelined loads -- more than the resident-grid effect (the 272-workgroup tail) gives back.
+#ifndef FWS_OCC
+#define FWS_OCC 6
+#endif
+#define FWS_ROWS 160                   // rows of the LDS buffer: keys 0..159, then keys 160..303 (144 rows)
+#define ATT_FWS_LDS (2 * FWS_ROWS * ATT_KS_STRIDE * sizeof(f16) + FWS_ROWS * 4)
+struct FwsRegs { int src[3]; f16x8 k[3], v[3]; };
+// this thread's 16-byte chunk (tid & 3) of rows (tid >> 2) + 64 it of the half starting at key `base` (nrows rows)
+__device__ __forceinline__ void fws_tab(FwsRegs& r, const int* __restrict__ ksrc, int base, int nrows, int tid) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int row = (tid >> 2) + 64 * it;
+        r.src[it] = row < nrows ? ksrc[base + row] : -1;
+    }
+}
+__device__ __forceinline__ void fws_rows(FwsRegs& r, buf_t rs_qkv, uint32_t soff_k, int tid) {
+    const uint32_t c16 = (uint32_t)(tid & 3) * 16;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const uint32_t o = r.src[it] >= 0 ? (uint32_t)r.src[it] * 1536u + c16 : BUF_OOB;
+        r.k[it] = buf_ld_h8(rs_qkv, o, soff_k);
+        r.v[it] = buf_ld_h8(rs_qkv, o, soff_k + 512);
+    }
+}
+__device__ __forceinline__ void fws_store(const FwsRegs& r, f16* Ks, f16* Vs, float* vflag, int nrows, int tid) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int row = (tid >> 2) + 64 * it, c = tid & 3;
+        if (row < nrows) {
+            if (c == 0) vflag[row] = r.src[it] >= 0 ? 0.f : -INFINITY;
+            *(f16x8*)(Ks + ATT_ROW(row, c)) = r.k[it];
+            *(f16x8*)(Vs + ATT_ROW(row, c)) = r.v[it];
+        }
+    }
+}
+// one half: NT 16-key tiles, taken in pairs (one PV k-step of 32 keys); bias tiles from `brow` (this lane's query row, first
+// key of the half), running maximum m, running sum l (this lane's share), output accumulators o
+template <int NT>
+__device__ __forceinline__ void fws_half(const f16* Ks, const f16* Vs, const float* vflag, const float* __restrict__ brow, f16x8 qfrag,
+                                         int lane, float& m, float& l, f32x4 (&o)[2]) {
+    const int g = lane >> 4, l15 = lane & 15;
+    f32x4 b0 = ld4(brow), b1 = NT > 1 ? ld4(brow + 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < (NT + 1) / 2; ++p) {
+        const bool two = 2 * p + 1 < NT;
+        f32x4 n0 = b0, n1 = b1;
+        if (2 * p + 2 < NT) n0 = ld4(brow + 16 * (2 * p + 2));          // the next pair's bias tiles are in flight meanwhile
+        if (2 * p + 3 < NT) n1 = ld4(brow + 16 * (2 * p + 3));
+        const f16x8 kf0 = *(const f16x8*)(Ks + ATT_ROW((32 * p + l15), g));
+        f32x4 s0 = mfma16x16x32_f16(kf0, qfrag, b0 + vflag4(vflag, 32 * p + 4 * g));   // C-in = bias + mask
+        f32x4 s1 = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (two) {
+            const f16x8 kf1 = *(const f16x8*)(Ks + ATT_ROW((32 * p + 16 + l15), g));
+            s1 = mfma16x16x32_f16(kf1, qfrag, b1 + vflag4(vflag, 32 * p + 16 + 4 * g));
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float mu = mn == -INFINITY ? 0.f : mn;                   // (every key so far masked: exponentials of -inf are 0)
+        const float alpha = fast_exp(m - mu);
+        f32x4 p0, p1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { p0[j] = fast_exp(s0[j] - mu); p1[j] = fast_exp(s1[j] - mu); }
+        l = l * alpha + ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+        m = mn;
+        const f16x8 pf = cat_f16x4(to_f16x4(p0), to_f16x4(p1));
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            o[mt] = mfma16x16x32_f16(att_tr_frag<FWS_ROWS>(Vs, 32 * p, 16 * mt, lane), pf, o[mt] * alpha);
+        b0 = n0; b1 = n1;
+    }
+}
+__global__ void __launch_bounds__(256, FWS_OCC) k_cfm_attn_fwd_s(Geo G, const h16* __restrict__ qkv,
+                                                           const int* __restrict__ key_src, const int* __restrict__ q_dst,
+                                                           const float* __restrict__ bias, float* __restrict__ ao,
+                                                           float* __restrict__ lse_out) {
+    CFFM_DYN_SMEM(smem);
+    f16* Ks = (f16*)smem;
+    f16* Vs = Ks + FWS_ROWS * ATT_KS_STRIDE;
+    float* vflag = (float*)(Vs + FWS_ROWS * ATT_KS_STRIDE);
+    const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qcol = 16 * wave + (lane & 15), g = lane >> 4;
+    const buf_t rs_qkv = qkv_rsrc(G, qkv);
+    const uint32_t soff_k = qkv_soff_k(G, b, h);
+    const int* ksrc = key_src + w * CFFM_NKEY_PAD;
+    const int qdst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;
+    FwsRegs ra, rb;
+    fws_tab(ra, ksrc, 0, FWS_ROWS, tid);
+    fws_tab(rb, ksrc, FWS_ROWS, CFFM_NKEY_PAD - FWS_ROWS, tid);
+    fws_rows(ra, rs_qkv, soff_k, tid);
+    const f16x8 qfrag = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)(w * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
+                                  (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
+    fws_store(ra, Ks, Vs, vflag, FWS_ROWS, tid);
+    fws_rows(rb, rs_qkv, soff_k, tid);                     // the second half's rows fly while the first half is multiplied
+    __syncthreads();
+    const float* brow = bias + ((long)h * CFFM_NQ_PAD + qcol) * CFFM_NKEY_PAD + 4 * g;
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    fws_half<FWS_ROWS / 16>(Ks, Vs, vflag, brow, qfrag, lane, m, l, o);
+    __syncthreads();
+    fws_store(rb, Ks, Vs, vflag, CFFM_NKEY_PAD - FWS_ROWS, tid);
+    __syncthreads();
+    fws_half<(CFFM_NKEY_PAD - FWS_ROWS) / 16>(Ks, Vs, vflag, brow + FWS_ROWS, qfrag, lane, m, l, o);
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (g == 0) lse_out[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol] = (qcol < CFFM_WA) ? m + logf(l) : 0.f;
+    if (qdst >= 0) {
+        const float inv = 1.f / l;
+        float* orow = ao + ((long)b * G.HW + qdst) * CFFM_C + h * CFFM_HD + 4 * g;
+        *(f32x4*)(orow) = o[0] * inv;
+        *(f32x4*)(orow + 16) = o[1] * inv;
+    }
+}
+
 // ---- forward, persistent form ------------------------------------------------------------------------------------------
 // grid (8 heads, NG window groups), FWP_OCC workgroups per CU.  The same mathematics as k_cfm_attn_fwd; what changes is where
 // the latencies go: the head's 19 bias tiles are loaded ONCE per workgroup and stay in registers (the one-shot kernel pulls
