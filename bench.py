@@ -216,9 +216,13 @@ def main():
                 lib.cffm_profile_enable(0)
                 lib.cffm_profile_collect(ms_buf, n_buf)
 
+            # the gradients the two graphs work on are the buffers THIS capture allocated -- not whatever `.grad` points to
+            # after a later eager step (the calibration below runs some)
+            static_grads = [p.grad for p in params_list]
+
             def replay_step():
                 ga.replay()
-                V.distributed.allreduce_gradients(params_list)
+                V.distributed.allreduce_gradients(params_list, grads=static_grads)
                 gb.replay()
             return replay_step
 
@@ -349,6 +353,18 @@ def main():
         lib.cffm_profile_enable(0)
         lib.cffm_profile_collect(ms_buf, n_buf)
         all_ms, all_n = list(ms_buf), list(n_buf)
+    ranks_in_sync = None
+    if multi and not args.ddp:
+        # data parallel correctness at run time: every rank started from rank 0's parameters and applied the same averaged
+        # gradients, so the parameters must still be bit-identical everywhere (the inputs differ per rank)
+        with torch.no_grad():
+            cs = torch.stack([p.detach().double().sum() for p in params_list] + [p.detach().double().abs().sum() for p in params_list])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_in_sync = bool(torch.equal(lo, hi))
+        if not ranks_in_sync and rank == 0:
+            sys.stderr.write('bench.py: the ranks\' parameters have diverged -- the gradient exchange is broken\n')
     if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -399,7 +415,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f32 accumulate; MFMA operands: split-bf16 (hi+lo, ~2^-17) in the Linear GEMMs, f16 in QK^T/AV',
             'data': 'synthetic',
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
-                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else 'forward+backward graph | RCCL all-reduce | AdamW graph'),
+                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'ranks_in_sync': ranks_in_sync, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else 'forward+backward graph | RCCL all-reduce | AdamW graph'),
                        'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one all-reduce of the flat gradient buffer per step') if multi else 'none'},
             'roofline': roof, 'kernels': stages,
             'kernels_note': 'per-stage HIP-event times from a separate instrumented pass of %d steps after the timed region '

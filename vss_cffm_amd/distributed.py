@@ -20,13 +20,15 @@ def broadcast_parameters(module, src=0):
             dist.broadcast(t.data, src)
 
 
-def allreduce_gradients(params, average=True):
+def allreduce_gradients(params, average=True, grads=None):
     """Average (or sum) the gradients of `params` over the ranks, in place: one collective per distinct underlying
-    gradient buffer (a layer's gradients share one), plus one per gradient that owns its storage."""
+    gradient buffer (a layer's gradients share one), plus one per gradient that owns its storage.
+    `grads`: reduce these tensors instead of the parameters' current `.grad` -- for a step replayed from a HIP graph the
+    gradients live in the buffers the CAPTURE allocated, whatever `.grad` points to by now."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
+    grads = [g for g in grads if g is not None] if grads is not None else [p.grad for p in params if p.grad is not None]
     if not grads:
         return 0
     bases = None
