@@ -173,6 +173,14 @@ int cffm_upce_fwd(const float* logits, const long long* labels, float* lse, floa
 int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse, const float* gscale, float scale,
                   float* dlogits, int M, int K, int h, int w, int H, int W, int ignore_index, void* stream);
 
+/* ---- evaluation counts ----
+ * mmseg/core/evaluation/metrics.py:62-119 `intersect_and_union` for one prediction / label map pair of n pixels (both int64 on
+ * the device): counts [3][num_classes] int64 = per-class pixels of (prediction == label) | prediction | label, over the pixels
+ * whose label is not ignore_index, ACCUMULATED into what is there (zero it first; `total_intersect_and_union` = call per image);
+ * union = prediction + label - intersect.  Exact integers; num_classes <= 1024; at most 2^32 pixels per call. */
+int cffm_seg_counts(const long long* pred, const long long* label, long n, int num_classes, int ignore_index,
+                    int reduce_zero_label, long long* counts, void* stream);
+
 /* ---- block / layer level ---- */
 /* x_ref: NHWC frames 0..2 [B,3,HW,256] (batch stride ref_bs), x_tgt NHWC target [B,HW,256] (stride tgt_bs);
  * writes the block's saved activations into `ws` (layout: cffm_block_ws_layout; ws[x2] is the output). */

@@ -7,5 +7,6 @@ from . import head  # noqa: F401,E402  (registers the three CFFM heads and Cross
 from .config import Config  # noqa: F401,E402
 from . import optim  # noqa: F401,E402
 from . import distributed  # noqa: F401,E402
+from . import evaluation  # noqa: F401,E402
 from .registry import (BACKBONES, HEADS, LOSSES, NECKS, SEGMENTORS, Registry, build_backbone,  # noqa: F401,E402
                        build_from_cfg, build_head, build_loss, build_neck, build_segmentor)

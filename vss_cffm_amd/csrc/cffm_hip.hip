@@ -1021,6 +1021,20 @@ int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- evaluation counts
+int cffm_seg_counts(const long long* pred, const long long* label, long n, int num_classes, int ignore_index, int reduce_zero_label,
+                    long long* counts, void* stream) {
+    REQUIRE(n >= 0 && n < (1L << 32) && num_classes >= 1 && num_classes <= SEGCNT_MAXK, "seg_counts: bad sizes");
+    if (!n) return 0;
+    REQUIRE(pred && label && counts, "seg_counts: null");
+    const long want = (n + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    CFFM_LAUNCH(k_seg_counts, (blocks), (256), 0, (hipStream_t)stream, pred, label, n, num_classes, ignore_index, reduce_zero_label,
+                (unsigned long long*)counts);
+    CHECK_LAUNCH("seg_counts");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- layer
 int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* params, const float* x_nchw,
                        float* y_tgt_nchw, const int* key_src, const int* q_dst, float* saved, float* scratch,

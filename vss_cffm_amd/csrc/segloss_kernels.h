@@ -253,3 +253,36 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
             if (k < G.K) dlogits[(((long)m * G.K + k) * G.h + qy) * G.w + qx] = sc * acc[i][j];
         }
 }
+
+
+// ---- evaluation: per-class pixel counts of a prediction map against a label map ------------------------------
+// Reference: mmseg/core/evaluation/metrics.py:62-119 `intersect_and_union` (numpy on the host): optional reduce_zero_label
+// (0 -> 255, the rest minus 1), drop label == ignore_index, then three np.histogram(bins=arange(K+1)) over the matching
+// predictions, the predictions and the labels -- a value v counts iff 0 <= v <= K, into bin min(v, K-1) (numpy's last bin is
+// closed).  Integer work: per-workgroup LDS histograms, one 64-bit atomic per (workgroup, non-empty bin); results are exact
+// and therefore independent of the order.  counts[3][K] (intersect | prediction | label) are ACCUMULATED (total_intersect_and_union).
+#define SEGCNT_MAXK 1024
+__global__ void __launch_bounds__(256) k_seg_counts(const long long* __restrict__ pred, const long long* __restrict__ label, long n, int K,
+                                                     int ignore, int reduce_zero, unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int hist[3 * SEGCNT_MAXK];
+    for (int e = threadIdx.x; e < 3 * K; e += 256) hist[e] = 0u;
+    __syncthreads();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        long long l = label[i];
+        const long long p = pred[i];
+        if (reduce_zero) {                       // metrics.py:98-102 (on uint8 label maps: 0 -> 255, others - 1, 254 -> 255)
+            if (l == 0) l = 255;
+            l -= 1;
+            if (l == 254) l = 255;
+        }
+        if (l == ignore) continue;
+        const bool pv = p >= 0 && p <= K, lv = l >= 0 && l <= K;
+        const int pb = (int)(p < K ? p : K - 1), lb = (int)(l < K ? l : K - 1);
+        if (pv) atomicAdd(&hist[K + pb], 1u);
+        if (lv) atomicAdd(&hist[2 * K + lb], 1u);
+        if (p == l && pv) atomicAdd(&hist[pb], 1u);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * K; e += 256)
+        if (hist[e]) atomicAdd(&counts[e], (unsigned long long)hist[e]);
+}

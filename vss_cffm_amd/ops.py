@@ -53,6 +53,14 @@ def _require_device(t, what):
         raise _lib.CffmError('%s: fp32 expected, got %s' % (what, t.dtype))
 
 
+def _require_int64(t, what):
+    if _lib._override is None and not t.is_cuda:
+        raise _lib.CffmError('%s: runs only on the GPU (got a %s tensor); there is no CPU fallback' % (what, t.device))
+    if t.dtype != torch.int64:
+        raise _lib.CffmError('%s: int64 expected, got %s' % (what, t.dtype))
+    return t.contiguous()
+
+
 _geom_cache = {}
 
 
