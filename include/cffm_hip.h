@@ -181,6 +181,11 @@ int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse
 int cffm_seg_counts(const long long* pred, const long long* label, long n, int num_classes, int ignore_index,
                     int reduce_zero_label, long long* counts, void* stream);
 
+/* video consistency VC_n, VC_perclip.py:62-78 `get_common`: gt / pred [F, npix] int64 label maps of one video; for every start
+ * frame i < F - n: counts[i][0] += pixels whose label is constant over frames i..i+n-1 in BOTH gt and pred, counts[i][1] += pixels
+ * constant in gt (acc_i = counts[i][0] / counts[i][1]); counts int64 [F - n][2], zero it first. */
+int cffm_vc_counts(const long long* gt, const long long* pred, int F, long npix, int n, long long* counts, void* stream);
+
 /* ---- block / layer level ---- */
 /* x_ref: NHWC frames 0..2 [B,3,HW,256] (batch stride ref_bs), x_tgt NHWC target [B,HW,256] (stride tgt_bs);
  * writes the block's saved activations into `ws` (layout: cffm_block_ws_layout; ws[x2] is the output). */

@@ -97,9 +97,52 @@ def test_numpy_restatement_against_reference_live():
                 assert np.array_equal(a, b)
 
 
+def np_get_common(list_, predlist, clip_num, h, w):
+    """VC_perclip.py:62-78, verbatim semantics (numpy)"""
+    accs = []
+    for i in range(len(list_) - clip_num):
+        global_common = np.ones((h, w))
+        predglobal_common = np.ones((h, w))
+        for j in range(1, clip_num):
+            global_common = np.logical_and(global_common, list_[i] == list_[i + j])
+            predglobal_common = np.logical_and(predglobal_common, predlist[i] == predlist[i + j])
+        pred = predglobal_common * global_common
+        with np.errstate(invalid='ignore', divide='ignore'):
+            accs.append(pred.sum() / global_common.sum())
+    return accs
+
+
+def run_vc(device, f=20, h=24, w=31):
+    rs = np.random.RandomState(9)
+    base = rs.randint(0, 6, size=(h, w))
+    gt = np.stack([np.where(rs.rand(h, w) < 0.04 * t, rs.randint(0, 6, size=(h, w)), base) for t in range(f)]).astype(np.int64)
+    pred = np.where(rs.rand(f, h, w) < 0.1, rs.randint(0, 6, size=(f, h, w)), gt).astype(np.int64)
+    for n in (1, 2, 8, 16, f, f + 3):
+        want = np_get_common(list(gt), list(pred), n, h, w)
+        acc, counts = E.video_consistency(torch.from_numpy(gt).to(device), torch.from_numpy(pred).to(device), n)
+        assert acc.shape == (len(want),) and counts.shape == (len(want), 2)
+        np.testing.assert_array_equal(acc.cpu().numpy(), np.array(want, dtype=np.float64))       # same integer ratio in float64
+    acc, counts = E.video_consistency(torch.zeros(5, 4, 4, dtype=torch.int64, device=device),
+                                      torch.ones(5, 4, 4, dtype=torch.int64, device=device), 2)
+    assert counts.cpu().tolist() == [[16, 16]] * 3
+    with pytest.raises(_lib.CffmError):
+        E.video_consistency(torch.zeros(5, 4, 4, dtype=torch.int64, device=device), torch.zeros(5, 4, 5, dtype=torch.int64, device=device), 2)
+
+
 def test_counts_emulated():
     with emu.active():
         run_cases(torch.device('cpu'))
+
+
+def test_video_consistency_emulated():
+    with emu.active():
+        run_vc(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_video_consistency_gpu():
+    run_vc(torch.device('cuda:0'))
+    run_vc(torch.device('cuda:0'), f=40, h=120, w=160)
 
 
 @pytest.mark.gpu

@@ -1035,6 +1035,17 @@ int cffm_seg_counts(const long long* pred, const long long* label, long n, int n
     return 0;
 }
 
+int cffm_vc_counts(const long long* gt, const long long* pred, int F, long npix, int n, long long* counts, void* stream) {
+    REQUIRE(F >= 0 && npix >= 0 && n >= 1 && npix < (1L << 31), "vc_counts: bad sizes");
+    if (F - n <= 0 || !npix) return 0;
+    REQUIRE(gt && pred && counts, "vc_counts: null");
+    REQUIRE(F - n <= 65535, "vc_counts: more than 65535 start frames in one call");
+    CFFM_LAUNCH(k_vc_counts, ((unsigned)((npix + 255) / 256), (unsigned)(F - n)), (256), 0, (hipStream_t)stream, gt, pred, npix, n,
+                (unsigned long long*)counts);
+    CHECK_LAUNCH("vc_counts");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- layer
 int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* params, const float* x_nchw,
                        float* y_tgt_nchw, const int* key_src, const int* q_dst, float* saved, float* scratch,

@@ -286,3 +286,35 @@ __global__ void __launch_bounds__(256) k_seg_counts(const long long* __restrict_
     for (int e = threadIdx.x; e < 3 * K; e += 256)
         if (hist[e]) atomicAdd(&counts[e], (unsigned long long)hist[e]);
 }
+
+
+// ---- evaluation: video consistency VC_n -----------------------------------------------------------------------
+// Reference: VC_perclip.py:62-78 `get_common`: for every start frame i < F - n, a pixel is "stable" when its label is the same in
+// frames i .. i+n-1; acc_i = |stable in the ground truth AND in the prediction| / |stable in the ground truth|.
+// counts[i][0] = the numerator, counts[i][1] = the denominator (exact integers, accumulated with one atomic per workgroup).
+// grid (ceil(h*w / 256), F - n)
+__global__ void __launch_bounds__(256) k_vc_counts(const long long* __restrict__ gt, const long long* __restrict__ pred, long npix, int n,
+                                                    unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int s_cnt[2][4];
+    const int i = blockIdx.y;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    float both = 0.f, stable = 0.f;
+    if (p < npix) {
+        const long long g0 = gt[(long)i * npix + p], p0 = pred[(long)i * npix + p];
+        bool gs = true, ps = true;
+        for (int j = 1; j < n; ++j) {
+            gs = gs && gt[(long)(i + j) * npix + p] == g0;
+            ps = ps && pred[(long)(i + j) * npix + p] == p0;
+        }
+        stable = gs ? 1.f : 0.f;
+        both = (gs && ps) ? 1.f : 0.f;
+    }
+    both = wave_sum(both);            // <= 64: exact in fp32
+    stable = wave_sum(stable);
+    if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = (unsigned int)both; s_cnt[1][threadIdx.x >> 6] = (unsigned int)stable; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned int v = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+        if (v) atomicAdd(&counts[2 * i + threadIdx.x], (unsigned long long)v);
+    }
+}

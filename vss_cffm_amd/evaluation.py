@@ -53,3 +53,18 @@ def eval_metrics(results, gt_seg_maps, num_classes, ignore_index, metrics=('mIoU
     if nan_to_num is not None:
         ret = [torch.nan_to_num(r, nan=float(nan_to_num)) for r in ret]
     return ret
+
+
+def video_consistency(gt_frames, pred_frames, clip_num):
+    """VC_perclip.py:62-78 `get_common` for one video: gt / pred [F,h,w] int64 label maps -> float64 [F - clip_num] accuracies
+    (|pixels stable over clip_num frames in gt AND pred| / |stable in gt|; 0/0 = nan as in numpy) and the int64 [F - clip_num, 2]
+    counts behind them.  The mean over all videos' accuracies is the reported VC_8 / VC_16."""
+    lib = _lib.get()
+    gt_frames, pred_frames = _require_int64(gt_frames, 'ground-truth frames'), _require_int64(pred_frames, 'predicted frames')
+    if gt_frames.dim() != 3 or gt_frames.shape != pred_frames.shape:
+        raise _lib.CffmError('video_consistency: [F,h,w] maps expected, got %s / %s' % (tuple(gt_frames.shape), tuple(pred_frames.shape)))
+    f, h, w = gt_frames.shape
+    m = max(f - int(clip_num), 0)
+    counts = torch.zeros(m, 2, dtype=torch.int64, device=gt_frames.device)
+    _lib.check(lib.cffm_vc_counts(_ptr(gt_frames), _ptr(pred_frames), f, h * w, int(clip_num), _ptr(counts), _stream(gt_frames)), lib)
+    return counts[:, 0].double() / counts[:, 1].double(), counts
