@@ -984,8 +984,7 @@ int cffm_upce_fwd(const float* logits, const long long* labels, float* lse, floa
     const size_t lds = (size_t)G.rn * G.cn * (UPCE_KP(K) + 1) * sizeof(float);
     TRY(upce_lds((const void*)k_upce_fwd, lds, "upce_fwd"));
     hipStream_t st = (hipStream_t)stream;
-    CFFM_LAUNCH(k_upce_fwd, ((unsigned)((W + UPCE_TILE - 1) / UPCE_TILE), (unsigned)((H + UPCE_TILE - 1) / UPCE_TILE), (unsigned)M),
-                (256), lds, st, logits, labels, lse, part, G);
+    CFFM_LAUNCH(k_upce_fwd, ((unsigned)cffm_upce_blocks(M, H, W)), (256), lds, st, logits, labels, lse, part, G);
     CHECK_LAUNCH("upce_fwd");
     return 0;
 }
@@ -1015,7 +1014,7 @@ int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse
     const size_t lds = ((size_t)G.rn * G.cn * UPCE_KP(K) + 2 * (size_t)G.foot + 2 * 16 * G.win * 4) * sizeof(float);
     TRY(upce_lds((const void*)k_upce_bwd, lds, "upce_bwd"));
     hipStream_t st = (hipStream_t)stream;
-    CFFM_LAUNCH(k_upce_bwd, ((unsigned)((w + UPCE_QT - 1) / UPCE_QT), (unsigned)((h + UPCE_QT - 1) / UPCE_QT), (unsigned)M), (256), lds,
+    CFFM_LAUNCH(k_upce_bwd, ((unsigned)((long)M * ((w + UPCE_QT - 1) / UPCE_QT) * ((h + UPCE_QT - 1) / UPCE_QT))), (256), lds,
                 st, logits, labels, lse, gscale, scale, dlogits, G);
     CHECK_LAUNCH("upce_bwd");
     return 0;

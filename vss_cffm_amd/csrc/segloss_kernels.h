@@ -62,14 +62,18 @@ __device__ __forceinline__ f32x4 upce_interp4(const float* s_l, int a, int b, in
     return (ta * hx0 + tb * lx) * hy0 + (tc * hx0 + td * lx) * ly;      // ATen's order of operations
 }
 
-// grid (ceil(W/16), ceil(H/16), M), 256 threads = 16 x 16 output pixels; dynamic LDS rn*cn*(KP+1) floats.
+// grid M * ceil(H/16) * ceil(W/16), 256 threads = 16 x 16 output pixels; dynamic LDS rn*cn*(KP+1) floats.
 // lse[m][y][x]; part[block][0] = sum of per-pixel losses, part[block][1] = number of pixels whose argmax is the label.
 __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                    float* __restrict__ lse, float* __restrict__ part, UpceGeom G) {
     CFFM_DYN_SMEM(smem);
     float* s_l = (float*)smem;
     __shared__ float s_red[2][4];
-    const int m = blockIdx.z, ty = blockIdx.y * UPCE_TILE, tx = blockIdx.x * UPCE_TILE;
+    // 1-D grid, re-numbered so that every XCD (workgroup b runs on XCD b % 8) owns a contiguous run of tiles: the tiles that
+    // share lines of the low-resolution logits (24-byte segments of 128-byte lines) then fill ONE L2, not eight
+    const int gx = (G.W + UPCE_TILE - 1) / UPCE_TILE, gy = (G.H + UPCE_TILE - 1) / UPCE_TILE;
+    const int lin = xcd_linear_id(), m = lin / (gx * gy), trem = lin - m * gx * gy;
+    const int ty = (trem / gx) * UPCE_TILE, tx = (trem - (trem / gx) * gx) * UPCE_TILE;
     int r0, c0, t1;
     float tl;
     segf_taps(ty, G.h, G.H, r0, t1, tl);
@@ -130,13 +134,13 @@ __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logi
     if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = loss; s_red[1][threadIdx.x >> 6] = hit; }
     __syncthreads();
     if (threadIdx.x < 2) {
-        const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const long blk = lin;
         part[blk * 2 + threadIdx.x] = (s_red[threadIdx.x][0] + s_red[threadIdx.x][1]) + (s_red[threadIdx.x][2] + s_red[threadIdx.x][3]);
     }
 }
 
 // dlogits[m][k][qy][qx] = scale * (*gscale) * sum over output pixels p tapping q (labels counted) of w(p,q) * (softmax_k(p) - [k == label_p])
-// grid (ceil(w/4), ceil(h/4), M); 256 threads = 16 low-resolution pixels x 16 class lanes, a lane owning the f32x4 class groups
+// grid M * ceil(h/4) * ceil(w/4); 256 threads = 16 low-resolution pixels x 16 class lanes, a lane owning the f32x4 class groups
 // cl, cl + 16, cl + 32, cl + 48 (K <= 256); dynamic LDS: rn*cn*KP floats (the tile's pixels and one ring around them: every tap of
 // every output pixel that taps a tile pixel) + the footprint's lse / labels + the tap tables (16 pixels x 2 x win x 16 B); foot / win are
 // sized by the host for the actual resize factor (a worst-case size left three workgroups per CU).
@@ -146,7 +150,9 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
     CFFM_DYN_SMEM(smem);
     float* s_l = (float*)smem;
     const int KP = UPCE_KP(G.K);
-    const int m = blockIdx.z, q0y = blockIdx.y * UPCE_QT, q0x = blockIdx.x * UPCE_QT;
+    const int gx = (G.w + UPCE_QT - 1) / UPCE_QT, gy = (G.h + UPCE_QT - 1) / UPCE_QT;      // XCD-contiguous tile order, as in the forward
+    const int lin = xcd_linear_id(), m = lin / (gx * gy), trem = lin - m * gx * gy;
+    const int q0y = (trem / gx) * UPCE_QT, q0x = (trem - (trem / gx) * gx) * UPCE_QT;
     const int r0 = q0y > 0 ? q0y - 1 : 0, c0 = q0x > 0 ? q0x - 1 : 0;
     upce_stage(s_l, logits, G, m, r0, c0);
     // the tile's footprint in the output: log-sum-exp and label of every pixel that can tap a tile pixel, staged once
