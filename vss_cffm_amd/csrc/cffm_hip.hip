@@ -894,6 +894,7 @@ int cffm_segfuse_fwd(float* y, const float* d, const float* const z[3], const in
     for (int m = 0; m < nmaps; ++m) { REQUIRE(z[m], "segfuse_fwd: null map"); mp.z[m] = z[m]; }
     const long rows = (long)N * H * W;
     if (!rows) return 0;
+    REQUIRE(rows < (1L << 31), "segfuse_fwd: too many output pixels");
     hipStream_t st = (hipStream_t)stream;
     const long patches = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
     CFFM_LAUNCH(k_segfuse_fwd, ((unsigned)((patches + 3) / 4)), (256), 0, st, y, d, mp, N, H, W);
@@ -984,6 +985,7 @@ int cffm_upce_fwd(const float* logits, const long long* labels, float* lse, floa
     const size_t lds = (size_t)G.rn * G.cn * (UPCE_KP(K) + 1) * sizeof(float);
     TRY(upce_lds((const void*)k_upce_fwd, lds, "upce_fwd"));
     hipStream_t st = (hipStream_t)stream;
+    REQUIRE(cffm_upce_blocks(M, H, W) < (1L << 31), "upce_fwd: too many tiles");
     CFFM_LAUNCH(k_upce_fwd, ((unsigned)cffm_upce_blocks(M, H, W)), (256), lds, st, logits, labels, lse, part, G);
     CHECK_LAUNCH("upce_fwd");
     return 0;
@@ -1014,6 +1016,7 @@ int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse
     const size_t lds = ((size_t)G.rn * G.cn * UPCE_KP(K) + 2 * (size_t)G.foot + 2 * 16 * G.win * 4) * sizeof(float);
     TRY(upce_lds((const void*)k_upce_bwd, lds, "upce_bwd"));
     hipStream_t st = (hipStream_t)stream;
+    REQUIRE((long)M * ((w + UPCE_QT - 1) / UPCE_QT) * ((h + UPCE_QT - 1) / UPCE_QT) < (1L << 31), "upce_bwd: too many tiles");
     CFFM_LAUNCH(k_upce_bwd, ((unsigned)((long)M * ((w + UPCE_QT - 1) / UPCE_QT) * ((h + UPCE_QT - 1) / UPCE_QT))), (256), lds,
                 st, logits, labels, lse, gscale, scale, dlogits, G);
     CHECK_LAUNCH("upce_bwd");
