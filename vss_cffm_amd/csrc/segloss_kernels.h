@@ -63,15 +63,59 @@ __device__ __forceinline__ void upce_cell_max(float* s_l, const UpceGeom& G) {
         s_l[cells * KP + e] = mx;
     }
 }
-__device__ __forceinline__ f32x4 upce_interp4(const float* s_l, int a, int b, int c, int d, int k4, float hx0, float lx, float hy0, float ly) {
+// Packed fp32 math on class PAIRS, spelled as instructions: left to itself the compiler pairs the two taps of ONE class (its SLP
+// vectoriser follows the expression tree), which costs register shuffles and a cross add per class -- ~14 VALU instructions per
+// (pixel, class), and these kernels are VALU-bound (SQ_ACTIVE_INST_VALU x resident waves ~ 100 %, profiles/r01_pmc_sq_rows.txt).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+#ifdef CFFM_EMU
+    return a * b;
+#else
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#endif
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+#ifdef CFFM_EMU
+    return a * b + c;
+#else
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+#ifdef CFFM_EMU
+    return a + b;
+#else
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#endif
+}
+#define UPCE_LO(v) __builtin_shufflevector(v, v, 0, 1)
+#define UPCE_HI(v) __builtin_shufflevector(v, v, 2, 3)
+// the four bilinear weights of a pixel, each duplicated into a register pair
+struct UpceW { f32x2 w00, w01, w10, w11; };
+__device__ __forceinline__ UpceW upce_weights(float hx0, float lx, float hy0, float ly) {
+    UpceW w;
+    const float a = hy0 * hx0, b = hy0 * lx, c = ly * hx0, d = ly * lx;
+    w.w00 = (f32x2){a, a}; w.w01 = (f32x2){b, b}; w.w10 = (f32x2){c, c}; w.w11 = (f32x2){d, d};
+    return w;
+}
+// four classes of one interpolated pixel, v = w00 ta + w01 tb + w10 tc + w11 td (one rounding away from ATen's nested form,
+// ~1e-7 relative), plus `off` (minus the bound / the log-sum-exp): two class pairs x (1 mul + 4 fma)
+__device__ __forceinline__ void upce_interp4(const float* s_l, int a, int b, int c, int d, int k4, const UpceW& w, f32x2 off, f32x2& lo, f32x2& hi) {
+    const f32x4 ta = ((const f32x4*)(s_l + a))[k4];
 #if UPCE_ABLATE & 2          // timing experiments only: one LDS read instead of four
-    const f32x4 ta = ((const f32x4*)(s_l + a))[k4], tb = ta * 1.5f, tc = ta * 0.5f, td = ta * 0.25f;
+    const f32x4 tb = ta, tc = ta, td = ta;
     (void)b; (void)c; (void)d;
 #else
-    const f32x4 ta = ((const f32x4*)(s_l + a))[k4], tb = ((const f32x4*)(s_l + b))[k4];
-    const f32x4 tc = ((const f32x4*)(s_l + c))[k4], td = ((const f32x4*)(s_l + d))[k4];
+    const f32x4 tb = ((const f32x4*)(s_l + b))[k4], tc = ((const f32x4*)(s_l + c))[k4], td = ((const f32x4*)(s_l + d))[k4];
 #endif
-    return (ta * hx0 + tb * lx) * hy0 + (tc * hx0 + td * lx) * ly;      // ATen's order of operations
+    lo = pk_fma(UPCE_LO(td), w.w11, pk_fma(UPCE_LO(tc), w.w10, pk_fma(UPCE_LO(tb), w.w01, pk_fma(UPCE_LO(ta), w.w00, off))));
+    hi = pk_fma(UPCE_HI(td), w.w11, pk_fma(UPCE_HI(tc), w.w10, pk_fma(UPCE_HI(tb), w.w01, pk_fma(UPCE_HI(ta), w.w00, off))));
 }
 
 // grid M * ceil(H/16) * ceil(W/16), 256 threads = 16 x 16 output pixels; dynamic LDS rn*cn*(KP+1) floats.
@@ -115,8 +159,12 @@ __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logi
         f32x4 sum4 = (f32x4){0.f, 0.f, 0.f, 0.f};
         float best = -3.0e38f;
         int arg = -1;
+        const UpceW wts = upce_weights(hx0, lx, hy0, ly);
+        const f32x2 zero2 = (f32x2){0.f, 0.f};
         for (int k4 = 0; k4 < KP / 4; ++k4) {
-            const f32x4 v = upce_interp4(s_l, a, b, c, d, k4, hx0, lx, hy0, ly);
+            f32x2 vlo, vhi;
+            upce_interp4(s_l, a, b, c, d, k4, wts, zero2, vlo, vhi);
+            const float v[4] = {vlo[0], vlo[1], vhi[0], vhi[1]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 sum4[j] += fast_exp(v[j] - bound);
@@ -127,14 +175,15 @@ __global__ void __launch_bounds__(256) k_upce_fwd(const float* __restrict__ logi
         if (!(sum > 1e-30f)) {      // taps disagreeing by more than ~70 in some class: the bound is too far above; use the maximum
             mx = best; sum = 0.f;
             for (int k4 = 0; k4 < KP / 4; ++k4) {
-                const f32x4 v = upce_interp4(s_l, a, b, c, d, k4, hx0, lx, hy0, ly);
-                for (int j = 0; j < 4; ++j) sum += fast_exp(v[j] - mx);
+                f32x2 vlo, vhi;
+                upce_interp4(s_l, a, b, c, d, k4, wts, zero2, vlo, vhi);
+                sum += (fast_exp(vlo[0] - mx) + fast_exp(vlo[1] - mx)) + (fast_exp(vhi[0] - mx) + fast_exp(vhi[1] - mx));
             }
         }
         float at_label = 0.f;
         if (counted) {
             const int kl = (int)lab;
-            at_label = hy0 * (hx0 * s_l[a + kl] + lx * s_l[b + kl]) + ly * (hx0 * s_l[c + kl] + lx * s_l[d + kl]);
+            at_label = fmaf(s_l[d + kl], wts.w11[0], fmaf(s_l[c + kl], wts.w10[0], fmaf(s_l[b + kl], wts.w01[0], s_l[a + kl] * wts.w00[0])));   // as upce_interp4
         }
         const float l = mx + logf(sum);
         lse[((long)m * G.H + oy) * G.W + ox] = l;
@@ -230,9 +279,9 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
     while (jx0 < jx1 && s_tx[q * G.win + jx0][3] == 0) ++jx0;
     while (jx1 > jx0 && s_tx[q * G.win + jx1 - 1][3] == 0) --jx1;
     const int ng = KP / 4;                      // 16-byte class groups; this lane owns groups cl, cl + 16, cl + 32, cl + 48
-    f32x4 acc[4];
+    f32x2 acc_lo[4], acc_hi[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) { acc_lo[i] = (f32x2){0.f, 0.f}; acc_hi[i] = (f32x2){0.f, 0.f}; }
     for (int jy = jy0; jy < jy1; ++jy) {
         const i32x4 ty = s_ty[q * G.win + jy];
         const float wy = __builtin_bit_cast(float, (int)ty[3]);
@@ -249,15 +298,19 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
             const float l = s_lse[fe];
             const float lx = __builtin_bit_cast(float, (int)tx[2]), hx0 = 1.f - lx;
             const int xa = tx[1], xb = xa + ((tx[0] & 1) ? KP : 0);
+            const UpceW wts = upce_weights(hx0, lx, hy0, ly);
+            const f32x2 ml = (f32x2){-l, -l}, wq2 = (f32x2){wq, wq};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k4 = cl + 16 * i;
                 if (k4 < ng) {
-                    const f32x4 v = upce_interp4(s_l, ra + xa, ra + xb, rb + xa, rb + xb, k4, hx0, lx, hy0, ly);
-                    f32x4 p;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) p[j] = UPCE_EXP(v[j] - l) - (4 * k4 + j == lab ? 1.f : 0.f);
-                    acc[i] += p * wq;
+                    f32x2 vlo, vhi;                                       // interpolated logit - lse (log2 units)
+                    upce_interp4(s_l, ra + xa, ra + xb, rb + xa, rb + xb, k4, wts, ml, vlo, vhi);
+                    const int e = lab - 4 * k4;                          // the label's position in this group, if it is in it
+                    const f32x2 plo = (f32x2){UPCE_EXP(vlo[0]) - (e == 0 ? 1.f : 0.f), UPCE_EXP(vlo[1]) - (e == 1 ? 1.f : 0.f)};
+                    const f32x2 phi = (f32x2){UPCE_EXP(vhi[0]) - (e == 2 ? 1.f : 0.f), UPCE_EXP(vhi[1]) - (e == 3 ? 1.f : 0.f)};
+                    acc_lo[i] = pk_fma(plo, wq2, acc_lo[i]);
+                    acc_hi[i] = pk_fma(phi, wq2, acc_hi[i]);
                 }
             }
         }
@@ -268,7 +321,7 @@ __global__ void __launch_bounds__(256) k_upce_bwd(const float* __restrict__ logi
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * (cl + 16 * i) + j;
-            if (k < G.K) dlogits[(((long)m * G.K + k) * G.h + qy) * G.w + qx] = sc * acc[i][j];
+            if (k < G.K) dlogits[(((long)m * G.K + k) * G.h + qy) * G.w + qx] = sc * (j < 2 ? acc_lo[i][j & 1] : acc_hi[i][j & 1]);
         }
 }
 
