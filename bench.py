@@ -92,8 +92,11 @@ def roofline_kernels(stages, b, nw, hw):
         'gemm_fc2_dx_gelu': ('mfma', 2.0 * np_ * 1024 * 256), 'gemm_fc1_dx': ('mfma', 2.0 * np_ * 256 * 1024),
         'gemm_proj_dx': ('mfma', 2.0 * np_ * 256 * 256), 'gemm_qkv_dx': ('mfma', 2.0 * nr * 768 * 256),
         'gemm_dw_group': ('mfma', 2.0 * (nr * 768 * 256 + np_ * (2 * 1024 * 256 + 256 * 256))),
+        # round 3: proj + residual + norm2 + fc1 + GELU + fc2 + residual in one row-panel launch, and the input-gradient chain back
+        'mlp_fwd_fused': ('mfma', 2.0 * np_ * (256 * 256 + 2 * 256 * 1024)), 'mlp_bwd_fused': ('mfma', 2.0 * np_ * (256 * 256 + 2 * 256 * 1024)),
         # attention backward: dS/dP recompute + dQ (query owners: 3 products), dK + dV + the S / dP recompute (key owners: 4)
-        'attn_bwd_q': ('mfma16', 3 * 2.0 * b * nw * 8 * 49 * 289 * 32), 'attn_bwd_kv': ('mfma16', 4 * 2.0 * b * nw * 8 * 49 * 289 * 32),
+        # attention backward, fused (round 2): S and dP recomputed once, dQ, dK, dV = 5 products of 49 x 289 x 32 per (window, head)
+        'attn_bwd_fused': ('mfma16', 5 * 2.0 * b * nw * 8 * 49 * 289 * 32),
         'attn_dkv_gather': ('hbm', 4.0 * (2 * nr * 512)),
         'ln_pool_fwd': ('hbm', 4.0 * (b * 4 * hw * 256 + nr * 256)), 'ln_pool_bwd': ('hbm', 4.0 * (2 * b * 4 * hw * 256 + nr * 256)),
         'residual_ln': ('hbm', 4.0 * 4 * np_ * 256), 'ln_bwd': ('hbm', 4.0 * 4 * np_ * 256),

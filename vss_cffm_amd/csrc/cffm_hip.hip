@@ -48,12 +48,12 @@ enum { ST_TRANSPOSE, ST_POOLMAT, ST_LN_POOL_FWD, ST_LN_POOL_BWD, ST_BIAS_ASM, ST
        ST_GEMM, ST_COLSUM, ST_RES_LN, ST_LN_BWD, ST_GELU, ST_GELU_BWD, ST_RES_OUT, ST_GTC_FWD, ST_GTC_BWD, ST_LN, ST_ADAMW, ST_NULL_PAIR,
        // per-kernel-family stages of the block (bench.py's `roofline_kernels`); the ST_GEMM / ST_ATTN_BWD totals above stay
        ST_G_QKV_FWD, ST_G_PROJ_FWD, ST_G_FC1_FWD, ST_G_FC2_FWD, ST_G_FC2_DX, ST_G_FC1_DX, ST_G_PROJ_DX, ST_G_QKV_DX, ST_G_DW,
-       ST_ATTN_BWD_Q, ST_ATTN_BWD_KV, ST_DKV_GATHER, ST_COUNT };
+       ST_ATTN_BWD_Q, ST_ATTN_BWD_KV, ST_DKV_GATHER, ST_MLP_FWD, ST_MLP_BWD, ST_COUNT };
 static const char* const k_stage_names[ST_COUNT] = {"transpose", "pool_matrix", "ln_pool_fwd", "ln_pool_bwd", "bias_assemble",
     "bias_scatter", "cfm_attn_fwd", "cfm_attn_bwd", "linear_gemm", "colsum", "residual_ln", "ln_bwd", "bias_gelu", "gelu_bwd",
     "residual_out", "gtc_attn_fwd", "gtc_attn_bwd", "layernorm", "adamw", "event_pair_null",
     "gemm_qkv_fwd", "gemm_proj_fwd", "gemm_fc1_fwd", "gemm_fc2_fwd", "gemm_fc2_dx_gelu", "gemm_fc1_dx", "gemm_proj_dx", "gemm_qkv_dx",
-    "gemm_dw_group", "attn_bwd_fused", "attn_bwd_bias_sum", "attn_dkv_gather"};
+    "gemm_dw_group", "attn_bwd_fused", "attn_bwd_bias_sum", "attn_dkv_gather", "mlp_fwd_fused", "mlp_bwd_fused"};
 #ifndef CFFM_EMU
 #include <vector>
 struct ProfRec { int stage; hipEvent_t e0, e1; };
@@ -216,6 +216,7 @@ int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* o) {
     o->act = p; p += up(B * HW * CFFM_HID);
     o->x2 = p; p += up(B * HW * CFFM_C);
     o->w_split = p; p += up(PREP_WFLOATS);   // qkv | proj | fc1 | fc2 weights in split-4 storage (k_param_prep)
+    o->w_frag = p; p += up(2 * PREP_WFLOATS); // the same in MFMA-fragment order: forward forms, then input-gradient forms (row-panel kernels)
     o->total = p;
     return 0;
 }
@@ -905,6 +906,85 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- fused row-panel stages
+// CFFM_PANEL=0 keeps the round-2 sequence of tiled GEMMs + row kernels (A/B measurements)
+static int panel_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFFM_PANEL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+#define MLP_MT 2
+#define MLP_D 4
+static int mlp_lds_grant() {
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void*)k_mlp_fwd<MLP_MT, MLP_D>, hipFuncAttributeMaxDynamicSharedMemorySize, PNL_FUSED_LDS(MLP_MT)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_mlp_bwd<MLP_MT, MLP_D>, hipFuncAttributeMaxDynamicSharedMemorySize, PNL_FUSED_LDS(MLP_MT)) != hipSuccess)
+            return -1;
+        granted = true;
+    }
+#endif
+    return 0;
+}
+long cffm_mlp_records(long NP) { return (NP + 16 * MLP_MT - 1) / (16 * MLP_MT); }
+
+int cffm_panel_pack_weight(const float* w, int N, int K, int form, float* w_frag, void* stream) {
+    REQUIRE(w && w_frag && N >= 16 && K >= 16 && N % 32 == 0 && K % 32 == 0 && (form == 0 || form == 1), "panel_pack_weight: bad arguments");
+    CFFM_LAUNCH(k_pnl_pack_weight, ((unsigned)(((long)N * K / 8 + 255) / 256)), (256), 0, (hipStream_t)stream, w, N, K, form, (f32x4*)w_frag);
+    CHECK_LAUNCH("panel_pack_weight");
+    return 0;
+}
+
+int cffm_mlp_fwd(const float* ao, const float* xt, long xt_bs, int rows_per_batch, const float* wp_f, const float* w1_f, const float* w2_f,
+                 const float* bp, const float* b1, const float* b2, const float* g2, const float* be2, float* x1, float* z2s, float* mean2,
+                 float* rstd2, float* hraw, float* acts, float* x2, long NP, void* stream) {
+    REQUIRE(NP >= 0 && NP < (1L << 21) && rows_per_batch >= 1, "mlp_fwd: bad sizes");
+    if (!NP) return 0;
+    REQUIRE(ao && xt && wp_f && w1_f && w2_f && bp && b1 && b2 && g2 && be2 && x1 && z2s && mean2 && rstd2 && hraw && acts && x2, "mlp_fwd: null");
+    REQUIRE(!mlp_lds_grant(), "mlp_fwd: LDS grant failed");
+    PROF2(ST_MLP_FWD);
+    MlpFwdArgs a;
+    a.ao = ao; a.xt = xt; a.xt_bs = xt_bs; a.rows_per_batch = rows_per_batch;
+    a.wp = (const f32x4*)wp_f; a.w1 = (const f32x4*)w1_f; a.w2 = (const f32x4*)w2_f;
+    a.bp = bp; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2;
+    a.x1 = x1; a.z2s = z2s; a.mean2 = mean2; a.rstd2 = rstd2; a.hraw = hraw; a.acts = acts; a.x2 = x2; a.NP = (int)NP;
+    CFFM_LAUNCH((k_mlp_fwd<MLP_MT, MLP_D>), ((unsigned)cffm_mlp_records(NP)), (PNL_THREADS), PNL_FUSED_LDS(MLP_MT), (hipStream_t)stream, a);
+    CHECK_LAUNCH("mlp_fwd");
+    return 0;
+}
+
+int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const float* x1, const float* mean2, const float* rstd2,
+                 const float* g2, const float* w2_n, const float* w1_n, const float* wp_n, float* dhs, float* dx1, float* dao, float* dg2,
+                 float* dbe2, float* db1, float* db2, float* dbp, long NP, void* stream) {
+    REQUIRE(NP >= 0 && NP < (1L << 21), "mlp_bwd: bad sizes");
+    if (!NP) return 0;
+    REQUIRE(dout && hraw && b1 && x1 && mean2 && rstd2 && g2 && w2_n && w1_n && wp_n && dhs && dx1 && dao, "mlp_bwd: null");
+    REQUIRE(!mlp_lds_grant(), "mlp_bwd: LDS grant failed");
+    PROF2(ST_MLP_BWD);
+    hipStream_t st = (hipStream_t)stream;
+    const int nrec = (int)cffm_mlp_records(NP);
+    float* rec = red_scratch((size_t)nrec * 2048, st);
+    REQUIRE(rec, "mlp_bwd: scratch allocation failed");
+    MlpBwdArgs a;
+    a.dout = dout; a.hraw = hraw; a.b1 = b1; a.x1 = x1; a.mean2 = mean2; a.rstd2 = rstd2; a.g2 = g2;
+    a.w2n = (const f32x4*)w2_n; a.w1n = (const f32x4*)w1_n; a.wpn = (const f32x4*)wp_n;
+    a.dhs = dhs; a.dx1 = dx1; a.dao = dao; a.rec_b1 = rec; a.rec_ln = rec + (size_t)nrec * 1024; a.NP = (int)NP;
+    CFFM_LAUNCH((k_mlp_bwd<MLP_MT, MLP_D>), ((unsigned)nrec), (PNL_THREADS), PNL_FUSED_LDS(MLP_MT), st, a);
+    RedSegs s1, s2;
+    s1.nseg = 0;
+    seg_add(s1, 0, CFFM_HID, db1, 0);
+    reduce_records(a.rec_b1, nrec, CFFM_HID, CFFM_HID, s1, st);
+    s2.nseg = 0;
+    seg_add(s2, 0, CFFM_C, dg2, 0);
+    seg_add(s2, CFFM_C, CFFM_C, dbe2, 0);
+    seg_add(s2, 2 * CFFM_C, CFFM_C, db2, 0);
+    seg_add(s2, 3 * CFFM_C, CFFM_C, dbp, 0);
+    reduce_records(a.rec_ln, nrec, 1024, 1024, s2, st);
+    CHECK_LAUNCH("mlp_bwd");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- block
 // bias tiles + pooling matrices of `n` blocks (workspaces ws0 + i*ws_stride) in ceil(n / PREP_MAXD) launches
 static int param_prep(const cffm_block_params* params, int n, float* ws0, long ws_stride, const cffm_block_ws& L, void* stream) {
@@ -921,10 +1001,11 @@ static int param_prep(const cffm_block_params* params, int n, float* ws0, long w
             a.bias[d] = ws + L.bias; a.M[d] = ws + L.M;
             a.w[d][0] = p.qkv_w; a.w[d][1] = p.proj_w; a.w[d][2] = p.fc1_w; a.w[d][3] = p.fc2_w;
             a.w_s[d] = ws + L.w_split;
+            a.w_f[d] = ws + L.w_frag;
         }
         a.nbias = nb;
         a.pack = gemm_use_lib() ? 0 : 1;
-        CFFM_LAUNCH(k_param_prep, (nb + 1 + (a.pack ? PREP_WBLOCKS : 0), nd), (256), 0, (hipStream_t)stream, a);
+        CFFM_LAUNCH(k_param_prep, (nb + 1 + (a.pack ? PREP_WBLOCKS + PREP_FBLOCKS : 0), nd), (256), 0, (hipStream_t)stream, a);
     }
     CHECK_LAUNCH("param_prep");
     return 0;
@@ -965,6 +1046,16 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
         TRY(cffm_linear_qkv_fwd(ws + L.zall, p->qkv_w, p->qkv_b, ws + L.qkv, NR, stream));
     }
     TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, (const void*)(ws + L.bias), ws + L.ao, ws + L.lse, stream));
+    if (sp && panel_on()) {
+        // proj + residual + norm2 + Mlp in one row-panel launch (panel_kernels.h); weights in fragment order from k_param_prep
+        const float* wf = ws + L.w_frag;
+        PROF(ST_GEMM);
+        TRY(cffm_mlp_fwd(ws + L.ao, x_tgt, tgt_bs, g->HW, wf + 768 * 256, wf + 768 * 256 + 256 * 256, wf + 768 * 256 + 256 * 256 + 1024 * 256,
+                         p->proj_b, p->fc1_b, p->fc2_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2, ws + L.mean2, ws + L.rstd2, ws + L.hraw,
+                         ws + L.act, ws + L.x2, NP, stream));
+        CHECK_LAUNCH("block_forward");
+        return 0;
+    }
     if (sp) {
         PROF(ST_GEMM); PROF2(ST_G_PROJ_FWD);
         REQUIRE(!gemm_nt_split_pre<false>(ws + L.ao, wp_s, yraw, NP, CFFM_C, CFFM_C, st), "block_forward: proj gemm failed");
@@ -1036,7 +1127,28 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     // x2 = x1 + act W2^T + b2
     // act = gelu(hraw + b1); hraw = z2 W1^T: the GELU backward runs in the epilogue of the fc2 input-gradient GEMM (dact is
     // never materialised; what is stored is dh, in split-4 storage since only GEMMs read it, plus column-sum records of it)
-    if (sp) {
+    const int panel = sp && panel_on();
+    if (panel) {
+        // the input-gradient chain fc2 -> GELU' -> fc1 -> norm2 -> proj in one row-panel launch; dh (split-4), dx1 and the bias / norm
+        // gradient records come out of it for the weight-gradient groups and the reductions below
+        const float* wfn = ws + L.w_frag + PREP_WFLOATS;
+        PROF(ST_GEMM);
+        TRY(cffm_mlp_bwd(dout, ws + L.hraw, p->fc1_b, ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, wfn + 768 * 256 + 256 * 256 + 1024 * 256,
+                         wfn + 768 * 256 + 256 * 256, wfn + 768 * 256, dact, dx1, dao, gr->norm2_w, gr->norm2_b, gr->fc1_b, gr->fc2_b, gr->proj_b, NP,
+                         stream));
+        if (!one_group) {
+            sa = side_fork(st, 0);
+            void* stream_a = (void*)sa;
+            const cffm_wgrad wga[2] = {{dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C}, {dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}};
+            const GemmTNPre prea[2] = {{1, 1}, {0, 1}};
+            {
+                void* stream = stream_a;
+                PROF2(ST_G_DW);
+                REQUIRE(!gemm_tn_group((const GemmTN*)wga, 2, sa, prea, sa == st ? lib_scratch : lib_scratch2, 320), "block_backward: weight-gradient gemm failed");
+            }
+            side_mark(sa, st, 0);
+        }
+    } else if (sp) {
         PROF(ST_GEMM); PROF2(ST_G_FC2_DX);
         const int nrec = GEMM_GELUBWD_RECORDS(NP);
         float* part = red_scratch((size_t)nrec * CFFM_HID, st);
@@ -1065,12 +1177,14 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
         TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
         TRY(gelu_bwd_impl(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, 0, stream));
     }
+    if (!panel) {
     DX_GEMM(ST_G_FC1_DX, true, dact, p->fc1_w, w1_s, dz2, NP, CFFM_HID, CFFM_C);
     // z2 = LN2(x1); x1 also feeds the residual
     TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1,
                              gr->fc2_b /* = colsum(dout) */, gr->proj_b /* = colsum(dx1) */, stream));
     // x1 = xt + ao Wp^T + bp
     DX_GEMM(ST_G_PROJ_DX, false, dx1, p->proj_w, wp_s, dao, NP, CFFM_C, CFFM_C);
+    }
     // attention: the fused kernel and the dK/dV gather stay on the chain; the bias-gradient tile sum and its scatter into the six
     // tables go to the side stream (branch 1), the q|k|v bias column sum and the weight gradients of q|k|v / proj after the gather
     // (branch 2)

@@ -1,0 +1,600 @@
+// panel_kernels.h -- "row panel" Linear GEMMs: one workgroup owns 16*MT complete rows of the activation matrix.
+//
+// Why a second GEMM form (round 3).  At CFFM-B1 sizes the Linear layers are small for this chip (M = 7200 token rows, N / K in
+// {256, 768, 1024}: 28 rows per CU): the tiled kernels of gemm_kernels.h run 64x64 tiles that re-stage BOTH operands through
+// LDS with one barrier per 32-deep K-tile and reach 9-17 % of the three-pass bf16 peak.  Here the activation operand of a
+// workgroup (a panel of 32 or 48 rows x the whole contraction) is staged ONCE into LDS as hi / lo bf16 images, and the weight
+// operand never touches LDS at all: k_param_prep leaves a copy of every weight in MFMA-FRAGMENT ORDER (16 output features x 32
+// contraction steps per 2 KiB unit: 64 lanes x {8 bf16 hi | 8 bf16 lo}), so that a wave fetches its B fragments with fully
+// coalesced 1 KiB buffer loads straight into registers, a ring of D k-steps ahead of the MFMAs.  The K-loop has no barrier
+// (one per 256-deep chunk of the contraction, for the double-buffered panel image), every wave streams on its own, and a
+// whole output row lives in one workgroup -- which is what lets residual + LayerNorm + the next Linear follow in the same
+// kernel (fused forms below).  Products are computed transposed (D = W_frag x X_frag^T), so a lane ends up with 4 consecutive
+// output features of one row: 16-byte stores, and 8-byte hi / lo stores when the result is the next GEMM's panel image.
+#pragma once
+#include "cffm_common.h"
+#include "gemm_kernels.h"
+
+#ifndef PNL_ABLATE
+#define PNL_ABLATE 0      // profiling builds of scripts/r03_panel_bench.hip only: 1 no B loads in the loop, 2 no MFMAs, 4 no epilogue stores, 8 no panel staging
+#endif
+#define PNL_KC 256          // contraction chunk held in LDS (floats per row)
+#define PNL_THREADS 512     // 8 waves: two per SIMD
+#define PNL_WAVES 8
+// bf16 element offset of 16-byte chunk `chunk` (8 k) of panel row `row` inside a [rows][256] image: the chunk index is XOR-ed
+// with the row so that the 16-lane groups a ds_read_b128 is served in ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: rows x two
+// adjacent k-chunks) cover the 16 bank quads exactly once (checked exhaustively in tests/test_geometry.py)
+__device__ __forceinline__ int pnl_off(int row, int chunk) { return row * PNL_KC + (((chunk ^ row) & 15) << 3) + ((chunk & 16) << 3); }
+#define PNL_IMG(MT) (16 * (MT) * PNL_KC)                       // bf16 elements of one image
+#define PNL_LDS(MT) (2 * 2 * PNL_IMG(MT) * 2)                  // bytes: double-buffered {hi, lo}
+
+// index (in 16-byte units) of the fragment of output tile jt, k-step ks, half h (0 hi, 1 lo) in a fragment-ordered weight
+__device__ __host__ __forceinline__ long pnl_frag_unit(int jt, int ks, int h, int KS) { return ((long)(jt * KS + ks) * 2 + h) * 64; }
+
+// Fragment-ordered copy of a weight for the two uses:
+//   NT form (forward, y = x W^T, W [N][K]):        out feature n = 16 jt + l15, contraction k = 32 ks + 8 g + e  -> W[n][k]
+//   NN form (input gradient, dx = dy W, W [N][K]): out feature k' = 16 jt + l15, contraction n = 32 ks + 8 g + e -> W[n][k']
+// one thread per (unit lane): writes 16 B hi + 16 B lo
+__device__ __forceinline__ void pnl_pack_weight(const float* __restrict__ W, int N, int K, bool nn, f32x4* __restrict__ dst, long item) {
+    const int lane = (int)(item & 63);
+    const long u = item >> 6;
+    const int OUT = nn ? K : N, KS = (nn ? N : K) / 32;
+    const int ks = (int)(u % KS), jt = (int)(u / KS);
+    if (jt * 16 >= OUT) return;
+    const int l15 = lane & 15, g = lane >> 4;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 16 * jt + l15, c = 32 * ks + 8 * g + e;
+        const float x = nn ? W[(long)c * K + o] : W[(long)o * K + c];
+        hi[e] = (bf16)x;
+        lo[e] = (bf16)(x - (float)hi[e]);
+    }
+    dst[pnl_frag_unit(jt, ks, 0, KS) + lane] = __builtin_bit_cast(f32x4, hi);
+    dst[pnl_frag_unit(jt, ks, 1, KS) + lane] = __builtin_bit_cast(f32x4, lo);
+}
+__global__ void __launch_bounds__(256) k_pnl_pack_weight(const float* __restrict__ W, int N, int K, int nn, f32x4* __restrict__ dst) {
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    if (item < (long)N * K / 8) pnl_pack_weight(W, N, K, nn != 0, dst, item);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release / acquire of ALL memory: on gfx9 it waits vmcnt(0),
+// i.e. for every global store issued so far to be acknowledged AND for the whole B-fragment ring that is in flight -- measured on the
+// fused forward kernel: 44.6 us with __syncthreads(), of which 20 us were the (seven times drained) stores.
+__device__ __forceinline__ void pnl_lds_barrier() {
+#ifdef CFFM_EMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
+// ---- panel staging: global -> registers -> LDS images -------------------------------------------------------------------
+template <int MT>
+struct PnlStage { f32x4 v[2 * MT]; };
+// rows m0 .. m0+16MT-1, floats [kc0, kc0+256) of each; rows >= M read as zeros (buffer bounds)
+template <int MT>
+__device__ __forceinline__ void pnl_stage_load(PnlStage<MT>& r, buf_t rs, int lda, int m0, int kc0, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2 * MT; ++it) {
+        const int item = tid + PNL_THREADS * it, row = item >> 6, c4 = item & 63;
+        r.v[it] = buf_ld16(rs, (uint32_t)((row * lda + 4 * c4) * 4), (uint32_t)(((long)m0 * lda + kc0) * 4));
+    }
+}
+template <int MT, bool PRE>
+__device__ __forceinline__ void pnl_stage_store(const PnlStage<MT>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2 * MT; ++it) {
+        const int item = tid + PNL_THREADS * it, row = item >> 6, c4 = item & 63;
+        bf16x4 h, l;
+        if (PRE) unsplit4(r.v[it], h, l);
+        else split4(r.v[it], h, l);
+        const int o = pnl_off(row, c4 >> 1) + 4 * (c4 & 1);
+        *(bf16x4*)(hi + o) = h;
+        *(bf16x4*)(lo + o) = l;
+    }
+}
+
+// ---- the streaming product of one 256-deep chunk --------------------------------------------------------------------------
+// acc[t][i] += W_frag(tile jt0 + t, k-steps ks0 .. ks0+7) x panel(rows 16 i .., chunk image)^T for t < NTW, in passes of NT tiles.
+// B ring: D k-steps of NT tiles x {hi, lo} in registers; the loads of step s + D are issued while step s is multiplied.
+// The ring runs across passes, chunks and (for the fused kernels) across GEMMs: `next` tells where the stream continues.
+template <int NT, int D>
+struct PnlRing { f32x4 v[D][NT][2]; };
+
+struct PnlStream {       // position of a wave's B stream: base unit of (jt, ks) = (jt0, 0) and the k-steps per tile
+    buf_t rs;
+    uint32_t voff;       // lane * 16
+    int KS;              // k-steps of 32 per output tile in this weight
+};
+template <int NT, int D>
+__device__ __forceinline__ void pnl_ring_load(PnlRing<NT, D>& ring, int slot, const PnlStream& st, int jt, int ks) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            ring.v[slot][j][h] = buf_ld16(st.rs, st.voff, (uint32_t)(pnl_frag_unit(jt + j, ks, h, st.KS) * 16));
+}
+
+// VMEM issue points are pinned per step (everything else may be scheduled across): left alone, hipcc sinks every prefetch down to
+// its first use and waits vmcnt(0) there, i.e. no prefetch at all (round-3 ISA dump: 26 us instead of 10 for fc1)
+__device__ __forceinline__ void pnl_pin_vmem() {
+#ifndef CFFM_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// Invariant at entry: the ring holds steps 0 .. D-2 of this chunk (slot = step % D); at exit: steps 0 .. D-2 of what follows.
+template <int MT, int NTW, int NT, int D>
+__device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT, D>& ring, const bf16* __restrict__ Ahi,
+                                              const bf16* __restrict__ Alo, const PnlStream& st, int jt0, int ks0, int l15, int g,
+                                              // where the stream goes after this chunk (its first D-1 steps are prefetched from here)
+                                              const PnlStream& nst, int njt0, int nks0) {
+    constexpr int NPASS = NTW / NT, SC = NPASS * 8;
+    static_assert(NTW % NT == 0 && SC % D == 0 && D <= SC && D >= 2, "ring depth must divide the steps of a chunk");
+    bf16x8 ah[2][MT], al[2][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        ah[0][i] = *(const bf16x8*)(Ahi + pnl_off(16 * i + l15, g));
+        al[0][i] = *(const bf16x8*)(Alo + pnl_off(16 * i + l15, g));
+    }
+#pragma unroll
+    for (int sc = 0; sc < SC; ++sc) {
+        const int p = sc / 8, cur = sc & 1;
+        // the slot consumed by the previous step takes step sc + D - 1 (of this chunk, or of what follows it)
+        const int sn = sc + D - 1, slot_n = sn % D;
+        if (PNL_ABLATE & 1) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { asm volatile("" : "+v"(ring.v[slot_n][j][0]), "+v"(ring.v[slot_n][j][1])); }
+        } else if (sn < SC) pnl_ring_load<NT, D>(ring, slot_n, st, jt0 + (sn / 8) * NT, ks0 + sn % 8);
+        else pnl_ring_load<NT, D>(ring, slot_n, nst, njt0 + ((sn - SC) / 8) * NT, nks0 + (sn - SC) % 8);
+        pnl_pin_vmem();
+        if (sc + 1 < SC) {
+            const int k8n = (sc + 1) % 8;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[cur ^ 1][i] = *(const bf16x8*)(Ahi + pnl_off(16 * i + l15, 4 * k8n + g));
+                al[cur ^ 1][i] = *(const bf16x8*)(Alo + pnl_off(16 * i + l15, 4 * k8n + g));
+            }
+        }
+        const int slot = sc % D;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, ring.v[slot][j][0]), bl = __builtin_bit_cast(bf16x8, ring.v[slot][j][1]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x4 c = acc[p * NT + j][i];
+                if (PNL_ABLATE & 2) { asm volatile("" : "+v"(c) : "v"(bh), "v"(bl), "v"(ah[cur][i]), "v"(al[cur][i])); acc[p * NT + j][i] = c; continue; }
+                c = mfma16x16x32_bf16(bh, al[cur][i], c);
+                c = mfma16x16x32_bf16(bl, ah[cur][i], c);
+                c = mfma16x16x32_bf16(bh, ah[cur][i], c);
+                acc[p * NT + j][i] = c;
+            }
+        }
+    }
+}
+
+// ---- plain panel GEMM: C[M][N] = A[M][K] W^T (+ bias), W in fragment order (NT or NN form decides what "W^T" means) ---------
+// grid = ceil(M / (16 MT)) workgroups of 512 threads; N = 8 waves x NTW tiles x 16; K a multiple of 256.
+// EPI: 0 plain fp32 (+bias)
+template <int MT, int NTW, int NT, int D, bool A_PRE, int EPI>
+__global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restrict__ A, int lda, int M, int K, const f32x4* __restrict__ Wf,
+                                                            float* __restrict__ C, int ldc, const float* __restrict__ bias) {
+    CFFM_DYN_SMEM(smem);
+    bf16* img = (bf16*)smem;     // [buf][hi | lo][16 MT][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 16 * MT;
+    const int NCH = K / PNL_KC, KS = K / 32, N = PNL_WAVES * NTW * 16;
+    const buf_t rsa = buf_make(A, (uint32_t)((long)M * lda * 4));
+    PnlStream st;
+    st.rs = buf_make(Wf, (uint32_t)((long)N * K * 4));
+    st.voff = lane * 16;
+    st.KS = KS;
+    const int jt0 = wave * NTW;
+    f32x4 acc[NTW][MT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    PnlRing<NT, D> ring;
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) pnl_ring_load<NT, D>(ring, s, st, jt0 + (s / 8) * NT, s % 8);
+    pnl_pin_vmem();
+    PnlStage<MT> sr;
+    pnl_stage_load<MT>(sr, rsa, lda, m0, 0, tid);
+    pnl_stage_store<MT, A_PRE>(sr, img, img + PNL_IMG(MT), tid);
+    if (NCH > 1) pnl_stage_load<MT>(sr, rsa, lda, m0, PNL_KC, tid);
+    pnl_lds_barrier();
+    for (int c = 0; c < NCH; ++c) {
+        const bf16* hi = img + (c & 1) * 2 * PNL_IMG(MT);
+        pnl_chunk_mma<MT, NTW, NT, D>(acc, ring, hi, hi + PNL_IMG(MT), st, jt0, 8 * c, l15, g, st, jt0, 8 * (c + 1));
+        if (c + 1 < NCH) {
+            bf16* nx = img + ((c + 1) & 1) * 2 * PNL_IMG(MT);
+            pnl_stage_store<MT, A_PRE>(sr, nx, nx + PNL_IMG(MT), tid);
+            if (c + 2 < NCH) pnl_stage_load<MT>(sr, rsa, lda, m0, (c + 2) * PNL_KC, tid);
+            pnl_lds_barrier();
+        }
+    }
+    // epilogue: acc[t][i][r] = C[m0 + 16 i + l15][16 (jt0 + t) + 4 g + r]
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int n = 16 * (jt0 + t) + 4 * g;
+        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *(const f32x4*)(bias + n);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + 16 * i + l15;
+            if (PNL_ABLATE & 4) { if (acc[t][i][0] == 1.2345f && m < M) C[m] = 1.f; continue; }
+            if (m < M) *(f32x4*)(C + (long)m * ldc + n) = acc[t][i] + bv;
+        }
+    }
+}
+
+// =====================================================================================================================
+// Fused row-panel kernels of the block (round 3): everything between the attention output and the block output in ONE
+// launch per direction.  A workgroup owns 16 MT token rows; intermediates (x1, LN2(x1), the hidden activations) live in LDS
+// / registers as the next GEMM's panel image, the three weights stream through the B ring back to back.
+//   forward  (cffm_transformer.py:602 proj, :823 residual, :824 norm2 + Mlp :10-26 + residual):
+//       x1 = xt + ao Wp^T + bp;  z2 = LN2(x1);  hraw = z2 W1^T;  act = gelu(hraw + b1);  x2 = x1 + act W2^T + b2
+//   backward (the input-gradient chain of the same lines):
+//       dh = (dout W2) * gelu'(hraw + b1);  dz2 = dh W1;  dx1 = dout + LN2'(dz2);  dao = dx1 Wp
+// replacing (forward) k_gemm_split<proj> + k_residual_ln + k_gemm_split<fc1+GELU> + k_gemm_split<fc2+residual> and (backward)
+// k_gemm_split<fc2 dX + GELU'> + k_gemm_split<fc1 dX> + k_ln_bwd_residual + k_gemm_split<proj dX>; the weight gradients keep
+// reading z2 / act / dh (split-4 storage) and x1 / dx1 / ao from memory as before.
+__device__ __forceinline__ f32x4 pnl_pack_hl(bf16x4 h, bf16x4 l) {
+    const f32x2_t a = __builtin_bit_cast(f32x2_t, h), b = __builtin_bit_cast(f32x2_t, l);
+    return (f32x4){a[0], a[1], b[0], b[1]};
+}
+// 4 consecutive features n .. n+3 of panel row `row` -> the hi / lo images (8-byte stores)
+__device__ __forceinline__ void pnl_img_put(bf16* __restrict__ hi, bf16* __restrict__ lo, int row, int n, bf16x4 h, bf16x4 l) {
+    const int o = pnl_off(row, n >> 3) + (n & 4);
+    *(bf16x4*)(hi + o) = h;
+    *(bf16x4*)(lo + o) = l;
+}
+// sum over the four lane groups g (lanes l15, l15 + 16, l15 + 32, l15 + 48): result in every lane
+__device__ __forceinline__ float pnl_sum_g(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+#define PNL_ST(v) ((v) && !(PNL_ABLATE & 4))
+#define PNL_FUSED_LDS(MT) (6 * PNL_IMG(MT) * 2 + 2 * PNL_WAVES * 16 * (MT) * 4)   // P + 2 x ACT (hi | lo each) + reduction scratch
+
+struct MlpFwdArgs {
+    const float* ao;                    // [NP][256] attention output
+    const float* xt; long xt_bs; int rows_per_batch;   // residual input: row m = xt + (m / rpb) * xt_bs + (m % rpb) * 256
+    const f32x4 *wp, *w1, *w2;          // fragment-ordered weights, NT form (pnl_pack_weight)
+    const float *bp, *b1, *b2, *g2, *be2;
+    float *x1, *z2s /* split-4 */, *mean2, *rstd2, *hraw, *acts /* split-4 */, *x2;
+    int NP;
+};
+
+template <int MT, int D>
+__global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
+    CFFM_DYN_SMEM(smem);
+    bf16* P = (bf16*)smem;                         // ao panel, later the z2 panel
+    bf16* ACT = P + 2 * PNL_IMG(MT);               // two hidden-chunk images
+    float* red = (float*)(ACT + 4 * PNL_IMG(MT));  // [2][8 waves][16 MT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 16 * MT, NP = a.NP;
+    PnlStream sp, s1, s2;
+    sp.rs = buf_make(a.wp, 256u * 256 * 4); sp.voff = lane * 16; sp.KS = 8;
+    s1.rs = buf_make(a.w1, 1024u * 256 * 4); s1.voff = lane * 16; s1.KS = 8;
+    s2.rs = buf_make(a.w2, 1024u * 256 * 4); s2.voff = lane * 16; s2.KS = 32;
+    PnlRing<2, D> ring;
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) pnl_ring_load<2, D>(ring, s, sp, 2 * wave, s);
+    pnl_pin_vmem();
+    {
+        PnlStage<MT> sr;
+        pnl_stage_load<MT>(sr, buf_make(a.ao, (uint32_t)((long)NP * 256 * 4)), 256, m0, 0, tid);
+        pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+    }
+    pnl_lds_barrier();
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[t][i] = z4;
+    pnl_chunk_mma<MT, 2, 2, D>(acc, ring, P, P + PNL_IMG(MT), sp, 2 * wave, 0, l15, g, s1, 2 * wave, 0);
+    // ---- x1 = xt + proj + bp, LayerNorm statistics over the 256 features of a row (8 waves x 32 features)
+    f32x4 x1v[2][MT];
+    bool valid[MT];
+    long mrow[MT];
+    float s[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const long m = m0 + 16 * i + l15;
+        valid[i] = m < NP;
+        mrow[i] = m;
+        s[i] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * wave + 16 * t + 4 * g;
+        const f32x4 bv = *(const f32x4*)(a.bp + n);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            f32x4 r = z4;
+            if (valid[i]) {
+                const long b = mrow[i] / a.rows_per_batch, rr = mrow[i] % a.rows_per_batch;
+                r = *(const f32x4*)(a.xt + b * a.xt_bs + rr * 256 + n);
+            }
+            const f32x4 v = acc[t][i] + bv + r;
+            x1v[t][i] = v;
+            if (PNL_ST(valid[i])) *(f32x4*)(a.x1 + mrow[i] * 256 + n) = v;
+            s[i] += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        s[i] = pnl_sum_g(s[i]);
+        if (g == 0) red[wave * 16 * MT + 16 * i + l15] = s[i];
+    }
+    pnl_lds_barrier();
+    float mu[MT], rs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < PNL_WAVES; ++w) tot += red[w * 16 * MT + 16 * i + l15];
+        mu[i] = tot * (1.f / 256);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 d = x1v[t][i] - mu[i];
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        q = pnl_sum_g(q);
+        if (g == 0) red[(PNL_WAVES + wave) * 16 * MT + 16 * i + l15] = q;
+    }
+    pnl_lds_barrier();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < PNL_WAVES; ++w) tot += red[(PNL_WAVES + w) * 16 * MT + 16 * i + l15];
+        rs[i] = 1.f / sqrtf(tot * (1.f / 256) + CFFM_LN_EPS);
+        if (wave == 0 && g == 0 && valid[i]) { a.mean2[mrow[i]] = mu[i]; a.rstd2[mrow[i]] = rs[i]; }
+    }
+    // z2 -> the panel image (the ao image is dead: every wave finished its proj product before the first barrier above)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * wave + 16 * t + 4 * g;
+        const f32x4 gm = *(const f32x4*)(a.g2 + n), be = *(const f32x4*)(a.be2 + n);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4 zv = (x1v[t][i] - mu[i]) * rs[i] * gm + be;
+            bf16x4 h, l;
+            split4(zv, h, l);
+            pnl_img_put(P, P + PNL_IMG(MT), 16 * i + l15, n, h, l);
+            if (PNL_ST(valid[i])) *(f32x4*)(a.z2s + mrow[i] * 256 + n) = pnl_pack_hl(h, l);
+        }
+    }
+    pnl_lds_barrier();
+    // ---- Mlp: hidden chunks of 256 features: fc1 chunk -> GELU -> chunk image -> fc2 accumulates over the chunk
+    f32x4 acc2[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc2[t][i] = z4;
+    for (int c = 0; c < 4; ++c) {
+        f32x4 h1[2][MT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) h1[t][i] = z4;
+        pnl_chunk_mma<MT, 2, 2, D>(h1, ring, P, P + PNL_IMG(MT), s1, 16 * c + 2 * wave, 0, l15, g, s2, 2 * wave, 8 * c);
+        bf16* Ah = ACT + (c & 1) * 2 * PNL_IMG(MT);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nl = 32 * wave + 16 * t + 4 * g, n = 256 * c + nl;
+            const f32x4 bv = *(const f32x4*)(a.b1 + n);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const f32x4 raw = h1[t][i];
+                f32x4 av;
+                for (int e = 0; e < 4; ++e) av[e] = gelu_erf(raw[e] + bv[e]);
+                bf16x4 h, l;
+                split4(av, h, l);
+                pnl_img_put(Ah, Ah + PNL_IMG(MT), 16 * i + l15, nl, h, l);
+                if (PNL_ST(valid[i])) {
+                    *(f32x4*)(a.hraw + mrow[i] * 1024 + n) = raw;
+                    *(f32x4*)(a.acts + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
+                }
+            }
+        }
+        pnl_lds_barrier();
+        const int cn = c < 3 ? c + 1 : 0;
+        pnl_chunk_mma<MT, 2, 2, D>(acc2, ring, Ah, Ah + PNL_IMG(MT), s2, 2 * wave, 8 * c, l15, g, s1, 16 * cn + 2 * wave, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * wave + 16 * t + 4 * g;
+        const f32x4 bv = *(const f32x4*)(a.b2 + n);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if (PNL_ST(valid[i])) *(f32x4*)(a.x2 + mrow[i] * 256 + n) = x1v[t][i] + acc2[t][i] + bv;
+    }
+}
+
+struct MlpBwdArgs {
+    const float* dout;                  // [NP][256] gradient of the block's output rows
+    const float* hraw; const float* b1; // saved fc1 product, fc1 bias
+    const float *x1, *mean2, *rstd2, *g2;
+    const f32x4 *w2n, *w1n, *wpn;       // fragment-ordered weights, NN form
+    float* dhs;                         // [NP][1024] split-4: gradient of hraw
+    float* dx1;                         // [NP][256]
+    float* dao;                         // [NP][256]
+    float* rec_b1;                      // [workgroups][1024] column sums of dh (fc1 bias gradient records)
+    float* rec_ln;                      // [workgroups][1024] dgamma2 | dbeta2 | colsum(dout) | colsum(dx1) records
+    int NP;
+};
+
+template <int MT, int D>
+__global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
+    CFFM_DYN_SMEM(smem);
+    bf16* P = (bf16*)smem;                         // dout panel, later the dx1 panel
+    bf16* DH = P + 2 * PNL_IMG(MT);                // two hidden-chunk images of dh
+    float* red = (float*)(DH + 4 * PNL_IMG(MT));   // [2][8 waves][16 MT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 16 * MT, NP = a.NP;
+    PnlStream s2, s1, sp;
+    s2.rs = buf_make(a.w2n, 1024u * 256 * 4); s2.voff = lane * 16; s2.KS = 8;    // out 1024 hidden, contraction 256
+    s1.rs = buf_make(a.w1n, 1024u * 256 * 4); s1.voff = lane * 16; s1.KS = 32;   // out 256, contraction 1024
+    sp.rs = buf_make(a.wpn, 256u * 256 * 4); sp.voff = lane * 16; sp.KS = 8;
+    PnlRing<2, D> ring;
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) pnl_ring_load<2, D>(ring, s, s2, 2 * wave, s);
+    pnl_pin_vmem();
+    const buf_t rs_dout = buf_make(a.dout, (uint32_t)((long)NP * 256 * 4));
+    {
+        PnlStage<MT> sr;
+        pnl_stage_load<MT>(sr, rs_dout, 256, m0, 0, tid);
+        pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+    }
+    pnl_lds_barrier();
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool valid[MT];
+    long mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const long m = m0 + 16 * i + l15;
+        valid[i] = m < NP;
+        mrow[i] = m;
+    }
+    f32x4 dz[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) dz[t][i] = z4;
+    for (int c = 0; c < 4; ++c) {
+        f32x4 da[2][MT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) da[t][i] = z4;
+        pnl_chunk_mma<MT, 2, 2, D>(da, ring, P, P + PNL_IMG(MT), s2, 16 * c + 2 * wave, 0, l15, g, s1, 2 * wave, 8 * c);
+        bf16* Ah = DH + (c & 1) * 2 * PNL_IMG(MT);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nl = 32 * wave + 16 * t + 4 * g, n = 256 * c + nl;
+            const f32x4 bv = *(const f32x4*)(a.b1 + n);
+            f32x4 cs = z4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x4 dh = z4;
+                if (valid[i]) {
+                    const f32x4 hr = *(const f32x4*)(a.hraw + mrow[i] * 1024 + n) + bv;
+                    for (int e = 0; e < 4; ++e) dh[e] = da[t][i][e] * gelu_erf_grad(hr[e]);
+                }
+                bf16x4 h, l;
+                split4(dh, h, l);
+                pnl_img_put(Ah, Ah + PNL_IMG(MT), 16 * i + l15, nl, h, l);
+                if (PNL_ST(valid[i])) *(f32x4*)(a.dhs + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
+                cs += dh;
+            }
+            for (int e = 0; e < 4; ++e) cs[e] = row16_sum(cs[e]);
+            if (l15 == 0) *(f32x4*)(a.rec_b1 + (long)blockIdx.x * 1024 + n) = cs;
+        }
+        pnl_lds_barrier();
+        const bool more = c < 3;
+        pnl_chunk_mma<MT, 2, 2, D>(dz, ring, Ah, Ah + PNL_IMG(MT), s1, 2 * wave, 8 * c, l15, g, more ? s2 : sp, more ? 16 * (c + 1) + 2 * wave : 2 * wave, 0);
+    }
+    // ---- LayerNorm backward + residual: dx1 = dout + rstd (gz - mean(gz) - xh mean(gz xh)), gz = dz2 * gamma
+    f32x4 xh[2][MT], gz[2][MT], dr[2][MT];
+    float mu[MT], rs[MT], m1[MT], m2[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        mu[i] = valid[i] ? a.mean2[mrow[i]] : 0.f;
+        rs[i] = valid[i] ? a.rstd2[mrow[i]] : 0.f;
+        m1[i] = m2[i] = 0.f;
+    }
+    f32x4 ag[2], ab[2], ar[2], ax[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * wave + 16 * t + 4 * g;
+        const f32x4 gm = *(const f32x4*)(a.g2 + n);
+        ag[t] = ab[t] = ar[t] = ax[t] = z4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            f32x4 xv = z4, dv = z4;
+            if (valid[i]) {
+                xv = *(const f32x4*)(a.x1 + mrow[i] * 256 + n);
+                dv = *(const f32x4*)(a.dout + mrow[i] * 256 + n);
+            }
+            xh[t][i] = (xv - mu[i]) * rs[i];
+            dr[t][i] = dv;
+            gz[t][i] = dz[t][i] * gm;
+            ag[t] += dz[t][i] * xh[t][i];
+            ab[t] += dz[t][i];
+            ar[t] += dv;
+            const f32x4 p = gz[t][i] * xh[t][i];
+            m1[i] += (gz[t][i][0] + gz[t][i][1]) + (gz[t][i][2] + gz[t][i][3]);
+            m2[i] += (p[0] + p[1]) + (p[2] + p[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        m1[i] = pnl_sum_g(m1[i]);
+        m2[i] = pnl_sum_g(m2[i]);
+        if (g == 0) {
+            red[wave * 16 * MT + 16 * i + l15] = m1[i];
+            red[(PNL_WAVES + wave) * 16 * MT + 16 * i + l15] = m2[i];
+        }
+    }
+    pnl_lds_barrier();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < PNL_WAVES; ++w) {
+            t1 += red[w * 16 * MT + 16 * i + l15];
+            t2 += red[(PNL_WAVES + w) * 16 * MT + 16 * i + l15];
+        }
+        m1[i] = t1 * (1.f / 256);
+        m2[i] = t2 * (1.f / 256);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * wave + 16 * t + 4 * g;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4 dxv = (gz[t][i] - m1[i] - xh[t][i] * m2[i]) * rs[i] + dr[t][i];
+            ax[t] += dxv;
+            bf16x4 h, l;
+            split4(dxv, h, l);
+            pnl_img_put(P, P + PNL_IMG(MT), 16 * i + l15, n, h, l);     // (the dout image is dead since the last hidden chunk)
+            if (PNL_ST(valid[i])) *(f32x4*)(a.dx1 + mrow[i] * 256 + n) = dxv;
+        }
+        for (int e = 0; e < 4; ++e) {
+            ag[t][e] = row16_sum(ag[t][e]);
+            ab[t][e] = row16_sum(ab[t][e]);
+            ar[t][e] = row16_sum(ar[t][e]);
+            ax[t][e] = row16_sum(ax[t][e]);
+        }
+        if (l15 == 0) {
+            float* rec = a.rec_ln + (long)blockIdx.x * 1024 + n;
+            *(f32x4*)(rec) = ag[t];
+            *(f32x4*)(rec + 256) = ab[t];
+            *(f32x4*)(rec + 512) = ar[t];
+            *(f32x4*)(rec + 768) = ax[t];
+        }
+    }
+    pnl_lds_barrier();
+    f32x4 dq[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) dq[t][i] = z4;
+    pnl_chunk_mma<MT, 2, 2, D>(dq, ring, P, P + PNL_IMG(MT), sp, 2 * wave, 0, l15, g, sp, 2 * wave, 8);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * wave + 16 * t + 4 * g;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if (PNL_ST(valid[i])) *(f32x4*)(a.dao + mrow[i] * 256 + n) = dq[t][i];
+    }
+}

@@ -8,6 +8,7 @@
 #pragma once
 #include "cffm_common.h"
 #include "cffa_kernels.h"
+#include "panel_kernels.h"
 
 // --------------------------------------------------------------------------- position-bias tables
 struct BiasTables {
@@ -79,6 +80,9 @@ __global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __re
 // arithmetic -- each weight element is otherwise re-split by every row panel of the GEMM (81x for the q|k|v Linear).
 #define PREP_WFLOATS (768 * 256 + 256 * 256 + 1024 * 256 + 256 * 1024)
 #define PREP_WBLOCKS (PREP_WFLOATS / 4 / 256)
+// ... and the same four weights in MFMA-fragment order for the row-panel kernels (panel_kernels.h), forward (NT) forms first,
+// input-gradient (NN) forms behind them, each set laid out qkv | proj | fc1 | fc2 like the split-4 copy: 2 x PREP_WFLOATS floats
+#define PREP_FBLOCKS (2 * PREP_WFLOATS / 8 / 256)
 struct PrepArgs {
     BiasTables t[PREP_MAXD];
     PoolW pw[PREP_MAXD];
@@ -86,6 +90,7 @@ struct PrepArgs {
     float* M[PREP_MAXD];
     const float* w[PREP_MAXD][4];
     float* w_s[PREP_MAXD];
+    float* w_f[PREP_MAXD];
     int nbias, pack;
 };
 __global__ void __launch_bounds__(256) k_param_prep(PrepArgs a) {
@@ -93,8 +98,22 @@ __global__ void __launch_bounds__(256) k_param_prep(PrepArgs a) {
     if (bx < a.nbias) { bias_assemble_body(a.t[d], nullptr, (h16*)a.bias[d]); return; }
     if (bx == a.nbias) { pool_matrix_body(a.pw[d], a.M[d]); return; }
     if (!a.pack) return;
-    long e = (long)(bx - a.nbias - 1) * 256 + threadIdx.x;   // float4 index into the concatenated weights
     const long n4[4] = {768 * 256 / 4, 256 * 256 / 4, 1024 * 256 / 4, 256 * 1024 / 4};
+    if (bx >= a.nbias + 1 + PREP_WBLOCKS) {   // fragment-ordered copies: one thread per 8 weights
+        long it = (long)(bx - a.nbias - 1 - PREP_WBLOCKS) * 256 + threadIdx.x;
+        const int form = it >= PREP_WFLOATS / 8;
+        if (form) it -= PREP_WFLOATS / 8;
+        const int N[4] = {768, 256, 1024, 256}, K[4] = {256, 256, 256, 1024};
+        long o8 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (it >= o8 && it < o8 + n4[k] / 2)
+                pnl_pack_weight(a.w[d][k], N[k], K[k], form != 0, (f32x4*)(a.w_f[d] + (long)form * PREP_WFLOATS + o8 * 8), it - o8);
+            o8 += n4[k] / 2;
+        }
+        return;
+    }
+    long e = (long)(bx - a.nbias - 1) * 256 + threadIdx.x;   // float4 index into the concatenated weights
     long off = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
