@@ -170,7 +170,7 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def head_step(dev, b, steps=10):
+def head_step(dev, b, steps=10, multi=False, rank=0):
     """One training step of the WHOLE CFFM-B1 decode head (forward_train + backward: SegFormer embedding, linear_fuse, the hot
     path, both classifiers, resize + cross entropy; every row of SURVEY 8f in libcffm_hip.so) on b clips x 4 frames of 480x480
     backbone-shaped features: the context the hot-path headline sits in (`head_step` in the JSON line; not `value`)."""
@@ -182,8 +182,14 @@ def head_step(dev, b, steps=10):
                align_corners=False, decoder_params=dict(embed_dim=256, depths=DEPTH),
                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0), num_clips=4)
     torch.manual_seed(0)
-    head = revert_sync_batchnorm(V.build_head(cfg)).to(dev).train()     # one process: plain BatchNorm statistics
-    gen = torch.Generator().manual_seed(1)
+    head = V.build_head(cfg)
+    if not multi:
+        head = revert_sync_batchnorm(head)     # one process: plain BatchNorm statistics
+    head = head.to(dev).train()
+    params = [p for p in head.parameters() if p.requires_grad]
+    if multi:   # N > 1: SyncBatchNorm exchanges the batch statistics (cffm_head.py:61-66), the gradients are averaged after the backward
+        V.distributed.broadcast_parameters(head, 0)
+    gen = torch.Generator().manual_seed(1 + rank)
     feats = [torch.randn(b * T, c, 480 // s, 480 // s, generator=gen).to(dev).requires_grad_(True) for c, s in zip(chans, (4, 8, 16, 32))]
     labels = torch.randint(0, 124, (b, T, 1, 480, 480), generator=gen)
     labels[torch.rand(b, T, 1, 480, 480, generator=gen) < 0.05] = 255
@@ -196,6 +202,15 @@ def head_step(dev, b, steps=10):
             f.grad = None
         res = head.forward_train(feats, None, labels, None, b, T)
         res['loss_seg'].backward()
+        if multi:   # ONE all-reduce of all 2.33 M + 1.69 M head parameters' gradients (flattened copy: context number, not the headline)
+            gs = [p.grad for p in params if p.grad is not None]
+            flat = torch.cat([g_.reshape(-1) for g_ in gs])
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG if dist.get_backend() == 'nccl' else dist.ReduceOp.SUM)
+            if dist.get_backend() != 'nccl':
+                flat.div_(dist.get_world_size())
+            torch._foreach_copy_(gs, [t.view_as(g_) for t, g_ in zip(flat.split([g_.numel() for g_ in gs]), gs)])
+    from vss_cffm_amd import ops as _ops
+    hook_was, _ops.block_grad_hook = _ops.block_grad_hook, None      # (the hot-path bench's per-block reducer is not part of this step)
     for _ in range(3):
         step()
     times = []
@@ -210,7 +225,16 @@ def head_step(dev, b, steps=10):
     eager_ms = times[len(times) // 2]
     # the same step replayed from a HIP graph (launched eagerly it is as much host- as GPU-bound: ~150 launches from Python)
     graph_ms, graph_note = None, None
+    grads_in_sync = None
+    if multi:   # every rank holds the same averaged gradients (MIN == MAX over the ranks of per-tensor sums)
+        sums = torch.stack([p.grad.double().sum() for p in params if p.grad is not None] + [p.grad.double().abs().sum() for p in params if p.grad is not None])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        grads_in_sync = bool(torch.equal(lo, hi)) and bool(torch.isfinite(sums).all())
     try:
+        if multi:
+            raise RuntimeError('not attempted at N > 1 (SyncBatchNorm + gradient all-reduce inside the step)')
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -236,8 +260,11 @@ def head_step(dev, b, steps=10):
     except Exception as ex:   # noqa: BLE001  (information only: the eager number stands)
         graph_note = 'graph capture of the head step failed: %s' % str(ex).splitlines()[0][:160]
         torch.cuda.synchronize(dev)
+    _ops.block_grad_hook = hook_was
     ms = eager_ms if graph_ms is None else min(eager_ms, graph_ms)
-    out = {'ms_per_step': round(ms, 3), 'clips_per_s': round(b * 1e3 / ms, 1), 'clips': b,
+    world = dist.get_world_size() if multi else 1
+    out = {'ms_per_step': round(ms, 3), 'clips_per_s': round(world * b * 1e3 / ms, 1), 'clips': world * b, 'world': world,
+           'grads_in_sync': grads_in_sync, 'norm': 'SyncBatchNorm over the ranks' if multi else 'BatchNorm (one process)',
            'eager_ms': round(eager_ms, 3), 'graph_replay_ms': None if graph_ms is None else round(graph_ms, 3),
            'workload': 'whole CFFM-B1 decode head, forward_train + backward on %d clips x 4 frames of 480x480 features '
                        '(120/60/30/15 px), dropout 0.1, BatchNorm in train mode; median of %d, launched eagerly and replayed from '
@@ -425,22 +452,34 @@ def main():
                 lib.cffm_profile_collect(ms_buf, n_buf)
             red = V.distributed.BlockwiseReducer(single_rank_too=force1)
             upper = lp.flat[lp.per_block:] if DEPTH > 1 else lp.flat
-            if os.environ.get('CFFM_BENCH_GRAPH_COLLECTIVES') and dist.get_backend() == 'nccl':
-                # experiment: the whole step INCLUDING the RCCL all-reduces as ONE graph -- validated with a single
-                # rank only (no multi-GPU box in this round), hence not the default
-                g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, pool=ga.pool()):
-                    lp.forward()
-                    lp.backward(gy_last, DEPTH - 1, min(1, DEPTH - 1))
-                    works = [dist.all_reduce(upper, op=dist.ReduceOp.AVG, async_op=True)]
-                    if DEPTH > 1:
-                        lp.backward(gy_last, 0, 0)
-                        works.append(dist.all_reduce(lp.block_slice(0), op=dist.ReduceOp.AVG, async_op=True))
-                    for w_ in works:
-                        w_.wait()
-                    opt.step()
-                nonlocal_note.append('ONE graph per step with the RCCL all-reduces captured inside (CFFM_BENCH_GRAPH_COLLECTIVES)')
-                return g1.replay
+            if os.environ.get('CFFM_BENCH_GRAPH_COLLECTIVES', '1') != '0' and dist.get_backend() == 'nccl':
+                # default at N > 1: the whole step INCLUDING the RCCL all-reduces as ONE graph -- one graph launch
+                # instead of three + two host-issued collectives (~0.06 ms per step with one rank).  A capture that fails on ANY rank
+                # sends EVERY rank back to the three-graph form above: the ranks agree on the outcome with an (eager) all-reduce, so
+                # nobody replays a graph whose peers are missing.  CFFM_BENCH_GRAPH_COLLECTIVES=0 skips the attempt.
+                ok, g1 = 1, None
+                try:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, pool=ga.pool()):
+                        lp.forward()
+                        lp.backward(gy_last, DEPTH - 1, min(1, DEPTH - 1))
+                        works = [dist.all_reduce(upper, op=dist.ReduceOp.AVG, async_op=True)]
+                        if DEPTH > 1:
+                            lp.backward(gy_last, 0, 0)
+                            works.append(dist.all_reduce(lp.block_slice(0), op=dist.ReduceOp.AVG, async_op=True))
+                        for w_ in works:
+                            w_.wait()
+                        opt.step()
+                except Exception as e:   # noqa: BLE001
+                    ok = 0
+                    sys.stderr.write('bench.py: rank %d: capturing the collectives failed (%s); every rank falls back to three graphs\n' % (rank, str(e).splitlines()[0][:120] if str(e) else type(e).__name__))
+                    torch.cuda.synchronize(dev)
+                agree = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                if int(agree.item()) == 1:
+                    nonlocal_note.append('ONE graph per step with the RCCL all-reduces captured inside (every rank captured it; CFFM_BENCH_GRAPH_COLLECTIVES=0 selects three graphs + host-issued all-reduces)')
+                    return g1.replay
+                nonlocal_note.append('three graphs + host-issued all-reduces (the one-graph capture with RCCL inside failed on at least one rank)')
 
             def replay_step():
                 ga.replay()
@@ -602,6 +641,15 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the whole-head training step (context number): every rank runs it -- SyncBatchNorm and the gradient exchange are collectives
+    hs_all = None
+    if not args.no_head_step:
+        if reducer is not None:
+            reducer.remove()
+        try:
+            hs_all = head_step(dev, b, multi=multi and not os.environ.get('CFFM_BENCH_FORCE_DIST'), rank=rank)
+        except Exception as e:   # noqa: BLE001  (context only: never costs the headline)
+            hs_all = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
 
     if rank == 0:
         nw, hw = ((GRID + 6) // 7) ** 2, GRID * GRID
@@ -651,12 +699,7 @@ def main():
                                 if (use_graph and graph_events) else
                                 ('eager pass right after the timed graph replays' if use_graph else 'inside the timed region'))}
         rk = roofline_kernels(stages, b, nw, hw) if stages else None
-        hs = None
-        if world == 1 and not args.no_head_step:
-            try:
-                hs = head_step(dev, b)
-            except Exception as e:   # noqa: BLE001  (context only: never costs the headline)
-                hs = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
+        hs = hs_all
         out = {
             'metric': 'clips/sec (fwd+bwd) CFFM-B1 480x480 T=4 hot path (CFFA+CFM, decoder_focal depth 2)',
             'value': round(world * b * args.steps / dt, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,

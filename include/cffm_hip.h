@@ -132,7 +132,8 @@ int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, con
  * output -- proj (cffm_transformer.py:602), residual (:823), norm2 + Mlp (fc1, exact GELU, fc2: :10-26) + residual (:824).
  * Weights are passed in MFMA-fragment order (cffm_panel_pack_weight: form 0 = forward y = x W^T, form 1 = input gradient
  * dx = dy W; N*K floats each; inside a block k_param_prep makes these copies).  z2s / acts / dhs are written in "split-4"
- * storage ({bf16 hi x4, bf16 lo x4} per 4 floats: the operand format of the weight-gradient GEMMs).
+ * storage ({bf16 hi x4, bf16 lo x4} per 4 floats: the operand format of the weight-gradient GEMMs); acts may be NULL (not
+ * stored: inside a block the fc2 weight gradient re-applies bias + GELU to hraw while it stages its tiles).
  *   forward : x1 = xt + ao Wp^T + bp; z2 = LN(x1; g2, be2); hraw = z2 W1^T; act = gelu(hraw + b1); x2 = x1 + act W2^T + b2
  *   backward: dh = (dout W2) * gelu'(hraw + b1); dx1 = dout + LN'(dh W1); dao = dx1 Wp; dg2, dbe2, db1, db2 = colsum(dout),
  *             dbp = colsum(dx1) (every one fully written)                                                                   */
@@ -357,8 +358,9 @@ typedef struct {
     int n;              /* 1..CFFM_ADAMW_CHUNK elements */
     int row;            /* row of consts / sched / state */
 } cffm_adamw_chunk2;
+/* active_rows (device, [nrows] ints, or NULL = every row): only rows that own a chunk of this call advance their step count */
 int cffm_adamw_step_rows(const cffm_adamw_chunk2* chunks /* device */, int nchunks, const float* grad_base, float* state,
-                         const float* sched, const double* consts, int nrows, void* stream);
+                         const float* sched, const double* consts, int nrows, const int* active_rows, void* stream);
 
 #ifdef __cplusplus
 }

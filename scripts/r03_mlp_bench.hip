@@ -30,7 +30,7 @@ static void unsplit(const std::vector<float>& s, std::vector<double>& out) {   /
 struct Err { double e = 0, r = 0; void add(double got, double ref) { e = fmax(e, fabs(got - ref)); r = fmax(r, fabs(ref)); } double rel() const { return e / (r > 0 ? r : 1); } };
 
 template <int MT, int D>
-static void run(int NP, bool check, int HW) {
+static void run(int NP, bool check, int HW, bool with_act = true) {
     const int B = (NP + HW - 1) / HW;
     std::vector<float> ao((size_t)NP * 256), xt((size_t)B * 4 * HW * 256), wp(256 * 256), w1(1024 * 256), w2(256 * 1024), bp(256), b1(1024), b2(256), g2(256), be2(256), dout((size_t)NP * 256);
     for (auto& v : ao) v = frand(); for (auto& v : xt) v = frand() * 1.5f; for (auto& v : dout) v = frand();
@@ -44,7 +44,7 @@ static void run(int NP, bool check, int HW) {
     f.wp = pack(d_wp, 256, 256, 0); f.w1 = pack(d_w1, 1024, 256, 0); f.w2 = pack(d_w2, 256, 1024, 0);
     f.bp = d_bp; f.b1 = d_b1; f.b2 = d_b2; f.g2 = d_g2; f.be2 = d_be2;
     f.x1 = devz<float>((size_t)NP * 256); f.z2s = devz<float>((size_t)NP * 256); f.mean2 = devz<float>(NP); f.rstd2 = devz<float>(NP);
-    f.hraw = devz<float>((size_t)NP * 1024); f.acts = devz<float>((size_t)NP * 1024); f.x2 = devz<float>((size_t)NP * 256); f.NP = NP;
+    f.hraw = devz<float>((size_t)NP * 1024); f.acts = devz<float>((size_t)NP * 1024); float* acts_keep = f.acts; if (!with_act) f.acts = nullptr; f.x2 = devz<float>((size_t)NP * 256); f.NP = NP;
     MlpBwdArgs b;
     b.dout = d_dout; b.hraw = f.hraw; b.b1 = d_b1; b.x1 = f.x1; b.mean2 = f.mean2; b.rstd2 = f.rstd2; b.g2 = d_g2;
     b.w2n = pack(d_w2, 256, 1024, 1); b.w1n = pack(d_w1, 1024, 256, 1); b.wpn = pack(d_wp, 256, 256, 1);
@@ -61,7 +61,7 @@ static void run(int NP, bool check, int HW) {
         auto x1 = host(f.x1, (size_t)NP * 256), x2 = host(f.x2, (size_t)NP * 256), hraw = host(f.hraw, (size_t)NP * 1024), mean = host(f.mean2, NP), rstd = host(f.rstd2, NP);
         auto dx1 = host(b.dx1, (size_t)NP * 256), dao = host(b.dao, (size_t)NP * 256), rb1 = host(b.rec_b1, (size_t)grid * 1024), rln = host(b.rec_ln, (size_t)grid * 1024);
         std::vector<double> z2, act, dh;
-        unsplit(host(f.z2s, (size_t)NP * 256), z2); unsplit(host(f.acts, (size_t)NP * 1024), act); unsplit(host(b.dhs, (size_t)NP * 1024), dh);
+        unsplit(host(f.z2s, (size_t)NP * 256), z2); unsplit(host(acts_keep, (size_t)NP * 1024), act); unsplit(host(b.dhs, (size_t)NP * 1024), dh);
         Err ex1, ez2, eh, ea, ex2, emu, ers, edh, edx1, edao, eb1, eg, ebt, ec2, ecp;
         std::vector<double> sb1(1024, 0), sg(256, 0), sbt(256, 0), sc2(256, 0), scp(256, 0);
         for (int m = 0; m < NP; ++m) {
@@ -98,11 +98,22 @@ static void run(int NP, bool check, int HW) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int R = 30;
         float msf, msb;
+        // rotating output buffers (8 sets, > the 256 MiB Infinity Cache): a step of the real layer never rewrites a warm buffer
+        const int NROT = 8;
+        float *rh[NROT], *ra[NROT], *rx1[NROT], *rz[NROT], *rx2[NROT];
+        for (int q = 0; q < NROT; ++q) { rh[q] = devz<float>((size_t)NP * 1024); ra[q] = devz<float>((size_t)NP * 1024); rx1[q] = devz<float>((size_t)NP * 256); rz[q] = devz<float>((size_t)NP * 256); rx2[q] = devz<float>((size_t)NP * 256); }
         for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_THREADS), lds, 0, f);
         CK(hipEventRecord(e0, 0)); for (int i = 0; i < R; ++i) hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_THREADS), lds, 0, f); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msf, e0, e1));
+        {
+            float msr;
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < R; ++i) { MlpFwdArgs fr = f; const int q = i % NROT; fr.hraw = rh[q]; fr.acts = with_act ? ra[q] : nullptr; fr.x1 = rx1[q]; fr.z2s = rz[q]; fr.x2 = rx2[q]; hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_THREADS), lds, 0, fr); }
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msr, e0, e1));
+            printf("   k_mlp_fwd with rotating output buffers: %.2f us\n", msr * 1e3 / R);
+        }
         for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kb, dim3(grid), dim3(PNL_THREADS), lds, 0, b);
         CK(hipEventRecord(e0, 0)); for (int i = 0; i < R; ++i) hipLaunchKernelGGL(kb, dim3(grid), dim3(PNL_THREADS), lds, 0, b); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msb, e0, e1));
-        printf("MT=%d D=%d NP=%d grid=%d: k_mlp_fwd %.2f us   k_mlp_bwd %.2f us\n", MT, D, NP, grid, msf * 1e3 / R, msb * 1e3 / R);
+        printf("MT=%d D=%d NP=%d grid=%d act-store=%d: k_mlp_fwd %.2f us   k_mlp_bwd %.2f us\n", MT, D, NP, grid, (int)with_act, msf * 1e3 / R, msb * 1e3 / R);
     }
 }
 
@@ -110,9 +121,11 @@ int main(int argc, char** argv) {
     srand(2);
     const bool quick = argc > 1;     // any argument: only the checks
     printf("PNL_ABLATE=%d\n", PNL_ABLATE);
-    if (!PNL_ABLATE) { run<2, 4>(500, true, 170); run<3, 4>(500, true, 170); }
+    if (!PNL_ABLATE) { run<2, 4>(500, true, 170); run<2, 2>(777, true, 300); }
     if (quick) return 0;
-    run<2, 4>(7200, false, 3600);
-    run<3, 4>(7200, false, 3600);
+    run<2, 4>(7200, false, 3600, true);
+    run<2, 4>(7200, false, 3600, false);
+    run<2, 2>(7200, false, 3600, false);
+    run<2, 8>(7200, false, 3600, false);
     return 0;
 }

@@ -5,7 +5,8 @@ with stand-ins for the absent mmcv/timm: oracle/ref_import.py) on 1 clip x 4 fra
 (120 / 60 / 30 / 15 px).  The full tensors are large (train logits 5 x 124 x 120 x 120), so the fixture keeps a stride-4
 spatial sample plus sum / abs-sum / square-sum of each tensor, the loss / accuracy of `losses()` on seeded 480x480 labels
 and the same statistics of the feature gradients.  Run in the build container only (about a minute of CPU):
-python tests/golden/make_golden_head_b1.py"""
+python tests/golden/make_golden_head_b1.py          (head_b1_480.npz)
+python tests/golden/make_golden_head_b1.py c4       (head_b1_512_b2.npz: BASELINE config 4, 512x512, 2 clips, stride-8 sample)"""
 import os
 import sys
 
@@ -34,33 +35,41 @@ def sample(t, stride=STRIDE):
 DFEAT_STRIDE = (4, 4, 2, 1)
 
 
-def main():
+# BASELINE config 4 ("CFFM-B2 512x512, batch 2 per GPU": same C = 256 / depths 2 head, grid 64x64 -> padded 70x70): the second fixture
+SIZE_C4, BATCH_C4, STRIDE_C4 = 512, 2, 8
+DFEAT_STRIDE_C4 = (16, 8, 4, 2)
+
+
+def main(size=SIZE, batch=1, stride=STRIDE, dstride=DFEAT_STRIDE, out_name='head_b1_480.npz', seeds=(70, 71, 72)):
     torch.manual_seed(0)
     d = {}
     head = RI.build_reference_head(in_channels=B1, depths=2)
     head.dropout.p = 0.0                      # train mode deterministic (the reference cannot be built with ratio 0)
-    res = head.load_state_dict(R.synth_state(head, seed=70), strict=False)
+    res = head.load_state_dict(R.synth_state(head, seed=seeds[0]), strict=False)
     assert not res.unexpected_keys
-    feats = feature_maps(1, 4, SIZE, chans=B1, seed=71)
+    feats = feature_maps(batch, 4, size, chans=B1, seed=seeds[1])
     head.eval()
     with torch.no_grad():
-        y = head(feats, 1, 4)                                                          # [1,124,120,120]
-    d['eval_logits_s4'], d['eval_logits_stats'] = sample(y), stats(y)
+        y = head(feats, batch, 4)                                                      # [B,124,size/4,size/4]
+    d['eval_logits_s4'], d['eval_logits_stats'] = sample(y, stride), stats(y)
     head.train()
     fg = [f.clone().requires_grad_(True) for f in feats]
-    out = head(fg, 1, 4)                                                               # [1,5,124,120,120]
-    d['train_logits_s4'], d['train_logits_stats'] = sample(out.detach()), stats(out.detach())
-    loss = head.losses(out, labels(1, 4, SIZE, seed=72))
+    out = head(fg, batch, 4)                                                           # [B,5,124,size/4,size/4]
+    d['train_logits_s4'], d['train_logits_stats'] = sample(out.detach(), stride), stats(out.detach())
+    loss = head.losses(out, labels(batch, 4, size, seed=seeds[2]))
     d['loss_seg'] = loss['loss_seg'].detach().numpy()
     d['acc_seg'] = loss['acc_seg'].detach().numpy()
     loss['loss_seg'].backward()
     for i, f in enumerate(fg):
-        d['dfeat%d_s' % i] = sample(f.grad, DFEAT_STRIDE[i])
+        d['dfeat%d_s' % i] = sample(f.grad, dstride[i])
         d['dfeat%d_stats' % i] = stats(f.grad)
-    np.savez_compressed(os.path.join(OUT, 'head_b1_480.npz'), **d)
+    np.savez_compressed(os.path.join(OUT, out_name), **d)
     for k, v in d.items():
         print(k, v.shape, float(np.abs(v).max()))
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'c4':
+        main(SIZE_C4, BATCH_C4, STRIDE_C4, DFEAT_STRIDE_C4, 'head_b1_512_b2.npz', (80, 81, 82))
+    else:
+        main()

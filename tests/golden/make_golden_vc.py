@@ -41,6 +41,16 @@ def vc_cases():
     return out
 
 
+def vc_large_case():
+    """one larger video (many workgroups per frame pair in k_vc_counts): 40 frames of 120 x 160, 124 classes"""
+    rs = np.random.RandomState(12)
+    f, h, w = 40, 120, 160
+    base = rs.randint(0, 124, size=(h, w))
+    gt = np.stack([np.where(rs.rand(h, w) < 0.02 * t, rs.randint(0, 124, size=(h, w)), base) for t in range(f)]).astype(np.int64)
+    pred = np.where(rs.rand(f, h, w) < 0.1, rs.randint(0, 124, size=(f, h, w)), gt).astype(np.int64)
+    return 'large', gt, pred
+
+
 CLIP_NUMS = (1, 2, 8, 16)    # VC_8 / VC_16 are the reference's two calls (VC_perclip.py:128-129)
 
 
@@ -52,6 +62,10 @@ def main():
         for n in CLIP_NUMS + (f, f + 3):
             with np.errstate(invalid='ignore', divide='ignore'):
                 d['%s/%d' % (name, n)] = np.asarray(get_common(list(gt), list(pred), n, h, w), dtype=np.float64)
+    name, gt, pred = vc_large_case()
+    for n in (8, 16):
+        with np.errstate(invalid='ignore', divide='ignore'):
+            d['%s/%d' % (name, n)] = np.asarray(get_common(list(gt), list(pred), n, gt.shape[1], gt.shape[2]), dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, 'vc_counts.npz'), **d)
     for k, v in d.items():
         print(k, v.shape, float(np.nanmean(v)) if v.size else None)

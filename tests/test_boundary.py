@@ -133,34 +133,36 @@ def _stats(t):
     return np.array([float(t.sum()), float(t.abs().sum()), float(t.square().sum()), float(t.abs().max())])
 
 
-def run_head_b1_480_golden(device):
+def run_head_b1_480_golden(device, fixture='head_b1_480', size=None, batch=1, stride=None, dstride=None, seeds=(70, 71, 72)):
     """BASELINE cfg2 / cfg3 at full size: the CFFM-B1 head on 1 clip x 4 frames of 480x480-shaped features against what the
     REFERENCE head produced (tests/golden/head_b1_480.npz, make_golden_head_b1.py): eval logits, train logits
     [1,5,124,120,120], loss_seg / acc_seg of losses() on 480x480 labels, feature gradients.  Tolerance: the north star's
     1e-3 (max|a-b| / max|b|) on logits; statistics (sum of squares, abs-sum) to 1e-3 relative."""
     from tests.golden.make_golden_head import feature_maps, labels
-    from tests.golden.make_golden_head_b1 import B1 as CH, DFEAT_STRIDE, SIZE, STRIDE
-    g = H.load_golden('head_b1_480')
+    from tests.golden import make_golden_head_b1 as G
+    CH = G.B1
+    SIZE, STRIDE, DFEAT_STRIDE = size or G.SIZE, stride or G.STRIDE, dstride or G.DFEAT_STRIDE
+    g = H.load_golden(fixture)
     tol = 1e-3
     m = build_head(RI.head_cfg(in_channels=CH, depths=2))
-    assert not m.load_state_dict(R.synth_state(m, seed=70), strict=False).unexpected_keys
+    assert not m.load_state_dict(R.synth_state(m, seed=seeds[0]), strict=False).unexpected_keys
     m.dropout.p = 0.0
     if device.type == 'cpu':
         Hd.revert_sync_batchnorm(m)
     m.to(device)
-    feats = [f.to(device) for f in feature_maps(1, 4, SIZE, chans=CH, seed=71)]
+    feats = [f.to(device) for f in feature_maps(batch, 4, SIZE, chans=CH, seed=seeds[1])]
     m.eval()
     with torch.no_grad():
-        y = m(feats, 1, 4)
-    assert y.shape == (1, 124, SIZE // 4, SIZE // 4)
+        y = m(feats, batch, 4)
+    assert y.shape == (batch, 124, SIZE // 4, SIZE // 4)
     assert H.rel_err(y[..., ::STRIDE, ::STRIDE].cpu(), g['eval_logits_s4']) < tol
     np.testing.assert_allclose(_stats(y)[1:3], g['eval_logits_stats'][1:3], rtol=tol)
     m.train()
     fg = [f.clone().requires_grad_(True) for f in feats]
-    out = m(fg, 1, 4)
+    out = m(fg, batch, 4)
     assert H.rel_err(out.detach()[..., ::STRIDE, ::STRIDE].cpu(), g['train_logits_s4']) < tol
     np.testing.assert_allclose(_stats(out)[1:3], g['train_logits_stats'][1:3], rtol=tol)
-    loss = m.losses(out, labels(1, 4, SIZE, seed=72).to(device))
+    loss = m.losses(out, labels(batch, 4, SIZE, seed=seeds[2]).to(device))
     assert abs(float(loss['loss_seg']) - float(g['loss_seg'])) < 1e-3 * float(g['loss_seg'])
     assert abs(float(loss['acc_seg']) - float(g['acc_seg'])) < 1e-3
     loss['loss_seg'].backward()
@@ -177,6 +179,14 @@ def run_head_b1_480_golden(device):
 @pytest.mark.gpu
 def test_head_b1_480_against_reference_golden_gpu():
     run_head_b1_480_golden(torch.device('cuda:0'))
+
+
+@pytest.mark.gpu
+def test_head_config4_512x512_batch2_against_reference_golden_gpu():
+    """BASELINE config 4 at head level: 2 clips x 4 frames of 512x512-shaped features (grid 64x64, padded 70x70,
+    nW = 100) against the reference head's outputs, loss, accuracy and feature gradients (tests/golden/head_b1_512_b2.npz)."""
+    from tests.golden import make_golden_head_b1 as G
+    run_head_b1_480_golden(torch.device('cuda:0'), 'head_b1_512_b2', G.SIZE_C4, G.BATCH_C4, G.STRIDE_C4, G.DFEAT_STRIDE_C4, (80, 81, 82))
 
 
 def test_head_against_reference_golden_emulated():

@@ -200,3 +200,125 @@ def test_blockwise_overlapped_allreduce_world_size_4_gloo(tmp_path):
             assert torch.equal(gs[0][k], gs[r][k]), k
             assert torch.equal(ps[0][k], ps[r][k]), k
         assert H.rel_err(gs[0][k], sum(pr[k] for pr in per_rank) / world) < 1e-5, k
+
+
+def _worker_blockwise_preexisting(rank, world, port, out):
+    """with .grad already set (zero_grad(set_to_none=False) / accumulation) autograd ADDS the backward's views into the
+    old tensors, so the slices the reducer exchanged are not the gradients: finish(params) must notice and exchange the real ones."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CFFM_EMU_THREADS='2')
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tests import emu
+    import vss_cffm_amd as V
+    with emu.active():
+        m = _layer()
+        V.distributed.broadcast_parameters(m, 0)
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)            # what optimizer.zero_grad(set_to_none=False) leaves behind
+        red = V.distributed.BlockwiseReducer().install()
+        try:
+            x, g = _clip(rank)
+            (m(x)[:, -1] * g).sum().backward()
+            params = list(m.parameters())
+            with pytest.raises(RuntimeError):
+                V.distributed.BlockwiseReducer.finish(_Replay(red), params, on_mismatch='raise')
+            assert red.finish(params) == 1 and red.fallbacks == 1
+        finally:
+            red.remove()
+    torch.save({k: p.grad.clone() for k, p in m.named_parameters()}, os.path.join(out, 'pgrad%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _Replay:
+    """a reducer whose pending list is a copy: lets the 'raise' policy be exercised without consuming the real exchanges"""
+
+    def __init__(self, red):
+        self.pending, self.average = list(red.pending), red.average
+
+    def __setattr__(self, k, v):
+        object.__setattr__(self, k, v)
+
+
+@pytest.mark.timeout(600)
+def test_blockwise_reducer_with_preexisting_grads_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker_blockwise_preexisting, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (torch.load(os.path.join(str(tmp_path), 'pgrad%d.pt' % r)) for r in range(world))
+    from tests import emu, helpers as H
+    per_rank = []
+    with emu.active():
+        for r in range(world):
+            m = _layer()
+            x, g = _clip(r)
+            (m(x)[:, -1] * g).sum().backward()
+            per_rank.append({k: p.grad for k, p in m.named_parameters()})
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+        assert H.rel_err(g0[k], (per_rank[0][k] + per_rank[1][k]) / world) < 1e-5, k
+
+
+def _bn_case(rank_or_all, world):
+    """[N,256,8,6] maps, channels-last, of rank r (or of all ranks concatenated), with the upstream gradients."""
+    gen = torch.Generator().manual_seed(77)
+    y = torch.randn(2 * world, 256, 8, 6, generator=gen) * 1.3 + 0.2
+    df = torch.randn(2 * world, 256, 8, 6, generator=gen)
+    ds = torch.randn(2 * world, 12, 256, generator=gen)
+    if rank_or_all is None:
+        return y, df, ds
+    sl = slice(2 * rank_or_all, 2 * rank_or_all + 2)
+    return y[sl], df[sl], ds[sl]
+
+
+def _worker_syncbn(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CFFM_EMU_THREADS='2')
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tests import emu
+    from vss_cffm_amd import ops
+    with emu.active():
+        bn = torch.nn.SyncBatchNorm(256)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, 256))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, 256))
+        bn.train()
+        y, df, ds = _bn_case(rank, world)
+        yd = y.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        fused, stack = ops.bn_relu_pool(yd, bn)
+        ((fused * df).sum() + (stack * ds).sum()).backward()
+    torch.save(dict(fused=fused.detach(), stack=stack.detach(), dy=yd.grad, dw=bn.weight.grad, db=bn.bias.grad, rm=bn.running_mean,
+                    rv=bn.running_var, nbt=bn.num_batches_tracked), os.path.join(out, 'bn%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_syncbn_rows_path_world_size_2_gloo(tmp_path):
+    """ops.bn_relu_pool with nn.SyncBatchNorm over two ranks (cffm_head.py:61-66 norm_cfg SyncBN) == single-process BatchNorm over
+    the concatenated batch: outputs, input gradients, running buffers; the parameter gradients are the per-rank shares (DDP sums /
+    averages them itself), so their SUM over the ranks is the single-process gradient."""
+    world = 2
+    mp.spawn(_worker_syncbn, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), 'bn%d.pt' % r)) for r in range(world)]
+    import torch.nn.functional as F
+    from tests import helpers as H
+    y, df, ds = _bn_case(None, world)
+    bn = torch.nn.BatchNorm2d(256).double()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 256))
+        bn.bias.copy_(torch.linspace(-0.2, 0.2, 256))
+    bn.train()
+    yr = y.double().requires_grad_(True)
+    fused = F.relu(bn(yr))
+    stack = F.avg_pool2d(fused, 2).flatten(2).transpose(1, 2)
+    ((fused * df.double()).sum() + (stack * ds.double()).sum()).backward()
+    for r in range(world):
+        sl = slice(2 * r, 2 * r + 2)
+        assert H.rel_err(res[r]['fused'], fused[sl].detach()) < 1e-5 and H.rel_err(res[r]['stack'], stack[sl].detach()) < 1e-5
+        assert H.rel_err(res[r]['dy'], yr.grad[sl]) < 2e-5
+        assert H.rel_err(res[r]['rm'], bn.running_mean) < 1e-5 and H.rel_err(res[r]['rv'], bn.running_var) < 1e-5
+        assert int(res[r]['nbt']) == 1
+    assert H.rel_err(res[0]['dw'] + res[1]['dw'], bn.weight.grad) < 2e-5
+    assert H.rel_err(res[0]['db'] + res[1]['db'], bn.bias.grad) < 2e-5

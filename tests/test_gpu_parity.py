@@ -117,10 +117,26 @@ def test_config4_512x512_batch2():
     y = m(xg)
     (y[:, -1] * gy.to(dev())).sum().backward()
     xo = x.clone().requires_grad_(True)
-    yo = O.layer_forward(xo, st, depth)
+    st_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in st.items()}
+    yo = O.layer_forward(xo, st_o, depth)
     (yo[:, -1] * gy).sum().backward()
     assert H.rel_err(y[:, -1], yo[:, -1]) < FWD_TOL
     assert H.rel_err(xg.grad, xo.grad) < BWD_TOL
+    # every parameter gradient at this size too (only y and dx were checked here); the scalar pool biases and the 4 / 9
+    # pooling weights of the strided reference frames are judged as in tests/helpers.py::check_layer_backward
+    worst = ('', 0.0)
+    for name, p in m.named_parameters():
+        ref = st_o[name].grad
+        assert ref is not None and p.grad is not None, name
+        if p.numel() == 1:
+            sib = st_o.get(name.replace('.bias', '.weight'))
+            err = H.scalar_grad_err(p.grad, ref.numpy(), None if sib is None or sib.grad is None else sib.grad.numpy())
+        else:
+            err = H.rel_err(p.grad, ref)
+        lim = 2 * BWD_TOL if ('pool_layers_clips' in name and p.numel() <= 9) else BWD_TOL
+        worst = max(worst, (name, err / lim * BWD_TOL), key=lambda t: t[1])
+        assert err < lim, '%s rel err %.3e >= %.1e' % (name, err, lim)
+    print('config4 worst parameter gradient', worst)
 
 
 def test_config5_gtc_8_prototypes_full_size():

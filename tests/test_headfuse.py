@@ -82,9 +82,23 @@ def run_bn_relu_pool(device, n=2, h=6, w=10):
         ops.bn_relu_pool(torch.zeros(1, 256, 5, 4, device=device), bn)              # odd side: the resize is not a 2x2 average
 
 
+def run_bn_momentum_none(device):
+    """BatchNorm(momentum=None): torch keeps a CUMULATIVE moving average (factor 1 / num_batches_tracked) -- ADVICE r2."""
+    gen = torch.Generator().manual_seed(5)
+    bn, ref = torch.nn.BatchNorm2d(256, momentum=None), torch.nn.BatchNorm2d(256, momentum=None)
+    bn.to(device).train(); ref.train()
+    for _ in range(3):
+        y = torch.randn(2, 4, 6, 256, generator=gen) * 1.5 + 0.1
+        ops.bn_relu_pool(y.to(device).permute(0, 3, 1, 2), bn)
+        ref(y.permute(0, 3, 1, 2).contiguous())
+    assert int(bn.num_batches_tracked) == 3
+    assert H.rel_err(bn.running_mean.cpu(), ref.running_mean) < 1e-5 and H.rel_err(bn.running_var.cpu(), ref.running_var) < 1e-5
+
+
 def test_bn_relu_pool_emulated():
     with emu.active():
         run_bn_relu_pool(torch.device('cpu'))
+        run_bn_momentum_none(torch.device('cpu'))
 
 
 @pytest.mark.gpu

@@ -252,8 +252,39 @@ def test_adamw_skips_params_without_grad_and_rejects_cpu():
             V.optim.AdamW([a]).step()
 
 
+def run_adamw_intermittent(device):
+    """a parameter that gets a gradient only in some steps keeps torch's per-parameter step count (bias correction, and
+    with the device-side schedule its iteration): the row's count advances only in the steps in which the row owns a chunk.
+    Both parameters join at step 1 (one row); the second then skips steps -- and gets its own row the first time the counts differ."""
+    gen = torch.Generator().manual_seed(9)
+    a0, b0 = torch.randn(300, generator=gen), torch.randn(70, generator=gen)
+    a, b = torch.nn.Parameter(a0.clone().to(device)), torch.nn.Parameter(b0.clone().to(device))
+    ra, rb = torch.nn.Parameter(a0.clone().double()), torch.nn.Parameter(b0.clone().double())
+    opt = V.optim.AdamW([a, b], lr=1e-2, weight_decay=0.01)
+    ref = torch.optim.AdamW([ra, rb], lr=1e-2, weight_decay=0.01)
+    for step in range(8):
+        ga, gb = torch.randn(300, generator=gen), torch.randn(70, generator=gen)
+        a.grad, ra.grad = ga.to(device), ga.double()
+        if step in (0, 3, 6):
+            b.grad, rb.grad = gb.to(device), gb.double()
+        else:
+            b.grad, rb.grad = None, None
+        opt.step()
+        ref.step()
+    assert float((a.detach().cpu().double() - ra.detach()).abs().max()) < 1e-5
+    assert float((b.detach().cpu().double() - rb.detach()).abs().max()) < 1e-5
+    sd = opt.state_dict()['state']
+    assert int(sd[0]['step']) == 8 and int(sd[1]['step']) == 3
+
+
+def test_adamw_intermittent_gradients_emulated():
+    with emu.active():
+        run_adamw_intermittent(torch.device('cpu'))
+
+
 @pytest.mark.gpu
 def test_adamw_gpu():
+    run_adamw_intermittent(torch.device('cuda:0'))
     run_adamw(torch.device('cuda:0'), steps=6)
     run_adamw_shared_buffer(torch.device('cuda:0'), steps=6)
     run_adamw_resume(torch.device('cuda:0'))

@@ -108,7 +108,7 @@ SIGNATURES = {
     'cffm_upce_maps_bwd': (ci, [vp, vp, vp, vp, vp, vp, C.c_float, vp, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, ci, ci, vp]),
     'cffm_adamw_step': (ci, [vp, ci, cd, cd, cd, cd, cd, ci, vp]),
     'cffm_adamw_step_dev': (ci, [vp, ci, vp, cd, cd, cd, cd, cd, vp, vp]),
-    'cffm_adamw_step_rows': (ci, [vp, ci, vp, vp, vp, vp, ci, vp]),
+    'cffm_adamw_step_rows': (ci, [vp, ci, vp, vp, vp, vp, ci, vp, vp]),
 }
 
 

@@ -23,7 +23,7 @@ def extract_state_dict(checkpoint):
     return out
 
 
-def load_reference_checkpoint(module, checkpoint, prefix='decode_head.', strict=False, map_location='cpu'):
+def load_reference_checkpoint(module, checkpoint, prefix='decode_head.', strict=False, map_location='cpu', trusted=False):
     """Load a reference (mmcv-format) checkpoint into `module` -- one of this package's decode heads by default.
 
     checkpoint: a path (``torch.load``-ed to `map_location`) or an already loaded dict.
@@ -32,11 +32,18 @@ def load_reference_checkpoint(module, checkpoint, prefix='decode_head.', strict=
         are taken as they are.
     strict=False mirrors mmcv's ``load_checkpoint``: keys that are missing / unexpected / of a different shape are reported,
     not raised.  Returns ``(missing_keys, unexpected_keys, meta)``; `meta` is the checkpoint's ``meta`` dict (CLASSES, PALETTE,
-    config text) or ``{}``."""
+    config text) or ``{}``.
+    trusted: a checkpoint FILE is read with ``torch.load(weights_only=True)``.  mmcv metas may hold python objects that the safe
+        unpickler refuses; only ``trusted=True`` (the caller vouches for the file: unpickling runs arbitrary code) retries with
+        ``weights_only=False`` -- and only after an unpickling error, never to mask a missing / corrupt file."""
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, '__fspath__'):
+        import pickle
         try:
             checkpoint = torch.load(checkpoint, map_location=map_location, weights_only=True)
-        except Exception:   # noqa: BLE001  (mmcv metas may hold non-tensor python objects)
+        except pickle.UnpicklingError as e:
+            if not trusted:
+                raise pickle.UnpicklingError('%s\n(the checkpoint holds objects the safe loader refuses; pass trusted=True to '
+                                             'load_reference_checkpoint if the file comes from a source you trust)' % e) from e
             checkpoint = torch.load(checkpoint, map_location=map_location, weights_only=False)
     sd = extract_state_dict(checkpoint)
     meta = checkpoint.get('meta', {}) if isinstance(checkpoint, dict) and isinstance(checkpoint.get('meta'), dict) else {}

@@ -314,6 +314,10 @@ struct SideStream {
 #ifndef CFFM_EMU
     hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[2] = {nullptr, nullptr}, order = nullptr;
+    // deferred join of a block backward (layer_backward_impl): what the NEXT block has to wait for
+    hipEvent_t dw_done = nullptr, bias_done = nullptr, tail_done[2] = {nullptr, nullptr}, join_all[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool bias_pending = false, tail_pending[2] = {false, false};
+    unsigned used = 0;          // side streams forked since the last full join
 #endif
 };
 static SideStream g_side;
@@ -346,6 +350,10 @@ static bool side_init(hipStream_t main) {
             bool ok = hipEventCreateWithFlags(&g_side.order, hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.tail_done[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_side.join_all[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&g_side.dw_done, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&g_side.bias_done, hipEventDisableTiming) == hipSuccess;
             state = ok ? 1 : 0;
         }
         (void)hipGetLastError();
@@ -374,9 +382,12 @@ static int dw_one_group(hipStream_t st) {
 }
 static hipStream_t side_fork(hipStream_t main, int i) {
 #ifndef CFFM_EMU
-    hipStream_t s = g_side.st[g_side.ns >= 4 ? (i & 3) : (g_side.ns > 1 ? (i & 1) : 0)];
-    if (g_side.on && hipEventRecord(g_side.fork[i], main) == hipSuccess && hipStreamWaitEvent(s, g_side.fork[i], 0) == hipSuccess)
+    const int idx = g_side.ns >= 4 ? (i & 3) : (g_side.ns > 1 ? (i & 1) : 0);
+    hipStream_t s = g_side.st[idx];
+    if (g_side.on && hipEventRecord(g_side.fork[i], main) == hipSuccess && hipStreamWaitEvent(s, g_side.fork[i], 0) == hipSuccess) {
+        g_side.used |= 1u << idx;
         return s;
+    }
     (void)hipGetLastError();
 #endif
     (void)i;
@@ -402,6 +413,38 @@ static void side_join(hipStream_t side, hipStream_t main, int i) {   // `main` c
     (void)side; (void)main; (void)i;
 }
 
+// `main` continues after everything issued on any side stream since the last full join
+static void side_join_all(hipStream_t main) {
+#ifndef CFFM_EMU
+    for (int i = 0; i < 4; ++i)
+        if ((g_side.used >> i) & 1u) {
+            if (hipEventRecord(g_side.join_all[i], g_side.st[i]) == hipSuccess) (void)hipStreamWaitEvent(main, g_side.join_all[i], 0);
+        }
+    g_side.used = 0;
+    g_side.bias_pending = g_side.tail_pending[0] = g_side.tail_pending[1] = false;
+    (void)hipGetLastError();
+#endif
+    (void)main;
+}
+// event helpers of the deferred join (no-ops when the work ran on `main` itself)
+static void side_record(hipStream_t side, hipStream_t main, void* ev) {
+#ifndef CFFM_EMU
+    if (side != main) (void)hipEventRecord((hipEvent_t)ev, side);
+#endif
+    (void)side; (void)main; (void)ev;
+}
+static void side_wait(hipStream_t main, void* ev) {
+#ifndef CFFM_EMU
+    (void)hipStreamWaitEvent(main, (hipEvent_t)ev, 0);
+#endif
+    (void)main; (void)ev;
+}
+#ifndef CFFM_EMU
+static void dw_group_launched(hipStream_t side) { (void)hipEventRecord(g_side.dw_done, side); }
+#else
+static void dw_group_launched(hipStream_t) {}
+#endif
+
 static void seg_add(RedSegs& r, int off, int width, float* out, int accumulate) {
     if (!out) return;
     const int k = r.nseg++;
@@ -409,8 +452,13 @@ static void seg_add(RedSegs& r, int off, int width, float* out, int accumulate) 
 }
 // Deferred second stages: inside a block backward (RedScope) the reductions are queued -- each with its own slice of a
 // library-owned record buffer -- and run as ONE launch at the end of the scope; outside a scope they launch at once.
-static float* g_red = nullptr;
-static size_t g_red_floats = 0;
+// Two record buffers, used alternately by consecutive scopes (block backwards): the reduction of block i (side stream) may still
+// read its records while block i - 1 already writes its own (deferred join, see block_backward_impl)
+static float* g_redbuf[2] = {nullptr, nullptr};
+static size_t g_red_floats_[2] = {0, 0};
+static int g_red_parity = 0;
+#define g_red g_redbuf[g_red_parity]
+#define g_red_floats g_red_floats_[g_red_parity]
 static struct { bool active; size_t bump; RedJobs jobs; } g_rq = {false, 0, {}};
 static void redq_flush(hipStream_t st) {
     RedJobs& J = g_rq.jobs;
@@ -423,7 +471,7 @@ static void redq_flush(hipStream_t st) {
 }
 struct RedScope {
     hipStream_t st;
-    explicit RedScope(hipStream_t s) : st(s) { g_rq.active = true; g_rq.bump = 0; g_rq.jobs.njob = 0; }
+    explicit RedScope(hipStream_t s) : st(s) { g_red_parity ^= 1; g_rq.active = true; g_rq.bump = 0; g_rq.jobs.njob = 0; }
     void finish() { redq_flush(st); g_rq.active = false; }
     void finish_on(hipStream_t other) { redq_flush(other); g_rq.active = false; }
     ~RedScope() { g_rq.active = false; g_rq.jobs.njob = 0; }
@@ -864,12 +912,12 @@ int cffm_adamw_step_dev(const cffm_adamw_chunk* chunks, int nchunks, const float
 }
 
 int cffm_adamw_step_rows(const cffm_adamw_chunk2* chunks, int nchunks, const float* grad_base, float* state, const float* sched,
-                         const double* consts, int nrows, void* stream) {
+                         const double* consts, int nrows, const int* active_rows, void* stream) {
     static_assert(sizeof(cffm_adamw_chunk2) == sizeof(AdamwChunk2), "chunk layout");
     if (nchunks <= 0) return 0;
     REQUIRE(chunks && state && sched && consts && nrows >= 1, "adamw_step_rows: null table or no rows");
     PROF(ST_ADAMW);
-    CFFM_LAUNCH(k_adamw_tick_rows, ((unsigned)((nrows + 63) / 64)), (64), 0, (hipStream_t)stream, state, sched, consts, nrows);
+    CFFM_LAUNCH(k_adamw_tick_rows, ((unsigned)((nrows + 63) / 64)), (64), 0, (hipStream_t)stream, state, sched, consts, nrows, active_rows);
     CFFM_LAUNCH(k_adamw_rows, ((unsigned)nchunks), (256), 0, (hipStream_t)stream, (const AdamwChunk2*)chunks, grad_base, (const float*)state, consts);
     CHECK_LAUNCH("adamw_rows");
     return 0;
@@ -908,6 +956,13 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
 
 // ------------------------------------------------------------------------------------------- fused row-panel stages
 // CFFM_PANEL=0 keeps the round-2 sequence of tiled GEMMs + row kernels (A/B measurements)
+// CFFM_STORE_ACT=1: the fused forward also stores gelu(hraw + b1) (split-4) and the fc2 weight gradient reads it, instead of
+// re-applying bias + GELU to hraw while it stages its tiles (A/B measurements)
+static int store_act() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFFM_STORE_ACT"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
 static int panel_on() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("CFFM_PANEL"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -941,7 +996,7 @@ int cffm_mlp_fwd(const float* ao, const float* xt, long xt_bs, int rows_per_batc
                  float* rstd2, float* hraw, float* acts, float* x2, long NP, void* stream) {
     REQUIRE(NP >= 0 && NP < (1L << 21) && rows_per_batch >= 1, "mlp_fwd: bad sizes");
     if (!NP) return 0;
-    REQUIRE(ao && xt && wp_f && w1_f && w2_f && bp && b1 && b2 && g2 && be2 && x1 && z2s && mean2 && rstd2 && hraw && acts && x2, "mlp_fwd: null");
+    REQUIRE(ao && xt && wp_f && w1_f && w2_f && bp && b1 && b2 && g2 && be2 && x1 && z2s && mean2 && rstd2 && hraw && x2, "mlp_fwd: null");   // (acts may be NULL: not stored)
     REQUIRE(!mlp_lds_grant(), "mlp_fwd: LDS grant failed");
     PROF2(ST_MLP_FWD);
     MlpFwdArgs a;
@@ -1052,7 +1107,8 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
         PROF(ST_GEMM);
         TRY(cffm_mlp_fwd(ws + L.ao, x_tgt, tgt_bs, g->HW, wf + 768 * 256, wf + 768 * 256 + 256 * 256, wf + 768 * 256 + 256 * 256 + 1024 * 256,
                          p->proj_b, p->fc1_b, p->fc2_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2, ws + L.mean2, ws + L.rstd2, ws + L.hraw,
-                         ws + L.act, ws + L.x2, NP, stream));
+                         store_act() ? ws + L.act : nullptr /* default: act is not stored, the fc2 weight gradient re-applies bias + GELU to hraw */,
+                         ws + L.x2, NP, stream));
         CHECK_LAUNCH("block_forward");
         return 0;
     }
@@ -1083,11 +1139,32 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     return 0;
 }
 
+static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
+                               const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
+                               const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
+                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, void* stream);
 int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                         const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
                         const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
                         float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, void* stream) {
+    return block_backward_impl(g, p, gr, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_ref, dref_bs, accum_ref,
+                               dx_tgt, dtgt_bs, scratch, 0, stream);
+}
+// `defer` (layer backward, round 3): the call returns with this block's parameter-gradient tail (partial-slab sums, record reductions,
+// pooling-matrix backward, bias-table scatter) still running on the side streams; the caller's stream has only waited for what reads
+// the scratch operands the NEXT block overwrites (the weight-gradient GEMMs).  The next block_backward_impl waits for the rest where
+// it needs it; the caller ends the sequence with side_join_all().  (Measured on the round-3 timeline: the chain idled ~32 us per
+// block between ln_pool_bwd and the next block's first kernel, behind four small side kernels.)
+static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
+                               const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
+                               const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
+                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, void* stream) {
     REQUIRE(g && p && gr && ws && dout && scratch, "block_backward: null");
+    {
+        static int defer_env = -1;   // CFFM_DEFER_JOIN=0: every block ends fully joined (round-2 behaviour; A/B measurements)
+        if (defer_env < 0) { const char* e = getenv("CFFM_DEFER_JOIN"); defer_env = (e && e[0] == '0') ? 0 : 1; }
+        defer = defer && defer_env;
+    }
     cffm_block_ws L;
     cffm_block_ws_layout(g, &L);
     const Scratch S = scratch_layout(g);
@@ -1104,6 +1181,12 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     hipStream_t st = (hipStream_t)stream;
     hipStream_t sa = st;
     side_init(st);
+#ifndef CFFM_EMU
+    if (g_side.tail_pending[g_red_parity]) {    // the reduction that last read this scope's record buffer (two blocks ago)
+        side_wait(st, g_side.tail_done[g_red_parity]);
+        g_side.tail_pending[g_red_parity] = false;
+    }
+#endif
     const int sp = gemm_use_lib() ? 0 : 1;   // see block_forward_impl: zall / z2 / act / weights (and dh below) in split-4 storage
     const int one_group = sp ? dw_one_group(st) : 0;
     if (sp && !one_group) {
@@ -1139,8 +1222,8 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
         if (!one_group) {
             sa = side_fork(st, 0);
             void* stream_a = (void*)sa;
-            const cffm_wgrad wga[2] = {{dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C}, {dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}};
-            const GemmTNPre prea[2] = {{1, 1}, {0, 1}};
+            const cffm_wgrad wga[2] = {{dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C}, {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}};
+            const GemmTNPre prea[2] = {{1, 1, nullptr}, {0, (panel && !store_act()) ? 2 : 1, p->fc1_b}};
             {
                 void* stream = stream_a;
                 PROF2(ST_G_DW);
@@ -1164,8 +1247,8 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
         if (!one_group) {
         sa = side_fork(st, 0);
         void* stream_a = (void*)sa;
-        const cffm_wgrad wga[2] = {{dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C}, {dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}};
-        const GemmTNPre prea[2] = {{1, 1}, {0, 1}};
+        const cffm_wgrad wga[2] = {{dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C}, {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}};
+        const GemmTNPre prea[2] = {{1, 1, nullptr}, {0, (panel && !store_act()) ? 2 : 1, p->fc1_b}};
         {
             void* stream = stream_a;
             PROF2(ST_G_DW);
@@ -1193,6 +1276,12 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
         PROF(ST_ATTN_BWD);
         float* dbp;
         int ng;
+#ifndef CFFM_EMU
+        if (g_side.bias_pending) {   // the previous block's bias-gradient tile sum still owns the tile buffer / dbiasT
+            side_wait(st, g_side.bias_done);
+            g_side.bias_pending = false;
+        }
+#endif
         TRY(attn_bwd_fused(g, ws + L.qkv, key_src, q_dst, (const h16*)(ws + L.bias), ws + L.ao, dao, ws + L.lse, dqkv, scratch + S.dkvp, &dbp, &ng, stream));
         s1 = sp ? side_fork(st, 1) : st;
         TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, (void*)s1));
@@ -1209,20 +1298,20 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
             // where two groups of two take 2 x 53), on the side stream beside q|k|v's input gradient and the CFFA backward; every
             // operand lives until the end of the block now that ln_pool_bwd no longer writes over `dout`
             const cffm_wgrad wg4[4] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C}, {dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C},
-                                       {dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}, {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
-            const GemmTNPre pre4[4] = {{0, 1}, {1, 1}, {0, 1}, {0, 0}};
+                                       {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}, {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
+            const GemmTNPre pre4[4] = {{0, 1, nullptr}, {1, 1, nullptr}, {0, (panel && !store_act()) ? 2 : 1, p->fc1_b}, {0, 0, nullptr}};
             void* stream = stream_b;
             PROF(ST_GEMM); PROF2(ST_G_DW);
-            REQUIRE(!gemm_tn_group((const GemmTN*)wg4, 4, sb, pre4, sb == st ? lib_scratch : lib_scratch2, 480), "block_backward: weight-gradient gemm failed");
+            REQUIRE(!gemm_tn_group((const GemmTN*)wg4, 4, sb, pre4, sb == st ? lib_scratch : lib_scratch2, 480, dw_group_launched), "block_backward: weight-gradient gemm failed");
             sa = sb;
             side_mark(sa, st, 0);
         } else {
         const cffm_wgrad wgb[2] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C}, {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
-        const GemmTNPre preb[2] = {{0, 1}, {0, 0}};
+        const GemmTNPre preb[2] = {{0, 1, nullptr}, {0, 0, nullptr}};
         {
             void* stream = stream_b;
             PROF(ST_GEMM); PROF2(ST_G_DW);
-            REQUIRE(!gemm_tn_group((const GemmTN*)wgb, 2, sb, preb, sb == st ? lib_scratch : lib_scratch2, 320), "block_backward: weight-gradient gemm failed");
+            REQUIRE(!gemm_tn_group((const GemmTN*)wgb, 2, sb, preb, sb == st ? lib_scratch : lib_scratch2, 320, dw_group_launched), "block_backward: weight-gradient gemm failed");
         }
         }
     } else {
@@ -1233,7 +1322,7 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     if (!sp) {
         const cffm_wgrad wg[4] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C},
                                   {dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C},
-                                  {dout, ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID},
+                                  {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID},
                                   {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
         TRY(cffm_linear_bwd_weight_group(wg, 4, stream));
     }
@@ -1249,6 +1338,17 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
     reductions.finish_on(s3);
     CHECK_LAUNCH("block_backward reductions");
     TRY(cffm_pool_matrix_bwd(dM, gr->pool_w, (void*)s3));
+#ifndef CFFM_EMU
+    if (defer && sp && sb != st && s3 != st) {
+        side_wait(st, g_side.dw_done);                  // the weight-gradient GEMMs have read dqkv / dh / dout / dx1 and the saved activations
+        side_record(s1, st, g_side.bias_done);
+        g_side.bias_pending = s1 != st;
+        side_record(s3, st, g_side.tail_done[g_red_parity]);
+        g_side.tail_pending[g_red_parity] = true;
+        return 0;
+    }
+#endif
+    (void)defer;
     side_mark(s3, st, 1);
     side_join(s3, st, 1);    // the caller's stream owns every gradient (and the scratch operands) again
     if (sp && sb != st && sb != s3) { side_mark(sb, st, 0); side_join(sb, st, 0); }   // ... on both side streams
@@ -1659,9 +1759,10 @@ int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_par
         const long dtgt_bs = (i == 0) ? 4 * img : img;
         // the last block reads the caller's gradient directly
         const float* dout = (i == depth - 1) ? dy_rows : scratch + (((depth - 1 - i) & 1) ? S.a2 : S.a);
-        TRY(cffm_block_backward(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_rows,
-                                4 * img, i != depth - 1, dtgt, dtgt_bs, scratch, stream));
+        TRY(block_backward_impl(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_rows,
+                                4 * img, i != depth - 1, dtgt, dtgt_bs, scratch, 1, stream));
     }
+    side_join_all((hipStream_t)stream);
     return 0;
 }
 
@@ -1690,6 +1791,9 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
     side_mark(sd, st, 0);
     TRY(cffm_transpose(x_nchw, xs, g->B * 4, CFFM_C, (int)HW, img, img, stream));
     side_join(sd, st, 0);
+#ifndef CFFM_EMU
+    g_side.used = 0;   // (that was this call's only side branch, joined here)
+#endif
     for (int i = 0; i < depth; ++i) {
         float* ws = blk0 + (long)i * L.total;
         const float* tgt = (i == 0) ? xs + 3 * img : blk0 + (long)(i - 1) * L.total + L.x2;
@@ -1744,11 +1848,12 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
         float* dcur = scratch + (((depth - 1 - i) & 1) ? S.a2 : S.a);
         float* dtgt = (i == 0) ? dxs + 3 * img : scratch + (((depth - i) & 1) ? S.a2 : S.a);
         const long dtgt_bs = (i == 0) ? 4 * img : img;
-        TRY(cffm_block_backward(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dcur, dxs, 4 * img,
-                                i != depth - 1, dtgt, dtgt_bs, scratch, stream));
+        TRY(block_backward_impl(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dcur, dxs, 4 * img,
+                                i != depth - 1, dtgt, dtgt_bs, scratch, 1, stream));
     }
     // (dy_full: the upstream gradient of the whole [B,4,C,H,W] output -- its pass-through frames 0..2 join dx in the same pass)
     if (last_block == 0) TRY(transpose_add(dxs, dx_nchw, g->B * 4, (int)HW, CFFM_C, img, img, dy_full, 4, 3, stream));
+    side_join_all((hipStream_t)stream);   // every parameter gradient of the range is complete behind this point of the stream
     return 0;
 }
 int cffm_layer_backward_range(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,

@@ -126,7 +126,7 @@ static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int
 
 // ---- grouped weight gradients: dw_p[N_p,K_p] = dy_p[M_p,N_p]^T x_p[M_p,K_p], p < n <= 4, one launch (k_gemm_group_tt) --------
 struct GemmTN { const float* dy; const float* x; float* dw; long M; int N, K; };
-struct GemmTNPre { int dy_pre, x_pre; };   // operand in split-4 storage
+struct GemmTNPre { int dy_pre, x_pre; const float* x_bias; };   // operand in split-4 storage (1); x_pre == 2: x = gelu(stored + x_bias) on load
 // `scratch_fn`: where the split-K partial slabs live (default: the library scratch of the caller's stream; a group issued on the
 // side stream of the block backward passes the side scratch -- the two run concurrently); `target_wgs`: workgroups to aim for
 // floats of split-K partial slabs a grouped launch of these problems asks its scratch for (same arithmetic as below)
@@ -148,11 +148,15 @@ static size_t gemm_tn_group_partial_floats(const GemmTN* pr, int n, int target_w
     }
     return part;
 }
+// `after_gemm`: called with the stream right behind the GEMM launch(es), before the partial-slab sum (the block backward records
+// an event there: from that point on the operands may be overwritten)
 static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const GemmTNPre* pre = nullptr,
-                               float* (*scratch_fn)(size_t) = lib_scratch, int target_wgs = 0) {
+                               float* (*scratch_fn)(size_t) = lib_scratch, int target_wgs = 0, void (*after_gemm)(hipStream_t) = nullptr) {
     bool groupable = n >= 1 && n <= GEMM_GROUP_MAX;
     for (int p = 0; p < n && groupable; ++p) groupable = pr[p].N % 128 == 0 && pr[p].K % 128 == 0 && pr[p].M >= 32;
     if (!groupable) {
+        for (int p = 0; p < n; ++p)
+            if (pre && pre[p].x_pre == 2) return -1;   // the on-load GELU exists in the grouped kernel only
         for (int p = 0; p < n; ++p) {
             const int a = pre ? pre[p].dy_pre : 0, b = pre ? pre[p].x_pre : 0;
             int rc;
@@ -162,6 +166,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
             else rc = gemm_tn_split<false, false>(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st);
             if (rc) return -1;
         }
+        if (after_gemm) after_gemm(st);
         return 0;
     }
     // one slice length for every problem: ~480 workgroups (two per CU are co-resident: 80 KB of LDS each)
@@ -186,7 +191,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
     int wg = 0, blk = 0, nsum = 0;
     for (int p = 0; p < n; ++p) {
         G.A[p] = pr[p].dy; G.B[p] = pr[p].x;
-        G.a_pre[p] = pre ? pre[p].dy_pre : 0; G.b_pre[p] = pre ? pre[p].x_pre : 0;
+        G.a_pre[p] = pre ? pre[p].dy_pre : 0; G.b_pre[p] = pre ? pre[p].x_pre : 0; G.b_bias[p] = pre ? pre[p].x_bias : nullptr;
         G.M[p] = pr[p].N; G.N[p] = pr[p].K; G.K[p] = (int)pr[p].M;
         G.C[p] = pr[p].dw;
         if (ksplit[p] > 1) {
@@ -200,7 +205,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
         wg += (pr[p].N / 128) * (pr[p].K / 128) * ksplit[p];
         G.wg_end[p] = wg;
     }
-    for (int p = n; p < GEMM_GROUP_MAX; ++p) { G.A[p] = G.B[p] = nullptr; G.C[p] = nullptr; G.M[p] = G.N[p] = 128; G.K[p] = 0; G.wg_end[p] = wg; G.a_pre[p] = G.b_pre[p] = 0; }
+    for (int p = n; p < GEMM_GROUP_MAX; ++p) { G.A[p] = G.B[p] = nullptr; G.C[p] = nullptr; G.M[p] = G.N[p] = 128; G.K[p] = 0; G.wg_end[p] = wg; G.a_pre[p] = G.b_pre[p] = 0; G.b_bias[p] = nullptr; }
     G.klen = klen; G.n = n;
 #ifndef CFFM_EMU
     static bool granted = false;
@@ -211,6 +216,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
     }
 #endif
     CFFM_LAUNCH(k_gemm_group_tt, ((unsigned)wg), (256), GEMM_LDS(128, 128, 32), st, G);
+    if (after_gemm) after_gemm(st);
     if (nsum) {
         Sg.cnt = nsum;
         for (int q = nsum; q < 4; ++q) { Sg.part[q] = nullptr; Sg.out[q] = nullptr; Sg.n[q] = 0; Sg.nsplit[q] = 0; Sg.blk_end[q] = blk; }
@@ -320,8 +326,8 @@ static int gemm_tn(const float* dy, const float* x, float* dw, long M, int N, in
     return gemm_use_lib() ? gemm_tn_lib(dy, x, dw, M, N, K, st) : gemm_tn_split<>(dy, x, dw, M, N, K, st);
 }
 static int gemm_tn_group(const GemmTN* pr, int n, hipStream_t st, const GemmTNPre* pre = nullptr, float* (*scratch_fn)(size_t) = lib_scratch,
-                         int target_wgs = 0) {
-    if (!gemm_use_lib()) return gemm_tn_group_split(pr, n, st, pre, scratch_fn, target_wgs);
+                         int target_wgs = 0, void (*after_gemm)(hipStream_t) = nullptr) {
+    if (!gemm_use_lib()) return gemm_tn_group_split(pr, n, st, pre, scratch_fn, target_wgs, after_gemm);
     if (pre) return -1;
     for (int p = 0; p < n; ++p)
         if (gemm_tn_lib(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st)) return -1;

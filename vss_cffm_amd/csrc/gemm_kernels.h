@@ -145,9 +145,12 @@ __device__ __forceinline__ uint32_t pack_bf16(bf16 a, bf16 b) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // registers -> LDS (split into hi / lo bf16 images)
+// `pre`: 0 plain fp32 (split here) | 1 the registers hold split-4 data: no arithmetic | 2 (row-contiguous operands only) the operand
+// is gelu(stored + bias): the weight gradient of fc2 reads the saved fc1 product `hraw` and re-applies bias + GELU while it stages the
+// tile, so the forward never writes the activation (29.5 MB per block at CFFM-B1 size) -- bit-identical to what it would have stored
 template <int ROWS, bool TR, int BK>
 __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __restrict__ hi, bf16* __restrict__ lo, int tid,
-                                           bool pre = false /* the registers hold split-4 data: no arithmetic */) {
+                                           int pre = 0, f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}) {
     if (!TR) {
 #pragma unroll
         for (int it = 0; it < ROWS * BK / 1024; ++it) {
@@ -168,8 +171,12 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& r, bf16* __
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 bf16x4 hh, ll;
-                if (pre) unsplit4(r.v[2 * it + h], hh, ll);
-                else split4(r.v[2 * it + h], hh, ll);
+                if (pre == 1) unsplit4(r.v[2 * it + h], hh, ll);
+                else if (pre == 2) {
+                    f32x4 a;
+                    for (int e = 0; e < 4; ++e) a[e] = gelu_erf(r.v[2 * it + h][e] + bias4[e]);
+                    split4(a, hh, ll);
+                } else split4(r.v[2 * it + h], hh, ll);
                 const int o = (row >> 4) * GEMM_TSUB + GEMM_TPOS(2 * kp + h) * 16 + (row & 15);
                 *(bf16x4*)(hi + o) = hh;
                 *(bf16x4*)(lo + o) = ll;
@@ -230,13 +237,16 @@ template <int BM, int BN, int BK, bool A_T, bool B_T, int EPI, int PF>
 __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                           int M, int N, int K, int lda, int ldb, int ldc, int klen, long split_stride,
                                           const float* __restrict__ bias, float* __restrict__ aux, int bx, int by, int bz,
-                                          bool a_pre = false, bool b_pre = false, float* __restrict__ aux2 = nullptr) {
+                                          bool a_pre = false, int b_pre = 0, float* __restrict__ aux2 = nullptr,
+                                          const float* __restrict__ b_bias = nullptr /* b_pre == 2: bias of the on-load GELU */) {
     bf16* Ah = (bf16*)smem;
     bf16* Al = Ah + GEMM_IMG(BM, BK);
     bf16* Bh = Al + GEMM_IMG(BM, BK);
     bf16* Bl = Bh + GEMM_IMG(BN, BK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int n0 = bx * BN, m0 = by * BM;
+    f32x4 bb4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (B_T && b_pre == 2) bb4 = *(const f32x4*)(b_bias + n0 + 4 * (tid % (BN / 4)));   // this thread's four operand rows are fixed
     const int kbeg = bz * klen, kend = (kbeg + klen < K) ? kbeg + klen : K;
     constexpr int MT = BM / 32, NT = BN / 32;  // 16x16 tiles per wave along M and N (wave tile = BM/2 x BN/2)
     const int wr = (wave >> 1) * (BM / 2), wc = (wave & 1) * (BN / 2);
@@ -258,7 +268,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
     tile_load<BM, A_T, BK>(ra[0], A, lda, m0, M, kbeg, kend, tid);
     tile_load<BN, B_T, BK>(rb[0], B, ldb, n0, N, kbeg, kend, tid);
     tile_store<BM, A_T, BK>(ra[0], Ah, Al, tid, a_pre);
-    tile_store<BN, B_T, BK>(rb[0], Bh, Bl, tid, b_pre);
+    tile_store<BN, B_T, BK>(rb[0], Bh, Bl, tid, b_pre, bb4);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {   // tile 1+u -> register set u (past kend -> zeros, never used)
         tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + (1 + u) * BK, kend, tid);
@@ -299,7 +309,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                     }
                 }
                 tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid, a_pre);
-                tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid, b_pre);
+                tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid, b_pre, bb4);
                 tile_load_fast<BM, A_T, BK>(ra[u], rsa, va, sa0 + (t + 1 + PF) * dsa, lda4);
                 tile_load_fast<BN, B_T, BK>(rb[u], rsb, vb, sb0 + (t + 1 + PF) * dsb, ldb4);
                 GEMM_INTERLEAVE(3 * MT * NT);
@@ -336,7 +346,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                 }
                 if (t + 1 < NKT && !(GEMM_ABLATE & 2)) {
                     tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid, a_pre);
-                    tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid, b_pre);
+                    tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid, b_pre, bb4);
                 }
                 if (t + 1 + PF < NKT && !(GEMM_ABLATE & 1)) {
                     tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + (t + 1 + PF) * BK, kend, tid);
@@ -446,7 +456,8 @@ struct GemmGroup {
     int M[GEMM_GROUP_MAX], N[GEMM_GROUP_MAX], K[GEMM_GROUP_MAX];
     int wg_end[GEMM_GROUP_MAX];        // exclusive prefix of workgroups per problem (after XCD re-numbering)
     int klen, n;
-    int a_pre[GEMM_GROUP_MAX], b_pre[GEMM_GROUP_MAX];   // operand already in split-4 storage
+    int a_pre[GEMM_GROUP_MAX], b_pre[GEMM_GROUP_MAX];   // operand already in split-4 storage (1); B only: 2 = gelu(stored + b_bias) on load
+    const float* b_bias[GEMM_GROUP_MAX];
 };
 __global__ void __launch_bounds__(256) k_gemm_group_tt(GemmGroup G) {
     CFFM_DYN_SMEM(smem);
@@ -457,5 +468,5 @@ __global__ void __launch_bounds__(256) k_gemm_group_tt(GemmGroup G) {
     if (p > 0) lin -= G.wg_end[p - 1];
     const int M = G.M[p], N = G.N[p], ntn = N / 128, ntm = M / 128;
     gemm_tile<128, 128, 32, true, true, 0, GROUP_PF>(smem, G.A[p], G.B[p], G.C[p], M, N, G.K[p], M, N, N, G.klen, (long)M * N, nullptr,
-                                              nullptr, lin % ntn, (lin / ntn) % ntm, lin / (ntn * ntm), G.a_pre[p] != 0, G.b_pre[p] != 0);
+                                              nullptr, lin % ntn, (lin / ntn) % ntm, lin / (ntn * ntm), G.a_pre[p] != 0, G.b_pre[p], nullptr, G.b_bias[p]);
 }

@@ -126,11 +126,16 @@ __device__ __forceinline__ void pnl_pin_vmem() {
 #endif
 }
 // Invariant at entry: the ring holds steps 0 .. D-2 of this chunk (slot = step % D); at exit: steps 0 .. D-2 of what follows.
-template <int MT, int NTW, int NT, int D>
+// `extra(sc)`: the caller's own memory traffic of step sc (deferred epilogue stores, operand prefetches), issued at the step's pinned
+// VMEM point.  Why: a CU's vector-memory path is one in-order queue -- a burst of epilogue stores (64 KiB per workgroup and chunk in the
+// fused forward) that drains at the HBM write rate (~6.5 B/clk per CU with every CU storing) holds up the B-fragment loads queued behind
+// it, and the matrix pipe idles: measured 44.6 us for the fused forward with the stores in bursts vs 24.4 us without any store.
+struct PnlNoExtra { __device__ __forceinline__ void operator()(int) const {} };
+template <int MT, int NTW, int NT, int D, class Extra = PnlNoExtra>
 __device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT, D>& ring, const bf16* __restrict__ Ahi,
                                               const bf16* __restrict__ Alo, const PnlStream& st, int jt0, int ks0, int l15, int g,
                                               // where the stream goes after this chunk (its first D-1 steps are prefetched from here)
-                                              const PnlStream& nst, int njt0, int nks0) {
+                                              const PnlStream& nst, int njt0, int nks0, const Extra& extra = Extra()) {
     constexpr int NPASS = NTW / NT, SC = NPASS * 8;
     static_assert(NTW % NT == 0 && SC % D == 0 && D <= SC && D >= 2, "ring depth must divide the steps of a chunk");
     bf16x8 ah[2][MT], al[2][MT];
@@ -149,6 +154,7 @@ __device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT,
             for (int j = 0; j < NT; ++j) { asm volatile("" : "+v"(ring.v[slot_n][j][0]), "+v"(ring.v[slot_n][j][1])); }
         } else if (sn < SC) pnl_ring_load<NT, D>(ring, slot_n, st, jt0 + (sn / 8) * NT, ks0 + sn % 8);
         else pnl_ring_load<NT, D>(ring, slot_n, nst, njt0 + ((sn - SC) / 8) * NT, nks0 + (sn - SC) % 8);
+        extra(sc);
         pnl_pin_vmem();
         if (sc + 1 < SC) {
             const int k8n = (sc + 1) % 8;
@@ -259,6 +265,7 @@ __device__ __forceinline__ float pnl_sum_g(float v) {
     return v;
 }
 #define PNL_ST(v) ((v) && !(PNL_ABLATE & 4))
+#define PNL_STORE4(p, v) (*(f32x4*)(p) = (v))
 #define PNL_FUSED_LDS(MT) (6 * PNL_IMG(MT) * 2 + 2 * PNL_WAVES * 16 * (MT) * 4)   // P + 2 x ACT (hi | lo each) + reduction scratch
 
 struct MlpFwdArgs {
@@ -266,7 +273,7 @@ struct MlpFwdArgs {
     const float* xt; long xt_bs; int rows_per_batch;   // residual input: row m = xt + (m / rpb) * xt_bs + (m % rpb) * 256
     const f32x4 *wp, *w1, *w2;          // fragment-ordered weights, NT form (pnl_pack_weight)
     const float *bp, *b1, *b2, *g2, *be2;
-    float *x1, *z2s /* split-4 */, *mean2, *rstd2, *hraw, *acts /* split-4 */, *x2;
+    float *x1, *z2s /* split-4 */, *mean2, *rstd2, *hraw, *acts /* split-4, or NULL: not stored (the fc2 weight gradient re-applies bias + GELU to hraw) */, *x2;
     int NP;
 };
 
@@ -402,7 +409,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
                 pnl_img_put(Ah, Ah + PNL_IMG(MT), 16 * i + l15, nl, h, l);
                 if (PNL_ST(valid[i])) {
                     *(f32x4*)(a.hraw + mrow[i] * 1024 + n) = raw;
-                    *(f32x4*)(a.acts + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
+                    if (a.acts) *(f32x4*)(a.acts + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
                 }
             }
         }
@@ -476,6 +483,13 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < MT; ++i) da[t][i] = z4;
+        // the saved fc1 product of this chunk is requested before the chunk's first product and consumed behind it
+        f32x4 hr[2][MT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) hr[t][i] = valid[i] ? *(const f32x4*)(a.hraw + mrow[i] * 1024 + 256 * c + 32 * wave + 16 * t + 4 * g) : z4;
+        pnl_pin_vmem();
         pnl_chunk_mma<MT, 2, 2, D>(da, ring, P, P + PNL_IMG(MT), s2, 16 * c + 2 * wave, 0, l15, g, s1, 2 * wave, 8 * c);
         bf16* Ah = DH + (c & 1) * 2 * PNL_IMG(MT);
 #pragma unroll
@@ -487,8 +501,8 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
             for (int i = 0; i < MT; ++i) {
                 f32x4 dh = z4;
                 if (valid[i]) {
-                    const f32x4 hr = *(const f32x4*)(a.hraw + mrow[i] * 1024 + n) + bv;
-                    for (int e = 0; e < 4; ++e) dh[e] = da[t][i][e] * gelu_erf_grad(hr[e]);
+                    const f32x4 hv = hr[t][i] + bv;
+                    for (int e = 0; e < 4; ++e) dh[e] = da[t][i][e] * gelu_erf_grad(hv[e]);
                 }
                 bf16x4 h, l;
                 split4(dh, h, l);

@@ -564,9 +564,13 @@ __global__ void __launch_bounds__(256) k_adamw_dev(const AdamwChunk* __restrict_
 // unless the caller orders it); kind 0 takes lr_t = the mirror's value.
 #define ADAMW_NCONST 12
 struct AdamwChunk2 { float* p; const float* g; float* m; float* v; int n; int row; };
-__global__ void k_adamw_tick_rows(float* __restrict__ state, const float* __restrict__ sched, const double* __restrict__ consts, int nrows) {
+// `active` (or NULL = every row): rows that own a chunk of THIS step's table.  A row whose parameters got no gradient this step keeps
+// its step count -- torch's per-parameter step does not advance either -- so its bias correction and schedule iteration stay right
+// when it next takes part (a parameter with gradients on 3 of 8 steps was off by 3.8e-2 when every row ticked).
+__global__ void k_adamw_tick_rows(float* __restrict__ state, const float* __restrict__ sched, const double* __restrict__ consts, int nrows,
+                                  const int* __restrict__ active) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
+    if (r >= nrows || (active && !active[r])) return;
     const double* c = consts + (long)ADAMW_NCONST * r;
     const double t = (double)state[4 * r] + 1.0, wd = (double)sched[2 * r + 1];
     double lr = (double)sched[2 * r];

@@ -1,11 +1,13 @@
 """Data-parallel glue for the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm).
 
 The reference trains under MMDistributedDataParallel (mmseg/apis/train.py:57-65): parameters broadcast from rank 0 once,
-gradients averaged over the ranks every step.  `_LayerFn.backward` produces every parameter gradient of the layer in ONE
-buffer (the .grad tensors are views of it), so the exchange step is ONE all-reduce of that buffer -- no per-parameter
-reducer hooks, no 52 copies into a bucket, no gradient-ready bookkeeping -- issued right after backward (the layer's
-backward is a single autograd node: there is nothing to overlap it with).  Clips shard over the ranks; the forward /
-backward kernels themselves have no collective.
+gradients averaged over the ranks every step, the exchange overlapped with the backward pass by the bucketed reducer.
+`_LayerFn.backward` produces every parameter gradient of the layer in ONE buffer laid out block by block (the .grad tensors
+are views of it) and runs the blocks last-to-first, so the exchange here is one all-reduce PER BLOCK, started as soon as that
+block's kernels are enqueued and travelling over xGMI while the previous block's backward runs (`BlockwiseReducer`) -- no
+per-parameter reducer hooks, no 52 copies into a bucket, no gradient-ready bookkeeping.  `allreduce_gradients` is the
+one-collective form (after the backward).  Clips shard over the ranks; the forward / backward kernels themselves have no
+collective.
 """
 import torch
 import torch.distributed as dist
@@ -127,13 +129,31 @@ class BlockwiseReducer:
         work = dist.all_reduce(flat_slice, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
         self.pending.append((work, flat_slice, self.average and not avg))
 
-    def finish(self):
-        """Wait (stream-side for RCCL) for every exchange started since the last call; returns how many there were."""
+    def finish(self, params=None, on_mismatch='fallback'):
+        """Wait (stream-side for RCCL) for every exchange started since the last call; returns how many there were.
+
+        The slices that were exchanged are pieces of the backward's own flat buffer.  They ARE the parameters' gradients only when
+        autograd adopted them as ``.grad`` -- i.e. when ``.grad`` was None before the backward (``zero_grad(set_to_none=True)``, the
+        torch default).  With pre-existing gradients (``set_to_none=False``, gradient accumulation) autograd ADDS the views into
+        the old ``.grad`` tensors instead, and the averaged buffer is one nobody reads.  Pass the parameters to have that checked:
+        every ``.grad`` must lie inside an exchanged slice; otherwise ``on_mismatch='fallback'`` exchanges the real ``.grad``
+        tensors now (`allreduce_gradients`: correct, not overlapped), ``'raise'`` raises."""
         n = len(self.pending)
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        spans = []
         for work, t, divide in self.pending:
             work.wait()
             if divide:
                 t.div_(world)
+            spans.append((t.data_ptr(), t.data_ptr() + 4 * t.numel()))
         self.pending = []
+        if params is not None and n:
+            stray = [p for p in params if p.grad is not None and
+                     not any(lo <= p.grad.data_ptr() and p.grad.data_ptr() + 4 * p.grad.numel() <= hi for lo, hi in spans)]
+            if stray:
+                if on_mismatch == 'raise':
+                    raise RuntimeError('BlockwiseReducer: %d gradients do not alias the exchanged buffer (the parameters had .grad set '
+                                       'before the backward: use zero_grad(set_to_none=True))' % len(stray))
+                self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+                allreduce_gradients(stray, average=self.average)
         return n

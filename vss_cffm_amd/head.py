@@ -7,9 +7,11 @@ contract and state_dict keys, around the MI355X hot path.
 * ``BaseDecodeHead_clips_flow``                     <- decode_head.py:513-835 (ctor contract, losses)
 * ``CrossEntropyLoss`` / ``accuracy``               <- losses/cross_entropy_loss.py:141, losses/accuracy.py:4
 
-``decoder_focal`` / ``decoder_swin`` (the hot path) and the SegFormer embedding in front of them (``_fuse``: SURVEY 8f.1,
-``ops.segformer_fuse``) run in libcffm_hip.so; BatchNorm, the 1x1 classifiers, the remaining resizes and the losses are
-stock PyTorch (SURVEY 8f "next").
+For GPU tensors the whole head runs in libcffm_hip.so on token rows (``rows_impl='hip'``): the SegFormer embedding
+(``ops.segformer_fuse``), ``linear_fuse``'s BatchNorm + ReLU + the 1/4 -> 1/8 resize (``ops.bn_relu_pool``), ``decoder_focal`` /
+``decoder_swin`` (the hot path), the 1x1 classifiers (``ops.conv1x1``), the 1/8 -> 1/4 resize of the clip-level logits
+(``ops.rows_resize``) and resize + cross entropy + accuracy (``ops.head_cross_entropy``); ``rows_impl='torch'``, CPU tensors and
+non-default loss settings take the reference's op sequence in stock PyTorch around the hot path.
 mmcv is absent on both boxes, so ``ConvModule`` / ``resize`` are re-provided with the same parameter names.
 """
 import glob

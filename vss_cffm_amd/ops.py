@@ -644,15 +644,17 @@ class _BnReluPoolFn(torch.autograd.Function):
             import torch.distributed as dist
             part = torch.empty(lib.cffm_colstats_records(r), 512, dtype=torch.float32, device=dev)
             _lib.check(lib.cffm_colstats(_ptr(rows), r, _ptr(part), st), lib)
-            packed = torch.cat([part.double().sum(0), torch.tensor([count], dtype=torch.float64, device=dev)])
+            packed = torch.cat([part.double().sum(0), torch.full((1,), count, dtype=torch.float64, device=dev)])
             dist.all_reduce(packed, group=group if group is not True else None)
-            sums, count = packed[:512], float(packed[512].item())
+            # the global element count stays ON THE DEVICE (a 0-d tensor): no host synchronisation between the two passes, so a
+            # head step under SyncBN neither stalls the stream nor breaks a stream capture (`.item()` here did both)
+            sums, count = packed[:512], packed[512]
             mean = sums[:256] / count
             var = (sums[256:] / count - mean * mean).clamp_min(0.)
             if running_mean is not None:
                 with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(mean.float(), alpha=momentum)
-                    running_var.mul_(1 - momentum).add_((var * (count / max(count - 1, 1))).float(), alpha=momentum)
+                    running_mean.mul_(1 - momentum).add_(mean.float() * momentum)
+                    running_var.mul_(1 - momentum).add_((var * (count / (count - 1).clamp_min(1.))).float() * momentum)
             rstd = (var + eps).rsqrt()
             coef[0], coef[1] = (weight.double() * rstd).float(), (bias.double() - mean * weight.double() * rstd).float()
             coef[2], coef[3] = rstd.float(), (-mean * rstd).float()
@@ -721,9 +723,14 @@ def bn_relu_pool(y, bn, want_stack=True, drop_mask=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             group = bn.process_group if bn.process_group is not None else True
     training = bn.training or bn.running_mean is None
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     if bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    if bn.momentum is not None:
+        momentum = bn.momentum
+    elif bn.training and bn.num_batches_tracked is not None:
+        momentum = 1.0 / float(bn.num_batches_tracked)      # torch: momentum=None means a cumulative moving average (one host read, as torch does)
+    else:
+        momentum = 0.0
     fused, stack = _BnReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, want_stack, group,
                                        drop_mask)
     return fused, (stack if want_stack else None)

@@ -19,7 +19,8 @@ walks the table with one workgroup per chunk.  A chunk names the ROW of three sm
 
 A row is a (parameter group, step count) pair: parameters that first receive a gradient later than the rest of their group
 (un-freezing, conditionally used branches) get a row -- and a bias correction -- of their own, as torch's per-parameter
-step does.  When all gradients alias one buffer -- what ``_LayerFn.backward`` produces -- the table stores their byte
+step does; a row advances its step count only in the steps in which one of its parameters has a gradient (the chunk table
+carries a flag per row), so intermittently used parameters keep torch's bias correction and schedule iteration.  When all gradients alias one buffer -- what ``_LayerFn.backward`` produces -- the table stores their byte
 offsets inside it and the buffer's address is a kernel argument: the table is built once, wherever the allocator puts the
 gradients.  Otherwise (DistributedDataParallel bucket views, foreign gradients) it stores absolute addresses and is
 rebuilt only when one of them changes.  The cache key covers every address the table holds (parameters, gradients, both
@@ -48,6 +49,8 @@ class _DeviceRows:
         self.sched_sent = None    # what the device copy of `sched` holds (None: unknown)
         self.tables = {}          # key -> device chunk table
         self.schedule = None      # device-side schedule fields (consts[3:10]) given to rows made later
+        self.inflight = []        # pinned staging buffers of eager-mode `sched` copies that may still be queued
+        self.members = {}         # row -> ids of the parameters updated with it
 
     def row_for(self, gi, step, group):
         for r, (g, t) in enumerate(self.rows):
@@ -66,9 +69,26 @@ class _DeviceRows:
             state[:n - 1] = old_state.cpu()
         consts[n - 1, 0], consts[n - 1, 1], consts[n - 1, 2] = b1, b2, group['eps']
         if self.schedule is not None:
-            consts[n - 1, 3:10] = torch.tensor(self.schedule, dtype=torch.float64)
+            sched = list(self.schedule)
+            if sched[6] is None:              # "iteration 0 = the next step of the row": resolved now that the row exists
+                sched[6] = float(step)
+            consts[n - 1, 3:10] = torch.tensor(sched, dtype=torch.float64)
         state[n - 1, 0] = float(step)
         self.consts, self.state = consts.to(dev), state.to(dev)
+        self.sched = torch.zeros(n, 2, dtype=torch.float32, device=dev)
+        self.sched_host = torch.zeros(n, 2, dtype=torch.float32, pin_memory=(dev.type == 'cuda'))
+        self.sched_sent = None
+        self.tables.clear()
+        return n - 1
+
+    def split_row(self, r):
+        """A copy of row r (same group, same step count, same constants), made ON THE DEVICE (no host sync: after graph replays
+        only the device knows the count): the parameters of r that sit out a step move there before r advances."""
+        self.rows.append(list(self.rows[r]))
+        dev = self.device
+        self.consts = torch.cat([self.consts, self.consts[r:r + 1]])
+        self.state = torch.cat([self.state, self.state[r:r + 1]])
+        n = len(self.rows)
         self.sched = torch.zeros(n, 2, dtype=torch.float32, device=dev)
         self.sched_host = torch.zeros(n, 2, dtype=torch.float32, pin_memory=(dev.type == 'cuda'))
         self.sched_sent = None
@@ -145,7 +165,7 @@ class AdamW(torch.optim.Optimizer):
         return st
 
     def _table(self, dr, ps, rows):
-        """-> (device chunk table, gradient base address or 0)."""
+        """-> (device chunk table, device flags of the rows it references, gradient base address or 0)."""
         grads = [p.grad for p in ps]
         for p, g in zip(ps, grads):
             if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device or g.is_sparse:
@@ -170,11 +190,13 @@ class AdamW(torch.optim.Optimizer):
                 r[:, 3] = v.data_ptr() + 4 * off
                 r[:, 4] = np.minimum(CHUNK, n - off) | (np.int64(row) << 32)     # {int n; int row;}
                 out.append(r)
-            tab = torch.from_numpy(np.concatenate(out)).to(dr.device)
+            act = np.zeros(len(dr.rows), dtype=np.int32)
+            act[list(set(rows))] = 1              # only the rows of THIS table advance their step count (k_adamw_tick_rows)
+            tab = (torch.from_numpy(np.concatenate(out)).to(dr.device), torch.from_numpy(act).to(dr.device))
             if len(dr.tables) >= 4:
                 dr.tables.clear()
             dr.tables[key] = tab
-        return tab, (base if shared else 0)
+        return tab[0], tab[1], (base if shared else 0)
 
     def refresh_hyper(self):
         """Write the groups' current lr / weight decay into the pinned host mirrors (no launch, no sync).  A captured
@@ -207,7 +229,7 @@ class AdamW(torch.optim.Optimizer):
                 c[r, 3:10] = torch.tensor([kind, float(max_iters or 0), power, min_lr, float(warmup_iters), warmup_ratio, first], dtype=torch.float64)
             dr.consts.copy_(c)
         self._pending_schedule = None if max_iters is None else (kind, float(max_iters), power, min_lr, float(warmup_iters), warmup_ratio,
-                                                                 float(first_step or 0))
+                                                                 None if first_step is None else float(first_step))
         for dr in self._devs.values():
             dr.schedule = self._pending_schedule
 
@@ -236,9 +258,23 @@ class AdamW(torch.optim.Optimizer):
             fresh = [(gi, group, p) for gi, group, p in items if id(p) not in self._row_of]
             for gi, group, p in fresh:       # (rows are made before any table is looked up: a new row rebuilds the tables)
                 st = self._moments(p)
-                self._row_of[id(p)] = (dev, dr.row_for(gi, st['step'], group))
+                r = dr.row_for(gi, st['step'], group)
+                self._row_of[id(p)] = (dev, r)
+                dr.members.setdefault(r, set()).add(id(p))
             ps = [p for _, _, p in items]
             rows = [self._row_of[id(p)][1] for p in ps]
+            # parameters that sit this step out must not advance with their row: they move to a copy of it first
+            present = {}
+            for p, r in zip(ps, rows):
+                present.setdefault(r, set()).add(id(p))
+            for r, here in present.items():
+                absent = dr.members.get(r, set()) - here
+                if absent:
+                    nr = dr.split_row(r)
+                    dr.members[r] = set(here)
+                    dr.members[nr] = set(absent)
+                    for pid in absent:
+                        self._row_of[pid] = (dev, nr)
             for p in ps:
                 self.state[p]['step'] += 1
             for r in set(rows):
@@ -246,14 +282,24 @@ class AdamW(torch.optim.Optimizer):
             self.refresh_hyper()
             capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
             now = dr.sched_host.clone() if not capturing else None
-            if capturing or dr.sched_sent is None or not torch.equal(now, dr.sched_sent):
-                dr.sched.copy_(dr.sched_host, non_blocking=True)
-                dr.sched_sent = now       # unknown (None) after a capture: replays re-read the mirror
-            tab, gbase = self._table(dr, ps, rows)
+            if capturing:
+                dr.sched.copy_(dr.sched_host, non_blocking=True)     # a memcpy node: replays re-read the mirror
+                dr.sched_sent = None
+            elif dr.sched_sent is None or not torch.equal(now, dr.sched_sent):
+                # eager: the host runs ahead of the stream, so the copy reads a buffer of its OWN (the mirror is rewritten by the
+                # next step's refresh_hyper while this copy may still be queued); buffers are dropped once their copy has run
+                src = now.pin_memory() if dev.type == 'cuda' else now
+                dr.sched.copy_(src, non_blocking=True)
+                if dev.type == 'cuda':
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    dr.inflight = [(b, e) for b, e in dr.inflight if not e.query()] + [(src, ev)]
+                dr.sched_sent = now
+            tab, active, gbase = self._table(dr, ps, rows)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == 'cuda' else C.c_void_p(0)
             _lib.check(lib.cffm_adamw_step_rows(C.c_void_p(tab.data_ptr()), tab.shape[0], C.c_void_p(gbase),
                                                 C.c_void_p(dr.state.data_ptr()), C.c_void_p(dr.sched.data_ptr()),
-                                                C.c_void_p(dr.consts.data_ptr()), len(dr.rows), stream), lib)
+                                                C.c_void_p(dr.consts.data_ptr()), len(dr.rows), C.c_void_p(active.data_ptr()), stream), lib)
         return loss
 
     def device_step_count(self, group=0):
