@@ -1,6 +1,7 @@
 // r03_mlp_bench.hip -- standalone check + timing of the fused row-panel kernels k_mlp_fwd / k_mlp_bwd (panel_kernels.h):
 // fp64 host reference at a small row count (every output incl. the records), then back-to-back timing at the CFFM-B1 size.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/r03_mlp_bench.hip -o build/r03_mlp_bench
+#define CFFM_EXPERIMENTS 1
 #include "../vss_cffm_amd/csrc/panel_kernels.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,7 +30,7 @@ static void unsplit(const std::vector<float>& s, std::vector<double>& out) {   /
 }
 struct Err { double e = 0, r = 0; void add(double got, double ref) { e = fmax(e, fabs(got - ref)); r = fmax(r, fabs(ref)); } double rel() const { return e / (r > 0 ? r : 1); } };
 
-template <int MT, int D>
+template <int MT, int D, bool WS = false>
 static void run(int NP, bool check, int HW, bool with_act = true) {
     const int B = (NP + HW - 1) / HW;
     std::vector<float> ao((size_t)NP * 256), xt((size_t)B * 4 * HW * 256), wp(256 * 256), w1(1024 * 256), w2(256 * 1024), bp(256), b1(1024), b2(256), g2(256), be2(256), dout((size_t)NP * 256);
@@ -50,12 +51,13 @@ static void run(int NP, bool check, int HW, bool with_act = true) {
     b.w2n = pack(d_w2, 256, 1024, 1); b.w1n = pack(d_w1, 1024, 256, 1); b.wpn = pack(d_wp, 256, 256, 1);
     b.dhs = devz<float>((size_t)NP * 1024); b.dx1 = devz<float>((size_t)NP * 256); b.dao = devz<float>((size_t)NP * 256);
     b.rec_b1 = devz<float>((size_t)grid * 1024); b.rec_ln = devz<float>((size_t)grid * 1024); b.NP = NP;
-    auto kf = k_mlp_fwd<MT, D>; auto kb = k_mlp_bwd<MT, D>;
-    const int lds = PNL_FUSED_LDS(MT);
+    auto kf = WS ? k_mlp_fwd_ws<MT, D> : k_mlp_fwd<MT, D>; auto kb = WS ? k_mlp_bwd_ws<MT, D> : k_mlp_bwd<MT, D>;
+    const int lds = WS ? PNL_WS_FWD_LDS(MT) : PNL_FUSED_LDS(MT), ldsb = WS ? PNL_WS_BWD_LDS(MT) : PNL_FUSED_LDS(MT);
+    const int PT = WS ? PNL_WS_THREADS : PNL_THREADS;
     CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    CK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_THREADS), lds, 0, f); CK(hipGetLastError());
-    hipLaunchKernelGGL(kb, dim3(grid), dim3(PNL_THREADS), lds, 0, b); CK(hipGetLastError());
+    CK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    hipLaunchKernelGGL(kf, dim3(grid), dim3(PT), lds, 0, f); CK(hipGetLastError());
+    hipLaunchKernelGGL(kb, dim3(grid), dim3(PT), ldsb, 0, b); CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     if (check) {
         auto x1 = host(f.x1, (size_t)NP * 256), x2 = host(f.x2, (size_t)NP * 256), hraw = host(f.hraw, (size_t)NP * 1024), mean = host(f.mean2, NP), rstd = host(f.rstd2, NP);
@@ -92,8 +94,8 @@ static void run(int NP, bool check, int HW, bool with_act = true) {
             for (int w = 0; w < grid; ++w) { s0 += rln[(size_t)w * 1024 + n]; s1 += rln[(size_t)w * 1024 + 256 + n]; s2 += rln[(size_t)w * 1024 + 512 + n]; s3 += rln[(size_t)w * 1024 + 768 + n]; }
             eg.add(s0, sg[n]); ebt.add(s1, sbt[n]); ec2.add(s2, sc2[n]); ecp.add(s3, scp[n]);
         }
-        printf("MT=%d D=%d NP=%d check (max|err|/max|ref|): x1 %.1e mean %.1e rstd %.1e z2 %.1e hraw %.1e act %.1e x2 %.1e | dh %.1e dx1 %.1e dao %.1e db1 %.1e dg %.1e dbeta %.1e db2 %.1e dbp %.1e\n",
-               MT, D, NP, ex1.rel(), emu.rel(), ers.rel(), ez2.rel(), eh.rel(), ea.rel(), ex2.rel(), edh.rel(), edx1.rel(), edao.rel(), eb1.rel(), eg.rel(), ebt.rel(), ec2.rel(), ecp.rel());
+        printf("WS=%d MT=%d D=%d NP=%d check (max|err|/max|ref|): x1 %.1e mean %.1e rstd %.1e z2 %.1e hraw %.1e act %.1e x2 %.1e | dh %.1e dx1 %.1e dao %.1e db1 %.1e dg %.1e dbeta %.1e db2 %.1e dbp %.1e\n",
+               (int)WS, MT, D, NP, ex1.rel(), emu.rel(), ers.rel(), ez2.rel(), eh.rel(), ea.rel(), ex2.rel(), edh.rel(), edx1.rel(), edao.rel(), eb1.rel(), eg.rel(), ebt.rel(), ec2.rel(), ecp.rel());
     } else {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int R = 30;
@@ -102,18 +104,18 @@ static void run(int NP, bool check, int HW, bool with_act = true) {
         const int NROT = 8;
         float *rh[NROT], *ra[NROT], *rx1[NROT], *rz[NROT], *rx2[NROT];
         for (int q = 0; q < NROT; ++q) { rh[q] = devz<float>((size_t)NP * 1024); ra[q] = devz<float>((size_t)NP * 1024); rx1[q] = devz<float>((size_t)NP * 256); rz[q] = devz<float>((size_t)NP * 256); rx2[q] = devz<float>((size_t)NP * 256); }
-        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_THREADS), lds, 0, f);
-        CK(hipEventRecord(e0, 0)); for (int i = 0; i < R; ++i) hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_THREADS), lds, 0, f); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msf, e0, e1));
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kf, dim3(grid), dim3(PT), lds, 0, f);
+        CK(hipEventRecord(e0, 0)); for (int i = 0; i < R; ++i) hipLaunchKernelGGL(kf, dim3(grid), dim3(PT), lds, 0, f); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msf, e0, e1));
         {
             float msr;
             CK(hipEventRecord(e0, 0));
-            for (int i = 0; i < R; ++i) { MlpFwdArgs fr = f; const int q = i % NROT; fr.hraw = rh[q]; fr.acts = with_act ? ra[q] : nullptr; fr.x1 = rx1[q]; fr.z2s = rz[q]; fr.x2 = rx2[q]; hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_THREADS), lds, 0, fr); }
+            for (int i = 0; i < R; ++i) { MlpFwdArgs fr = f; const int q = i % NROT; fr.hraw = rh[q]; fr.acts = with_act ? ra[q] : nullptr; fr.x1 = rx1[q]; fr.z2s = rz[q]; fr.x2 = rx2[q]; hipLaunchKernelGGL(kf, dim3(grid), dim3(PT), lds, 0, fr); }
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msr, e0, e1));
             printf("   k_mlp_fwd with rotating output buffers: %.2f us\n", msr * 1e3 / R);
         }
-        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kb, dim3(grid), dim3(PNL_THREADS), lds, 0, b);
-        CK(hipEventRecord(e0, 0)); for (int i = 0; i < R; ++i) hipLaunchKernelGGL(kb, dim3(grid), dim3(PNL_THREADS), lds, 0, b); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msb, e0, e1));
-        printf("MT=%d D=%d NP=%d grid=%d act-store=%d: k_mlp_fwd %.2f us   k_mlp_bwd %.2f us\n", MT, D, NP, grid, (int)with_act, msf * 1e3 / R, msb * 1e3 / R);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kb, dim3(grid), dim3(PT), ldsb, 0, b);
+        CK(hipEventRecord(e0, 0)); for (int i = 0; i < R; ++i) hipLaunchKernelGGL(kb, dim3(grid), dim3(PT), ldsb, 0, b); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&msb, e0, e1));
+        printf("WS=%d MT=%d D=%d NP=%d grid=%d act-store=%d: k_mlp_fwd %.2f us   k_mlp_bwd %.2f us\n", (int)WS, MT, D, NP, grid, (int)with_act, msf * 1e3 / R, msb * 1e3 / R);
     }
 }
 
@@ -121,11 +123,10 @@ int main(int argc, char** argv) {
     srand(2);
     const bool quick = argc > 1;     // any argument: only the checks
     printf("PNL_ABLATE=%d\n", PNL_ABLATE);
-    if (!PNL_ABLATE) { run<2, 4>(500, true, 170); run<2, 2>(777, true, 300); }
+    if (!PNL_ABLATE) { run<2, 4>(500, true, 170); run<2, 2, true>(777, true, 300); run<2, 2, true>(500, true, 170); }
     if (quick) return 0;
     run<2, 4>(7200, false, 3600, true);
-    run<2, 4>(7200, false, 3600, false);
-    run<2, 2>(7200, false, 3600, false);
-    run<2, 8>(7200, false, 3600, false);
+    run<2, 2, true>(7200, false, 3600, true);
+    run<2, 2, true>(7200, false, 3600, false);
     return 0;
 }

@@ -20,9 +20,13 @@
 // shapes always do: 256 channels, H*W a multiple of 4 for the 60 x 60 grid); otherwise 4-byte accesses, same tile walk.
 // addend (may be NULL): laid out like dst; added to image z unless z % add_mod == add_skip (the layer backward's last transpose:
 // dx of the three pass-through frames also receives the upstream gradient of those frames, cffm_transformer.py:826).
+// copy_dst (may be NULL): laid out like src; image z is ALSO copied there unchanged unless z % add_mod == add_skip (the layer
+// forward's first transpose: the three pass-through frames of the reference's output, cffm_transformer.py:826, leave with the read
+// that the transpose does anyway -- round 2 ran a separate 44 MB copy kernel beside it).
 __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, float* __restrict__ dst,
                                                     int rows, int cols, long src_bs, long dst_bs,
-                                                    const float* __restrict__ addend, int add_mod, int add_skip) {
+                                                    const float* __restrict__ addend, int add_mod, int add_skip,
+                                                    float* __restrict__ copy_dst = nullptr) {
     __shared__ float tile[64][65];   // tile[c][r]; odd stride: the scalar LDS accesses below are at most 2-way conflicted
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const float* s = src + (long)blockIdx.z * src_bs;
@@ -31,15 +35,18 @@ __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src
     const bool vin = (cols % 4 == 0) && (src_bs % 4 == 0) && (((uintptr_t)src & 15) == 0);
     const bool vout = (rows % 4 == 0) && (dst_bs % 4 == 0) && (((uintptr_t)dst & 15) == 0) && (((uintptr_t)addend & 15) == 0);
     const float* ad = (addend && ((int)blockIdx.z % add_mod) != add_skip) ? addend + (long)blockIdx.z * dst_bs : nullptr;
+    float* cp = (copy_dst && ((int)blockIdx.z % add_mod) != add_skip) ? copy_dst + (long)blockIdx.z * src_bs : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + p + 16 * k, c = c0 + 4 * q;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (r < rows) {
-            if (vin && c + 3 < cols) v = *(const f32x4*)(s + (long)r * cols + c);
-            else
+            if (vin && c + 3 < cols) {
+                v = *(const f32x4*)(s + (long)r * cols + c);
+                if (cp) *(f32x4*)(cp + (long)r * cols + c) = v;
+            } else
                 for (int e = 0; e < 4; ++e)
-                    if (c + e < cols) v[e] = s[(long)r * cols + c + e];
+                    if (c + e < cols) { v[e] = s[(long)r * cols + c + e]; if (cp) cp[(long)r * cols + c + e] = v[e]; }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) tile[4 * q + e][p + 16 * k] = v[e];

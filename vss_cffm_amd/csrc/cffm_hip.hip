@@ -520,11 +520,11 @@ static unsigned ew_grid(long n4) {
 
 // ------------------------------------------------------------------------------------------- stages
 static int transpose_add(const float* src, float* dst, int batch, int rows, int cols, long src_bs, long dst_bs, const float* addend,
-                         int add_mod, int add_skip, void* stream) {
+                         int add_mod, int add_skip, void* stream, float* copy_dst = nullptr) {
     PROF(ST_TRANSPOSE);
     REQUIRE(src && dst && batch > 0 && rows > 0 && cols > 0, "transpose: bad arguments");
     CFFM_LAUNCH(k_transpose, ((cols + 63) / 64, (rows + 63) / 64, batch), (256), 0, (hipStream_t)stream, src, dst, rows, cols,
-                src_bs, dst_bs, addend, add_mod > 0 ? add_mod : 1, add_skip);
+                src_bs, dst_bs, addend, add_mod > 0 ? add_mod : 1, add_skip, copy_dst);
     CHECK_LAUNCH("transpose");
     return 0;
 }
@@ -956,11 +956,12 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
 
 // ------------------------------------------------------------------------------------------- fused row-panel stages
 // CFFM_PANEL=0 keeps the round-2 sequence of tiled GEMMs + row kernels (A/B measurements)
-// CFFM_STORE_ACT=1: the fused forward also stores gelu(hraw + b1) (split-4) and the fc2 weight gradient reads it, instead of
-// re-applying bias + GELU to hraw while it stages its tiles (A/B measurements)
+// CFFM_STORE_ACT=0: the fused forward does NOT store gelu(hraw + b1); the fc2 weight gradient re-applies bias + GELU to hraw while it
+// stages its tiles (29.5 MB less written per block, but the GELU then sits in the weight-gradient GEMM's staging path: measured
+// 0.8914 vs 0.8843 ms per step without / with the stored activation, means of three alternating runs -- storing is the default)
 static int store_act() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_STORE_ACT"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) { const char* e = getenv("CFFM_STORE_ACT"); v = (e && e[0] == '0') ? 0 : 1; }
     return v;
 }
 static int panel_on() {
@@ -982,6 +983,46 @@ static int mlp_lds_grant() {
 #endif
     return 0;
 }
+// q|k|v Linear and its input gradient as row-panel GEMMs (weights in fragment order): rows per workgroup (32 or 48) chosen so that
+// the grid wastes the least of its last round on 256 CUs
+static int panel_mt(long M) {
+    const long w2 = (M + 31) / 32, w3 = (M + 47) / 48;
+    return ((w3 + 255) / 256) * 3 < ((w2 + 255) / 256) * 2 ? 3 : 2;
+}
+extern "C++" {
+template <int MT, int NTW, bool A_PRE, int EPI>
+static int panel_gemm_launch(const float* A, int lda, long M, int K, const float* wf, float* Cout, int ldc, const float* bias, void* aux,
+                             hipStream_t st) {
+    auto kern = k_panel_gemm<MT, NTW, 2, 4, A_PRE, EPI>;
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS(MT)) != hipSuccess) return -1;
+        granted = true;
+    }
+#endif
+    CFFM_LAUNCH(kern, ((unsigned)((M + 16 * MT - 1) / (16 * MT))), (PNL_THREADS), PNL_LDS(MT), st, A, lda, (int)M, K, (const f32x4*)wf, Cout, ldc, bias, aux);
+    return 0;
+}
+}  // extern "C++"
+// qkv16[M][768] (f16) = f16((x W^T + b) [q third * 32^-0.5]), x in split-4 storage, W fragment-ordered (forward form)
+static int panel_qkv_fwd(const float* x_s, const float* wf, const float* b, h16* qkv16, long M, hipStream_t st) {
+    return panel_mt(M) == 3 ? panel_gemm_launch<3, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st)
+                            : panel_gemm_launch<2, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st);
+}
+// dx[M][256] = dqkv[M][768] W, W fragment-ordered (input-gradient form)
+static int panel_qkv_dx(const float* dqkv, const float* wfn, float* dx, long M, hipStream_t st) {
+    return panel_mt(M) == 3 ? panel_gemm_launch<3, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st)
+                            : panel_gemm_launch<2, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st);
+}
+// CFFM_PANEL_QKV=0: the q|k|v Linear keeps the tiled GEMMs (A/B: 0.8843 tiled vs 0.8729 ms per step as row panels, means of three
+// alternating runs with the activation stored)
+static int panel_qkv_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFFM_PANEL_QKV"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v && panel_on();
+}
+
 long cffm_mlp_records(long NP) { return (NP + 16 * MLP_MT - 1) / (16 * MLP_MT); }
 
 int cffm_panel_pack_weight(const float* w, int N, int K, int form, float* w_frag, void* stream) {
@@ -1094,7 +1135,10 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
     TRY(ln_pool_fwd_impl(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
                          ws + L.mean1, ws + L.rstd1, sp, stream));
-    if (sp) {
+    if (sp && panel_qkv_on()) {
+        PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
+        REQUIRE(!panel_qkv_fwd(ws + L.zall, ws + L.w_frag, p->qkv_b, (h16*)(ws + L.qkv), NR, st), "block_forward: qkv gemm failed");
+    } else if (sp) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
         REQUIRE(!gemm_nt_qkv16_split_pre(ws + L.zall, wq_s, p->qkv_b, (h16*)(ws + L.qkv), NR, 768, CFFM_C, st), "block_forward: qkv gemm failed");
     } else {
@@ -1107,7 +1151,7 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
         PROF(ST_GEMM);
         TRY(cffm_mlp_fwd(ws + L.ao, x_tgt, tgt_bs, g->HW, wf + 768 * 256, wf + 768 * 256 + 256 * 256, wf + 768 * 256 + 256 * 256 + 1024 * 256,
                          p->proj_b, p->fc1_b, p->fc2_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2, ws + L.mean2, ws + L.rstd2, ws + L.hraw,
-                         store_act() ? ws + L.act : nullptr /* default: act is not stored, the fc2 weight gradient re-applies bias + GELU to hraw */,
+                         store_act() ? ws + L.act : nullptr /* CFFM_STORE_ACT=0: the fc2 weight gradient re-applies bias + GELU to hraw */,
                          ws + L.x2, NP, stream));
         CHECK_LAUNCH("block_forward");
         return 0;
@@ -1317,7 +1361,12 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     } else {
         TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
     }
-    DX_GEMM(ST_G_QKV_DX, false, dqkv, p->qkv_w, wq_s, dzall, NR, 768, CFFM_C);
+    if (sp && panel_qkv_on()) {
+        PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
+        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st), "block_backward: q|k|v input-gradient gemm failed");
+    } else {
+        DX_GEMM(ST_G_QKV_DX, false, dqkv, p->qkv_w, wq_s, dzall, NR, 768, CFFM_C);
+    }
 #undef DX_GEMM
     if (!sp) {
         const cffm_wgrad wg[4] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C},
@@ -1782,14 +1831,9 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
     side_init(st);
     hipStream_t sd = side_fork(st, 0);
     TRY(param_prep(params, depth, blk0, L.total, L, (void*)sd));
-    if (y_full) {
-        const long n4 = 3 * img / 4;
-        CFFM_LAUNCH(k_copy_batched, ((unsigned)std::min<long>((n4 + 255) / 256, 2048), (unsigned)g->B), (256), 0, sd, x_nchw, y_full, n4,
-                    4 * img, 4 * img);
-        CHECK_LAUNCH("layer_forward: pass-through copy");
-    }
     side_mark(sd, st, 0);
-    TRY(cffm_transpose(x_nchw, xs, g->B * 4, CFFM_C, (int)HW, img, img, stream));
+    // NCHW -> NHWC of the four frames; frames 0..2 also go to y_full as they are (the reference's pass-through frames) with the same read
+    TRY(transpose_add(x_nchw, xs, g->B * 4, CFFM_C, (int)HW, img, img, nullptr, 4, 3, stream, y_full));
     side_join(sd, st, 0);
 #ifndef CFFM_EMU
     g_side.used = 0;   // (that was this call's only side branch, joined here)
