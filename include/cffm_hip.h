@@ -314,6 +314,14 @@ int cffm_rows_resize_bwd(const float* ddst, long ddst_map_stride, float* dsrc, l
 int cffm_clip_format(const unsigned char* frames, const unsigned char* labels, float* out_img, long long* out_lab, int T, int H, int W,
                      int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3], int to_rgb,
                      float pad_val, int seg_pad_val, int reduce_zero_label, void* stream);
+/* the same with PhotoMetricDistortion_clips' brightness / contrast (mmseg/datasets/pipelines/transforms.py:2028-2150, convert() :2057)
+ * between flip and normalisation, per frame: brightness_beta[t] / contrast_alpha[t] (HOST arrays of T floats, or NULL) -- NaN = branch
+ * not taken for that frame; v = u8(clip(v + beta)), then v = u8(clip(v * alpha)) in float32 as numpy does.  The saturation / hue
+ * branches (cv2 8-bit HSV) are not provided. */
+int cffm_clip_format_photo(const unsigned char* frames, const unsigned char* labels, float* out_img, long long* out_lab, int T, int H,
+                           int W, int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3],
+                           int to_rgb, float pad_val, int seg_pad_val, int reduce_zero_label, const float* brightness_beta,
+                           const float* contrast_alpha, void* stream);
 
 /* ---- parameter update of the training step (the reference trains the head with AdamW, lr 6e-5, betas (0.9, 0.999),
  * weight decay 0.01: local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:35) ----

@@ -1,6 +1,7 @@
 // r03_panel_bench.hip -- standalone micro-benchmark of the row-panel GEMM (vss_cffm_amd/csrc/panel_kernels.h) at the block's
 // shapes: correctness against fp64 on sampled rows, then back-to-back launch time.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/r03_panel_bench.hip -o build/r03_panel_bench
+#define CFFM_EXPERIMENTS 1
 #include "../vss_cffm_amd/csrc/panel_kernels.h"
 #include <stdio.h>
 #include <stdlib.h>

@@ -141,6 +141,45 @@ def reference_clip_pipeline(frames, labels, seed, crop_size, cat_max_ratio=0.75)
     return results['img'].data.numpy(), results['gt_semantic_seg'].data.numpy(), bool(results['flip'])
 
 
+class HsvDrawn(Exception):
+    """the seeded stream took the saturation / hue branch (cv2's HSV conversion: cannot be pinned here)"""
+
+
+def reference_photo_pipeline(frames, labels, seed, crop_size):
+    """the same pipeline with the reference's PhotoMetricDistortion_clips between flip and normalisation (vspw_repeat2.py:13).
+    Raises HsvDrawn when a frame draws saturation / hue; -> (img, gt, flip) otherwise."""
+    _, Tr, Fm = _reference_modules()
+    import mmcv
+    from vss_cffm_amd.data import reduce_zero_label
+
+    def no_hsv(*a, **k):
+        raise HsvDrawn()
+    mmcv.bgr2hsv, mmcv.hsv2bgr = no_hsv, no_hsv
+    results = dict(img=[f for f in frames], gt_semantic_seg=[reduce_zero_label(l) for l in labels], seg_fields=['gt_semantic_seg'])
+    np.random.seed(seed)
+    for tr in (Tr.RandomCrop_clips(crop_size=crop_size, cat_max_ratio=0.75), Tr.RandomFlip_clips(prob=0.5), Tr.PhotoMetricDistortion_clips(),
+               Tr.Normalize_clips(mean=MEAN, std=STD, to_rgb=True), Tr.Pad_clips(size=crop_size, pad_val=0, seg_pad_val=255),
+               Fm.DefaultFormatBundle_clips()):
+        results = tr(results)
+    return results['img'].data.numpy(), results['gt_semantic_seg'].data.numpy(), bool(results['flip'])
+
+
+def photo_cases(n=4):
+    """the first n (clip seed, stream seed, frames) whose stream draws only brightness / contrast: found by running the reference"""
+    out = []
+    for t, clip_seed in ((2, 21), (3, 22), (4, 23), (2, 24)):
+        frames, labels = synth_clip(clip_seed, t=t)
+        for seed in range(200, 4000):
+            try:
+                reference_photo_pipeline(frames, labels, seed, (64, 96))
+            except HsvDrawn:
+                continue
+            out.append((clip_seed, seed, t))
+            break
+    return out[:n]
+
+
+PHOTO_CASES = [(21, 214, 2), (22, 220, 3), (23, 220, 4), (24, 214, 2)]    # what photo_cases() found (checked by main())
 CLIP_CASES = [(1, (64, 64)), (2, (64, 64)), (3, (96, 160)), (4, (80, 120)), (5, (48, 200))]   # (seed, crop size): incl. boxes past the frame
 
 
@@ -158,6 +197,12 @@ def main():
         frames, labels = synth_clip(seed)
         img, gt, flip = reference_clip_pipeline(frames, labels, 100 + seed, crop)
         d['clip/%d/img' % seed], d['clip/%d/gt' % seed], d['clip/%d/flip' % seed] = img, gt, np.array(flip)
+    found = photo_cases()
+    assert found == PHOTO_CASES, found
+    for clip_seed, seed, t in PHOTO_CASES:
+        frames, labels = synth_clip(clip_seed, t=t)
+        img, gt, flip = reference_photo_pipeline(frames, labels, seed, (64, 96))
+        d['photo/%d/img' % clip_seed], d['photo/%d/gt' % clip_seed], d['photo/%d/flip' % clip_seed] = img, gt, np.array(flip)
     np.savez_compressed(os.path.join(OUT, 'clip_pipeline.npz'), **d)
     for k, v in d.items():
         print(k, v.shape)

@@ -49,6 +49,26 @@ def run_clip_cases(device):
         assert img.shape == g['clip/%d/img' % seed].shape and gt.dtype == torch.int64
         assert torch.equal(gt.cpu(), torch.from_numpy(g['clip/%d/gt' % seed]))                 # integer work: equality
         torch.testing.assert_close(img.cpu(), torch.from_numpy(g['clip/%d/img' % seed]), rtol=0, atol=1e-6)
+    # PhotoMetricDistortion_clips between flip and normalisation: brightness / contrast per frame, drawn in the reference's order
+    # (goldens: the reference class itself, on seeded streams that never take its cv2-HSV branches)
+    from tests.golden.make_golden_clip import PHOTO_CASES
+    for clip_seed, seed, t in PHOTO_CASES:
+        frames, labels = synth_clip(clip_seed, t=t)
+        np.random.seed(seed)
+        fmt = D.ClipFormatter(crop_size=(64, 96), cat_max_ratio=0.75, flip_prob=0.5, photo=D.PhotoMetricDistortionClips())
+        img, gt, params = fmt(torch.from_numpy(frames).to(device), torch.from_numpy(labels).to(device), last_label_host=labels[-1])
+        assert params['flip'] == bool(g['photo/%d/flip' % clip_seed]) and len(params['photo']['beta']) == t
+        assert torch.equal(gt.cpu(), torch.from_numpy(g['photo/%d/gt' % clip_seed]))
+        torch.testing.assert_close(img.cpu(), torch.from_numpy(g['photo/%d/img' % clip_seed]), rtol=0, atol=1e-6)
+        assert any(v == v for v in params['photo']['beta'] + params['photo']['alpha'])       # (something was actually distorted)
+    # a stream that draws saturation / hue: refused by default, those two steps left out with on_hsv='skip'
+    np.random.seed(3)
+    with pytest.raises(_lib.CffmError):
+        for _ in range(8):
+            D.PhotoMetricDistortionClips().draw(4)
+    np.random.seed(3)
+    ph = D.PhotoMetricDistortionClips(on_hsv='skip').draw(4)
+    assert len(ph['saturation']) == 4 and len(ph['hue']) == 4
     # image only (test-time clips have no labels), explicit parameters
     frames, _ = synth_clip(7)
     fmt = D.ClipFormatter(crop_size=(90, 150), cat_max_ratio=1.0, flip_prob=0.5)
@@ -91,3 +111,53 @@ def test_golden_is_what_the_reference_classes_produce_live():
     frames, labels = synth_clip(seed)
     img, gt, flip = reference_clip_pipeline(frames, labels, 100 + seed, crop)
     assert np.array_equal(img, g['clip/%d/img' % seed]) and np.array_equal(gt, g['clip/%d/gt' % seed])
+
+
+def _video_tree(root, videos):
+    import os
+    for split, names in (('train', ['v_a', 'v_c']), ('val', ['v_b']), ('test', ['v_d'])):
+        with open(os.path.join(root, split + '.txt'), 'w') as f:
+            f.write(''.join(n + '\n' for n in names))
+    for v, n in videos.items():
+        for sub, suf in (('origin', '.jpg'), ('mask', '.png')):
+            os.makedirs(os.path.join(root, 'data', v, sub))
+            for i in range(n):
+                open(os.path.join(root, 'data', v, sub, '%08d%s' % (3 * i + 1, suf)), 'w').close()
+
+
+def test_clip_lister_lists_and_serves_clips(tmp_path):
+    """VSPWDataset2-shaped lister (custom.py:1959-2100) over a directory-tree fixture."""
+    root = str(tmp_path)
+    _video_tree(root, {'v_a': 14, 'v_b': 5, 'v_c': 9, 'v_d': 12})
+    tr = D.ClipLister(root, 'train')
+    assert tr.videolists == ['v_a', 'v_c'] and len(tr) == 2 and len(tr.img_all) == 23
+    np.random.seed(4); random.seed(4)
+    it = tr.train_item(0)
+    assert it['video'] == 'v_a' and len(it['frames']) == 4 and it['img_paths'][3].endswith('/data/v_a/origin/' + it['frames'][3])
+    assert it['mask_paths'][0].endswith('.png') and '/mask/' in it['mask_paths'][0]
+    order = tr.imgdic['v_a'][::-1] if it['reversed'] else tr.imgdic['v_a']
+    pos = [order.index(n) for n in it['frames']]
+    assert [p - pos[3] for p in pos] == [-9, -6, -3, 0]
+    np.random.seed(4); random.seed(4)
+    assert tr.train_item(1) is None                                  # 9 frames: no frame has 9 predecessors
+    va = D.ClipLister(root, 'val')
+    assert len(va) == 5 and [len(va.test_item(i)['frames']) for i in range(5)] == [1, 1, 1, 4, 4]
+    assert va.test_item(4)['frames'] == [va.imgdic['v_b'][i] for i in (0, 2, 3, 4)]
+    allv = D.ClipLister(root, 'train_val_generate_prototype')
+    assert allv.videolists == ['v_a', 'v_c', 'v_b', 'v_d'] and len(allv) == 4
+
+
+@pytest.mark.skipif(not RI.available(), reason='/root/reference not present')
+def test_clip_lister_against_reference_dataset_live(tmp_path):
+    """the same tree through the reference's CustomDataset_video2.__init__ (executed where it lies): identical lists and lengths."""
+    from tests.golden.make_golden_clip import _reference_modules
+    Cu, _, _ = _reference_modules()
+    root = str(tmp_path)
+    _video_tree(root, {'v_a': 14, 'v_b': 5, 'v_c': 9, 'v_d': 12})
+    for split in ('train', 'val', 'train_val_generate_prototype'):
+        try:
+            ref = Cu.CustomDataset_video2(pipeline=[], img_dir='', split=split, data_root=root, dilation=[-9, -6, -3])
+        except Exception as e:   # noqa: BLE001  (the stand-in mmcv may lack what Compose needs)
+            pytest.skip('reference dataset not constructible here: %s' % e)
+        mine = D.ClipLister(root, split)
+        assert mine.videolists == ref.videolists and mine.imgdic == ref.imgdic and mine.img_all == ref.img_all and len(mine) == len(ref)

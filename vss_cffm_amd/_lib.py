@@ -101,6 +101,7 @@ SIGNATURES = {
     'cffm_rows_resize_fwd': (ci, [vp, cl, vp, cl, ci, ci, ci, ci, ci, ci, vp]),
     'cffm_rows_resize_bwd': (ci, [vp, cl, vp, cl, ci, ci, ci, ci, ci, ci, vp]),
     'cffm_clip_format': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.c_float * 3, C.c_float * 3, ci, C.c_float, ci, ci, vp]),
+    'cffm_clip_format_photo': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.c_float * 3, C.c_float * 3, ci, C.c_float, ci, ci, vp, vp, vp]),
     'cffm_upce_blocks': (cl, [ci, ci, ci]),
     'cffm_upce_fwd': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     'cffm_upce_bwd': (ci, [vp, vp, vp, vp, C.c_float, vp, ci, ci, ci, ci, ci, ci, ci, vp]),

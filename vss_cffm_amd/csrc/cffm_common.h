@@ -7,6 +7,18 @@
 #endif
 #include <stdint.h>
 
+// ---- profiling / rejected-variant switches -------------------------------------------------------------------------------------
+// The kernels carry compile-time hooks of measurements recorded in DESIGN.md (ablations: *_ABLATE, in-kernel cycle stamps:
+// *_TIMING, rejected forms: FWD_DMA, VFLAG_RD, the persistent attention forward, the wave-specialised fused Mlp kernels).  They
+// exist only in -DCFFM_EXPERIMENTS builds (scripts/): build_native.sh does not define it, and without it every switch is pinned to
+// "off" here, so libcffm_hip.so contains exactly the kernels bench.py runs.
+#ifndef CFFM_EXPERIMENTS
+#if defined(GEMM_ABLATE) || defined(FWD_ABLATE) || defined(BWD_ABLATE) || defined(LNPB_ABLATE) || defined(PNL_ABLATE) || defined(FWD_DMA) || \
+    defined(VFLAG_RD) || defined(FWD_TIMING) || defined(BWD_TIMING) || defined(UPCE_ABLATE)
+#error "profiling switches need -DCFFM_EXPERIMENTS"
+#endif
+#endif
+
 // ---- fixed problem constants of the reference head (cffm_head.py:74-95) ------------------------
 #define CFFM_C 256         // embed_dim of every CFFM config
 #define CFFM_HEADS 8

@@ -616,36 +616,34 @@ int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* con
     return 0;
 }
 
-#ifndef CFFM_ATTN_FWD_DEFAULT
-#define CFFM_ATTN_FWD_DEFAULT 0
-#endif
 int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst, const void* biasH, float* ao,
                   float* lse, void* stream) {
     PROF(ST_ATTN_FWD);
     REQUIRE(g && qkv16 && key_src && q_dst && biasH && ao && lse, "attn_fwd: null");
     const h16* bias = (const h16*)biasH;
-    // Two forms (CFFM_ATTN_FWD = oneshot | persistent; CFFM_FWD_PER = windows per workgroup of the persistent form):
-    //  * one workgroup per (window, head), four per CU;
-    //  * persistent: a workgroup walks `per` windows of one head with the bias tiles in registers and the next window's gathers in
-    //    flight; groups sized so that 8 x groups workgroups fit the chip's FWP_OCC x 256 slots in one round.
+    // one workgroup per (window, head), four per CU.  (-DCFFM_EXPERIMENTS builds also carry the rejected persistent form --
+    // CFFM_ATTN_FWD=persistent, CFFM_FWD_PER = windows per workgroup -- for scripts/r02_fwd_persist.sh.)
+#ifdef CFFM_EXPERIMENTS
     static int variant = -1, per_env = 0;
     if (variant < 0) {
         const char* e = getenv("CFFM_ATTN_FWD");
-        variant = (e && e[0] == 'o') ? 0 : (e && e[0] == 'p') ? 1 : CFFM_ATTN_FWD_DEFAULT;
+        variant = (e && e[0] == 'p') ? 1 : 0;
         const char* pe = getenv("CFFM_FWD_PER");
         per_env = pe ? atoi(pe) : 0;
     }
-    if (variant == 0) {
-        CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
-                    key_src, q_dst, bias, ao, lse);
-    } else {
+    if (variant == 1) {
         const int total = g->B * g->nW, slots = 32 * FWP_OCC;     // 8 heads x 32 x FWP_OCC = every workgroup slot of 256 CUs
         int per = per_env > 0 ? per_env : (total + slots - 1) / slots;
         if (per < 1) per = 1;
         const int ng = (total + per - 1) / per;
         CFFM_LAUNCH(k_cfm_attn_fwd_p, (CFFM_HEADS, ng), (256), ATT_FWP_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16, key_src, q_dst,
                     bias, ao, lse, per);
+        CHECK_LAUNCH("attn_fwd");
+        return 0;
     }
+#endif
+    CFFM_LAUNCH(k_cfm_attn_fwd, (g->B * g->nW * CFFM_HEADS), (256), ATT_FWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
+                key_src, q_dst, bias, ao, lse);
     CHECK_LAUNCH("attn_fwd");
     return 0;
 }
@@ -1719,7 +1717,15 @@ int cffm_rows_resize_bwd(const float* ddst, long ddst_map_stride, float* dsrc, l
 int cffm_clip_format(const unsigned char* frames, const unsigned char* labels, float* out_img, long long* out_lab, int T, int H, int W,
                      int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3], int to_rgb,
                      float pad_val, int seg_pad_val, int reduce_zero_label, void* stream) {
+    return cffm_clip_format_photo(frames, labels, out_img, out_lab, T, H, W, y1, x1, ch, cw, flip, Ho, Wo, mean, std, to_rgb, pad_val,
+                                  seg_pad_val, reduce_zero_label, nullptr, nullptr, stream);
+}
+int cffm_clip_format_photo(const unsigned char* frames, const unsigned char* labels, float* out_img, long long* out_lab, int T, int H, int W,
+                           int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3], int to_rgb,
+                           float pad_val, int seg_pad_val, int reduce_zero_label, const float* brightness_beta, const float* contrast_alpha,
+                           void* stream) {
     REQUIRE(T >= 0 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1, "clip_format: bad sizes");
+    REQUIRE(!(brightness_beta || contrast_alpha) || T <= CLIP_MAXT, "clip_format: at most %d frames with photometric parameters", CLIP_MAXT);
     REQUIRE(y1 >= 0 && x1 >= 0 && ch >= 0 && cw >= 0 && y1 + ch <= H && x1 + cw <= W && ch <= Ho && cw <= Wo,
             "clip_format: crop box %d+%d x %d+%d does not fit a %dx%d frame / %dx%d output", y1, ch, x1, cw, H, W, Ho, Wo);
     if (!T) return 0;
@@ -1727,6 +1733,12 @@ int cffm_clip_format(const unsigned char* frames, const unsigned char* labels, f
     ClipFmt P;
     P.T = T; P.H = H; P.W = W; P.y1 = y1; P.x1 = x1; P.ch = ch; P.cw = cw; P.flip = flip ? 1 : 0; P.Ho = Ho; P.Wo = Wo;
     P.to_rgb = to_rgb ? 1 : 0; P.reduce_zero_label = reduce_zero_label ? 1 : 0; P.seg_pad = seg_pad_val; P.pad_val = pad_val;
+    P.photo = (brightness_beta || contrast_alpha) ? 1 : 0;
+    for (int t = 0; t < CLIP_MAXT; ++t) {   // NaN = "not taken" (the reference draws a parameter only when the branch is taken)
+        const float bt = (brightness_beta && t < T) ? brightness_beta[t] : NAN, al = (contrast_alpha && t < T) ? contrast_alpha[t] : NAN;
+        P.has_b[t] = bt == bt; P.has_c[t] = al == al;
+        P.beta[t] = P.has_b[t] ? bt : 0.f; P.alpha[t] = P.has_c[t] ? al : 1.f;
+    }
     for (int c = 0; c < 3; ++c) {
         REQUIRE(std[c] != 0.f, "clip_format: zero std");
         P.mean[c] = mean[c];

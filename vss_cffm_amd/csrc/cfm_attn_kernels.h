@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
     FWD_STAMP(6);
 }
 
+#ifdef CFFM_EXPERIMENTS   // measured and rejected (17.2 us at two per CU, spills at three): not in the product library
 // ---- forward, persistent form -------------------------------------------------------------------------------------------
 // grid (8 heads, NG window groups), FWP_OCC workgroups per CU.  The same mathematics as k_cfm_attn_fwd; what changes is where the
 // latencies go.  The one-shot kernel's workgroups all start together and run their phases in lockstep (everybody waits for its
@@ -459,6 +460,8 @@ __global__ void __launch_bounds__(256, FWP_OCC) k_cfm_attn_fwd_p(Geo G, const h1
         __syncthreads();   // LDS is restaged for the next window
     }
 }
+
+#endif  // CFFM_EXPERIMENTS
 
 // =====================================================================================================
 // Fused backward (round 2): ONE kernel does what k_cfm_attn_bwd_q + k_cfm_attn_bwd_kv did with two stagings, two S / dP

@@ -5,6 +5,10 @@
 //   LoadAnnotations(reduce_zero_label)          label 0 -> 255, the rest minus 1 (254 -> 255)   pipelines/loading.py
 //   RandomCrop_clips   transforms.py:1524-1600   one crop box for every frame of the clip, img[y1:y2, x1:x2]
 //   RandomFlip_clips   transforms.py:852-910     horizontal mirror of the (cropped) frames and label maps
+//   PhotoMetricDistortion_clips  transforms.py:2028-2150  per FRAME: random brightness (+beta) and random contrast (*alpha), each
+//                      `np.clip(float32(img) * alpha + beta, 0, 255).astype(uint8)` (convert(), :2057-2061); the saturation / hue
+//                      branches go through cv2's 8-bit HSV conversion, which this environment cannot pin -- they are drawn (to keep
+//                      the random stream in step) and refused or skipped by the host (vss_cffm_amd/data.py), never approximated here
 //   Normalize_clips    transforms.py:1260-1297   BGR -> RGB, (v - mean) * (1 / std) in float32 (mmcv.imnormalize)
 //   Pad_clips          transforms.py:990-1085    bottom / right padding to the crop size: 0 in the (normalised) image, 255 in the labels
 //   DefaultFormatBundle_clips  formating.py:261-305   HWC -> CHW, frames stacked: img [T,3,H,W] float32, labels [T,1,H,W] int64
@@ -14,6 +18,7 @@
 #pragma once
 #include "cffm_common.h"
 
+#define CLIP_MAXT 16
 struct ClipFmt {
     int T, H, W;            // input frames [T][H][W][3] uint8 (BGR as decoded), labels [T][H][W] uint8
     int y1, x1, ch, cw;     // crop box: rows y1 .. y1+ch-1, columns x1 .. x1+cw-1 (already clipped to the image)
@@ -21,7 +26,21 @@ struct ClipFmt {
     int Ho, Wo;             // output size (>= ch, cw: the rest is padding)
     int to_rgb, reduce_zero_label, seg_pad;
     float mean[3], stdinv[3], pad_val;   // in OUTPUT channel order (RGB when to_rgb)
+    int photo;              // per-frame brightness / contrast present
+    float beta[CLIP_MAXT], alpha[CLIP_MAXT];   // frame t: v = u8(clip(v + beta)) (beta != 0: brightness taken), then v = u8(clip(v * alpha)) (alpha != 1)
+    unsigned char has_b[CLIP_MAXT], has_c[CLIP_MAXT];
 };
+// uint8 -> convert(alpha, beta) of the reference: float32 multiply, float32 add (two roundings: no FMA), clip, truncate
+__device__ __forceinline__ float clip_convert(float v, float alpha, float beta) {
+#ifdef CFFM_EMU
+    volatile float m = v * alpha;
+    float t = m + beta;
+#else
+    float t = __fadd_rn(__fmul_rn(v, alpha), beta);
+#endif
+    t = fminf(fmaxf(t, 0.f), 255.f);
+    return (float)(int)t;      // astype(uint8) of a value in [0, 255]: truncation
+}
 __global__ void __launch_bounds__(256) k_clip_format(const unsigned char* __restrict__ frames, const unsigned char* __restrict__ labels,
                                                       float* __restrict__ out_img, long long* __restrict__ out_lab, ClipFmt P) {
     const long n = (long)P.T * P.Ho * P.Wo;
@@ -34,7 +53,11 @@ __global__ void __launch_bounds__(256) k_clip_format(const unsigned char* __rest
             const unsigned char* px = frames + (((long)t * P.H + sy) * P.W + sx) * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = (float)px[P.to_rgb ? 2 - c : c];
+                float v = (float)px[P.to_rgb ? 2 - c : c];
+                if (P.photo) {
+                    if (P.has_b[t]) v = clip_convert(v, 1.f, P.beta[t]);
+                    if (P.has_c[t]) v = clip_convert(v, P.alpha[t], 0.f);
+                }
                 out_img[o + c * plane] = (v - P.mean[c]) * P.stdinv[c];
             }
         } else {

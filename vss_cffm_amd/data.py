@@ -5,9 +5,11 @@ Reference: ``CustomDataset_video2`` (mmseg/datasets/custom.py:1959) picks the fr
 edge cases :2366-2388 -- and runs the pipeline of local_configs/_base_/datasets/vspw_repeat2.py:8-19 on them, frame by frame in
 numpy / cv2 inside the dataloader workers.  Here the random DECISIONS are drawn on the host in the reference's order (same numpy /
 ``random`` calls, so a seeded run picks the same crop and flip), and crop + flip + BGR->RGB + normalisation + padding + CHW stacking
-are ONE kernel over the whole clip (``cffm_clip_format``, csrc/clip_kernels.h).  Not covered: image decoding, the random rescale
-(cv2's fixed-point bilinear resize) and the photometric distortion (cv2 HSV conversion) -- they need the image stack this
-environment does not have and stay upstream of ``ClipFormatter`` (frames arrive decoded, at the scale to crop from).
+are ONE kernel over the whole clip (``cffm_clip_format_photo``, csrc/clip_kernels.h), including the brightness / contrast steps of
+``PhotoMetricDistortion_clips`` (``PhotoMetricDistortionClips``).  Not covered: image decoding, the random rescale and the test-time
+``AlignedResize_clips`` (cv2's fixed-point bilinear resize) and the saturation / hue steps of the photometric distortion (cv2's 8-bit
+HSV conversion) -- none of them can be pinned without cv2, which neither box has; they stay upstream of ``ClipFormatter`` (frames
+arrive decoded, at the scale to crop from).  ``ClipLister`` restates the video / frame lists of ``CustomDataset_video2``.
 """
 import ctypes as C
 import random as _pyrandom
@@ -52,6 +54,43 @@ def reduce_zero_label(lab):
     return lab
 
 
+class PhotoMetricDistortionClips:
+    """The random decisions of ``PhotoMetricDistortion_clips`` (pipelines/transforms.py:2028-2150), drawn per FRAME in the reference's
+    order: ``randint(2)`` brightness (+ ``uniform(-delta, delta)``), ``randint(2)`` mode, [mode 1: ``randint(2)`` contrast (+ ``uniform``)],
+    ``randint(2)`` saturation (+ ``uniform``), ``randint(2)`` hue (+ ``randint(-delta, delta)``), [mode 0: contrast] -- so a seeded run stays in
+    step with the reference's stream.  Brightness and contrast are applied by the clip kernel (``convert()``, :2057-2061, in float32 as
+    numpy does).  Saturation and hue go through cv2's 8-bit BGR<->HSV conversion (mmcv.bgr2hsv / hsv2bgr), whose rounding cannot be
+    pinned without cv2: a frame that draws them raises (``on_hsv='raise'``, default) or has just those two steps left out
+    (``on_hsv='skip'``: a documented deviation, never an approximation of the colour conversion)."""
+
+    def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, on_hsv='raise',
+                 np_random=np.random):
+        if on_hsv not in ('raise', 'skip'):
+            raise ValueError("on_hsv must be 'raise' or 'skip'")
+        self.brightness_delta, self.contrast_range = brightness_delta, tuple(contrast_range)
+        self.saturation_range, self.hue_delta, self.on_hsv, self.rng = tuple(saturation_range), hue_delta, on_hsv, np_random
+
+    def draw(self, n_frames):
+        """-> dict(beta [T], alpha [T] (NaN = not taken), saturation [T], hue [T] (None = not taken))."""
+        r = self.rng
+        beta, alpha, sat, hue = [], [], [], []
+        for _ in range(n_frames):
+            b = float(r.uniform(-self.brightness_delta, self.brightness_delta)) if r.randint(2) else float('nan')
+            mode = int(r.randint(2))
+            a = float('nan')
+            if mode == 1 and r.randint(2):
+                a = float(r.uniform(*self.contrast_range))
+            s_ = float(r.uniform(*self.saturation_range)) if r.randint(2) else None
+            h_ = int(r.randint(-self.hue_delta, self.hue_delta)) if r.randint(2) else None
+            if mode == 0 and r.randint(2):
+                a = float(r.uniform(*self.contrast_range))
+            beta.append(b); alpha.append(a); sat.append(s_); hue.append(h_)
+        if self.on_hsv == 'raise' and any(v is not None for v in sat + hue):
+            raise _lib.CffmError('PhotoMetricDistortionClips: a frame drew the saturation / hue distortion, which needs cv2\'s 8-bit HSV '
+                                 'conversion (not available here; on_hsv=\'skip\' leaves those two steps out)')
+        return dict(beta=beta, alpha=alpha, saturation=sat, hue=hue)
+
+
 class ClipFormatter:
     """RandomCrop_clips + RandomFlip_clips + Normalize_clips + Pad_clips + DefaultFormatBundle_clips for one decoded clip.
 
@@ -62,11 +101,12 @@ class ClipFormatter:
 
     def __init__(self, crop_size=(480, 480), cat_max_ratio=0.75, flip_prob=0.5, mean=(123.675, 116.28, 103.53),
                  std=(58.395, 57.12, 57.375), to_rgb=True, pad_val=0, seg_pad_val=255, ignore_index=255, reduce_zero_label=True,
-                 np_random=np.random):
+                 np_random=np.random, photo=None):
         self.crop_size, self.cat_max_ratio, self.flip_prob = tuple(crop_size), cat_max_ratio, flip_prob
         self.mean, self.std, self.to_rgb = tuple(mean), tuple(std), to_rgb
         self.pad_val, self.seg_pad_val, self.ignore_index, self.rzl = pad_val, seg_pad_val, ignore_index, reduce_zero_label
         self.rng = np_random
+        self.photo = photo            # a PhotoMetricDistortionClips (drawn after the flip, as the pipeline orders them) or None
 
     def _bbox(self, h, w):
         margin_h, margin_w = max(h - self.crop_size[0], 0), max(w - self.crop_size[1], 0)
@@ -74,8 +114,8 @@ class ClipFormatter:
         ox = int(self.rng.randint(0, margin_w + 1))
         return oy, oy + self.crop_size[0], ox, ox + self.crop_size[1]
 
-    def draw(self, last_label, shape=None):
-        """-> dict(y1, x1, ch, cw, flip).  last_label: the TARGET frame's raw uint8 label map [H,W] (or None with `shape`)."""
+    def draw(self, last_label, shape=None, n_frames=4):
+        """-> dict(y1, x1, ch, cw, flip[, photo]).  last_label: the TARGET frame's raw uint8 label map [H,W] (or None with `shape`)."""
         h, w = last_label.shape[:2] if last_label is not None else shape
         box = self._bbox(h, w)
         if self.cat_max_ratio < 1. and last_label is not None:
@@ -89,7 +129,10 @@ class ClipFormatter:
                 box = self._bbox(h, w)
         flip = bool(self.rng.rand() < self.flip_prob) if self.flip_prob is not None else False
         y1, x1 = box[0], box[2]
-        return dict(y1=y1, x1=x1, ch=min(box[1], h) - y1, cw=min(box[3], w) - x1, flip=flip)
+        out = dict(y1=y1, x1=x1, ch=min(box[1], h) - y1, cw=min(box[3], w) - x1, flip=flip)
+        if self.photo is not None:
+            out['photo'] = self.photo.draw(n_frames)
+        return out
 
     def apply(self, frames, labels, params):
         """frames [T,H,W,3] uint8 (BGR), labels [T,H,W] uint8 or None, on the device -> (img [T,3,Ho,Wo] float32,
@@ -112,14 +155,80 @@ class ClipFormatter:
         lab = torch.empty(t, 1, ho, wo, dtype=torch.int64, device=frames.device) if labels is not None else None
         stream = C.c_void_p(torch.cuda.current_stream(frames.device).cuda_stream) if frames.is_cuda else C.c_void_p(0)
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
-        _lib.check(lib.cffm_clip_format(ptr(frames), ptr(labels), ptr(img), ptr(lab), t, h, w, params['y1'], params['x1'], params['ch'],
-                                        params['cw'], int(params['flip']), ho, wo, (C.c_float * 3)(*self.mean), (C.c_float * 3)(*self.std),
-                                        int(self.to_rgb), float(self.pad_val), int(self.seg_pad_val), int(self.rzl), stream), lib)
+        ph = params.get('photo')
+        if ph is not None and len(ph['beta']) != t:
+            raise _lib.CffmError('ClipFormatter: photometric parameters for %d frames, clip has %d' % (len(ph['beta']), t))
+        beta = (C.c_float * t)(*ph['beta']) if ph is not None else None
+        alpha = (C.c_float * t)(*ph['alpha']) if ph is not None else None
+        _lib.check(lib.cffm_clip_format_photo(ptr(frames), ptr(labels), ptr(img), ptr(lab), t, h, w, params['y1'], params['x1'], params['ch'],
+                                              params['cw'], int(params['flip']), ho, wo, (C.c_float * 3)(*self.mean),
+                                              (C.c_float * 3)(*self.std), int(self.to_rgb), float(self.pad_val), int(self.seg_pad_val),
+                                              int(self.rzl), beta, alpha, stream), lib)
         return img, lab
 
     def __call__(self, frames, labels, last_label_host=None):
         """last_label_host: numpy copy of the target frame's raw labels for the crop decision (default: labels[-1] copied back)."""
         if last_label_host is None and labels is not None:
             last_label_host = labels[-1].cpu().numpy()
-        params = self.draw(last_label_host, shape=tuple(frames.shape[1:3]))
+        params = self.draw(last_label_host, shape=tuple(frames.shape[1:3]), n_frames=int(frames.shape[0]))
         return self.apply(frames, labels, params) + (params,)
+
+
+class ClipLister:
+    """The video / frame lists of ``CustomDataset_video2`` (mmseg/datasets/custom.py:1959-2100) and the clips it serves.
+
+    ``<data_root>/<split>.txt`` names the videos (one per line); split ``'train_val_generate_prototype'`` concatenates train, val
+    and test (:2063-2072).  A video's frames are ``sorted(os.listdir(<data_root>/data/<video>/origin))`` (:2079-2084); label maps live
+    in ``.../mask/`` under the same name with ``seg_map_suffix``.  Length and indexing follow the reference: a TRAINING item is a
+    video (``len(videolists)``, one random clip per visit: ``clip_indices_train``, custom.py:2251-2267), every other split serves one
+    clip per frame (``len(img_all)``, ``clip_indices_test``, :2366-2388)."""
+
+    def __init__(self, data_root, split, dilation=DILATION, img_suffix='.jpg', seg_map_suffix='.png', flip_video=True):
+        import os
+        self.data_root, self.split, self.dilation = data_root, split, list(dilation)
+        self.img_suffix, self.seg_map_suffix, self.flip_video = img_suffix, seg_map_suffix, flip_video
+        names = ['train', 'val', 'test'] if split == 'train_val_generate_prototype' else [split]
+        self.videolists = []
+        for n in names:
+            with open(os.path.join(data_root, n + '.txt')) as f:
+                self.videolists += [line.rstrip('\n') for line in f.readlines()]     # (the reference drops the last character of every line)
+        self.imgdic, self.img_all = {}, []
+        for video in self.videolists:
+            imglist = sorted(os.listdir(os.path.join(data_root, 'data', video, 'origin')))
+            self.imgdic[video] = imglist
+            self.img_all += [[video, img] for img in imglist]
+
+    @property
+    def per_video(self):
+        return self.split in ('train', 'train_val_generate_prototype')
+
+    def __len__(self):
+        return len(self.videolists) if self.per_video else len(self.img_all)
+
+    def _paths(self, video, names):
+        import os
+        img_dir, ann_dir = os.path.join(self.data_root, 'data', video, 'origin/'), os.path.join(self.data_root, 'data', video, 'mask/')
+        return ([os.path.join(img_dir, n) for n in names], [os.path.join(ann_dir, n.replace(self.img_suffix, self.seg_map_suffix)) for n in names])
+
+    def train_item(self, idx, np_random=np.random, py_random=_pyrandom):
+        """-> dict(video, reversed, frames (names, oldest reference frame first, target last), img_paths, mask_paths) or None (video too
+        short), with the reference's two random draws (custom.py:2256-2263)."""
+        video = self.videolists[idx]
+        imglist = self.imgdic[video]
+        got = clip_indices_train(len(imglist), self.dilation, self.flip_video, np_random, py_random)
+        if got is None:
+            return None
+        rev, idxs = got
+        if rev:
+            imglist = imglist[::-1]
+        names = [imglist[i] for i in idxs]
+        imgs, masks = self._paths(video, names)
+        return dict(video=video, reversed=rev, frames=names, img_paths=imgs, mask_paths=masks)
+
+    def test_item(self, idx):
+        """-> dict(video, frames, img_paths, mask_paths): the clip of frame idx of ``img_all`` (1 to 4 frames, target last)."""
+        video, img_name = self.img_all[idx]
+        imglist = self.imgdic[video]
+        names = [imglist[i] for i in clip_indices_test(imglist.index(img_name), len(imglist), self.dilation)]
+        imgs, masks = self._paths(video, names)
+        return dict(video=video, frames=names, img_paths=imgs, mask_paths=masks)
