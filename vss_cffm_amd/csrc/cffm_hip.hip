@@ -380,6 +380,30 @@ static int dw_one_group(hipStream_t st) {
     return stream_is_capturing(st);
 #endif
 }
+// Launch ORDER matters under stream capture: of the kernels that depend on one node, the graph executor keeps the FIRST-launched on
+// the node's own hardware queue and moves the others to different queues -- and a dependency that crosses queues costs 5-10 us where
+// same-queue succession costs ~1.5 (round-3 timeline: the chain hopped queues at every fork because the side work was launched first).
+// So a fork is split: side_fork_mark() records the point on `main`, the chain's next kernel is launched, and only then
+// side_fork_take() makes the side stream wait for the mark and hands it out.
+static void side_fork_mark(hipStream_t main, int i) {
+#ifndef CFFM_EMU
+    if (g_side.on) (void)hipEventRecord(g_side.fork[i], main);
+#endif
+    (void)main; (void)i;
+}
+static hipStream_t side_fork_take(hipStream_t main, int i) {
+#ifndef CFFM_EMU
+    const int idx = g_side.ns >= 4 ? (i & 3) : (g_side.ns > 1 ? (i & 1) : 0);
+    hipStream_t s = g_side.st[idx];
+    if (g_side.on && hipStreamWaitEvent(s, g_side.fork[i], 0) == hipSuccess) {
+        g_side.used |= 1u << idx;
+        return s;
+    }
+    (void)hipGetLastError();
+#endif
+    (void)i;
+    return main;
+}
 static hipStream_t side_fork(hipStream_t main, int i) {
 #ifndef CFFM_EMU
     const int idx = g_side.ns >= 4 ? (i & 3) : (g_side.ns > 1 ? (i & 1) : 0);
@@ -1325,6 +1349,9 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         }
 #endif
         TRY(attn_bwd_fused(g, ws + L.qkv, key_src, q_dst, (const h16*)(ws + L.bias), ws + L.ao, dao, ws + L.lse, dqkv, scratch + S.dkvp, &dbp, &ng, stream));
+        // (side work first here, although that makes the chain change hardware queues under graph replay -- see side_fork_mark: with the
+        //  chain launched first the executor parked these side kernels behind the NEXT block's chain and the step's tail grew:
+        //  0.864 vs 0.849 ms per step, means of three alternating runs)
         s1 = sp ? side_fork(st, 1) : st;
         TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, (void*)s1));
         TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
@@ -1841,11 +1868,12 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
     // the parameter-derived tables do not depend on x: they are built on the side stream while the input is transposed
     hipStream_t st = (hipStream_t)stream;
     side_init(st);
-    hipStream_t sd = side_fork(st, 0);
-    TRY(param_prep(params, depth, blk0, L.total, L, (void*)sd));
-    side_mark(sd, st, 0);
+    side_fork_mark(st, 0);
     // NCHW -> NHWC of the four frames; frames 0..2 also go to y_full as they are (the reference's pass-through frames) with the same read
     TRY(transpose_add(x_nchw, xs, g->B * 4, CFFM_C, (int)HW, img, img, nullptr, 4, 3, stream, y_full));
+    hipStream_t sd = side_fork_take(st, 0);
+    TRY(param_prep(params, depth, blk0, L.total, L, (void*)sd));
+    side_mark(sd, st, 0);
     side_join(sd, st, 0);
 #ifndef CFFM_EMU
     g_side.used = 0;   // (that was this call's only side branch, joined here)
