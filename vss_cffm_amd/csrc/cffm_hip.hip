@@ -343,10 +343,13 @@ static bool side_init(hipStream_t main) {
         const char* e = getenv("CFFM_SIDE_STREAM");
         const char* n = getenv("CFFM_SIDE_STREAMS");
         forced_ns = !n ? 0 : (n[0] == '1' ? 1 : (n[0] == '4' ? 4 : 2));
-        if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&g_side.st[0], hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&g_side.st[1], hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&g_side.st[2], hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&g_side.st[3], hipStreamNonBlocking) == hipSuccess) {
+        // CFFM_SIDE_PRIO=low: the side streams get the lowest stream priority (parameter-gradient work yields to the chain's kernels
+        // when both have workgroups ready)
+        int lo = 0, hi = 0;
+        const char* pr = getenv("CFFM_SIDE_PRIO");
+        const bool low = pr && pr[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+        auto mk = [&](hipStream_t* st_) { return (low ? hipStreamCreateWithPriority(st_, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(st_, hipStreamNonBlocking)) == hipSuccess; };
+        if (!(e && e[0] == '0') && mk(&g_side.st[0]) && mk(&g_side.st[1]) && mk(&g_side.st[2]) && mk(&g_side.st[3])) {
             bool ok = hipEventCreateWithFlags(&g_side.order, hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) == hipSuccess;
