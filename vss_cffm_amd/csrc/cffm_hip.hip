@@ -228,7 +228,7 @@ long cffm_layer_saved_floats(const cffm_geom* g, int depth) {
 }
 
 // scratch carve (floats): fwd uses [0, BHW*C); bwd uses all of it
-struct Scratch { long a, a2, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, dkvp, total; };
+struct Scratch { long a, a2, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, dkvp, alt, total; };
 static Scratch scratch_layout(const cffm_geom* g) {
     const long B = g->B, HW = g->HW, RC = g->RC;
     Scratch s;
@@ -245,6 +245,11 @@ static Scratch scratch_layout(const cffm_geom* g) {
     s.dbiasT = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     s.dxs = p; p += up(B * 4 * HW * CFFM_C);
     s.dkvp = p; p += up(B * g->nW * ((long)CFFM_NKEY_PAD * 256 + CFFM_HEADS));   // f16 partial rows + their (window, head) scales
+    // second copies of what a block's side work (weight-gradient GEMMs, column sums, bias-tile sum) still reads after the chain has
+    // moved on to the next block: blocks alternate between the two sets (block_backward_impl `par`), so the next block's chain never
+    // waits for the side streams.  Offsets relative to `alt`: b | dact | dqkv | dbiasT
+    s.alt = p;
+    p += up(B * HW * CFFM_C) + up(B * HW * CFFM_HID) + up(B * RC * 768) + up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     s.total = p;
     return s;
 }
@@ -313,10 +318,12 @@ struct SideStream {
                                 // 1 / 3 (the small kernels) do not queue behind each other
 #ifndef CFFM_EMU
     hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[2] = {nullptr, nullptr}, order = nullptr;
+    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[2] = {nullptr, nullptr}, order = nullptr, tail_order = nullptr;
     // deferred join of a block backward (layer_backward_impl): what the NEXT block has to wait for
-    hipEvent_t dw_done = nullptr, bias_done = nullptr, tail_done[2] = {nullptr, nullptr}, join_all[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool bias_pending = false, tail_pending[2] = {false, false};
+    hipEvent_t dw_done[2] = {nullptr, nullptr}, bias_done[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, join_all[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool bias_pending[2] = {false, false}, dw_pending[2] = {false, false}, tail_pending[2] = {false, false};
+    const float* dw_dout[2] = {nullptr, nullptr};   // the `dout` a pending weight-gradient group still reads
+    int par = 0;                // scratch set of the block backward being issued
     unsigned used = 0;          // side streams forked since the last full join
 #endif
 };
@@ -350,13 +357,14 @@ static bool side_init(hipStream_t main) {
         const bool low = pr && pr[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         auto mk = [&](hipStream_t* st_) { return (low ? hipStreamCreateWithPriority(st_, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(st_, hipStreamNonBlocking)) == hipSuccess; };
         if (!(e && e[0] == '0') && mk(&g_side.st[0]) && mk(&g_side.st[1]) && mk(&g_side.st[2]) && mk(&g_side.st[3])) {
-            bool ok = hipEventCreateWithFlags(&g_side.order, hipEventDisableTiming) == hipSuccess;
+            bool ok = hipEventCreateWithFlags(&g_side.order, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&g_side.tail_order, hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.tail_done[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_side.join_all[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&g_side.dw_done, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&g_side.bias_done, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.dw_done[i], hipEventDisableTiming) == hipSuccess &&
+                                             hipEventCreateWithFlags(&g_side.bias_done[i], hipEventDisableTiming) == hipSuccess;
             state = ok ? 1 : 0;
         }
         (void)hipGetLastError();
@@ -372,6 +380,22 @@ static bool side_init(hipStream_t main) {
 // sooner).  Launched eagerly the side stream really runs beside the chain and `split` wins (0.886 vs 0.911 ms per step); a replayed
 // HIP graph executes its branches almost serially, so there the cheaper `one` wins (0.927 vs 0.950).  Default: by whether the
 // caller's stream is being captured; CFFM_DW_GROUP=one|split forces a form.
+// How the side work of a block backward is attached to the chain (bit mask; default 38 = 2 | 4 | 32, the rest for A/B measurements).
+// Under stream capture the graph executor (ROCm 7.2) gives a node's FIRST-captured dependant the node's own stream and every further
+// dependant the next of its (four) streams, depth first -- so whatever is launched first behind a fork stays on the chain's stream,
+// and side branches that reach the same stream number run one after the other in topological order.  The chain must therefore be
+// launched first at every fork and must never wait for a side branch inside the step:
+//   bit 0  the dK/dV gather is launched before the bias-tile sum of the attention backward        (superseded by bit 2)
+//   bit 1  the q|k|v input-gradient GEMM is launched before the column sum / weight-gradient group
+//   bit 2  the bias-tile sum + scatter get no branch of their own: they follow the weight-gradient group on its stream
+//   bit 5  the record reductions + pooling-matrix backward are launched only after the NEXT chain kernel (tail_flush)
+// Measured (B = 2, depth 2, replayed graph, same box): 0 -> 0.830-0.833 ms per step, 4 -> 0.808-0.810, 38 (with the two scratch sets
+// of scratch_layout, so that no block waits for the previous block's weight gradients) -> 0.798-0.811 against 0.821-0.848 for 4.
+static int fork_order() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFFM_FORK_ORDER"); v = e ? atoi(e) : 38; }
+    return v;
+}
 static int dw_one_group(hipStream_t st) {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("CFFM_DW_GROUP"); forced = !e ? -1 : (e[0] == 's' ? 0 : 1); }
@@ -448,7 +472,7 @@ static void side_join_all(hipStream_t main) {
             if (hipEventRecord(g_side.join_all[i], g_side.st[i]) == hipSuccess) (void)hipStreamWaitEvent(main, g_side.join_all[i], 0);
         }
     g_side.used = 0;
-    g_side.bias_pending = g_side.tail_pending[0] = g_side.tail_pending[1] = false;
+    g_side.bias_pending[0] = g_side.bias_pending[1] = g_side.dw_pending[0] = g_side.dw_pending[1] = g_side.tail_pending[0] = g_side.tail_pending[1] = false;
     (void)hipGetLastError();
 #endif
     (void)main;
@@ -467,7 +491,7 @@ static void side_wait(hipStream_t main, void* ev) {
     (void)main; (void)ev;
 }
 #ifndef CFFM_EMU
-static void dw_group_launched(hipStream_t side) { (void)hipEventRecord(g_side.dw_done, side); }
+static void dw_group_launched(hipStream_t side) { (void)hipEventRecord(g_side.dw_done[g_side.par], side); }
 #else
 static void dw_group_launched(hipStream_t) {}
 #endif
@@ -487,8 +511,7 @@ static int g_red_parity = 0;
 #define g_red g_redbuf[g_red_parity]
 #define g_red_floats g_red_floats_[g_red_parity]
 static struct { bool active; size_t bump; RedJobs jobs; } g_rq = {false, 0, {}};
-static void redq_flush(hipStream_t st) {
-    RedJobs& J = g_rq.jobs;
+static void redq_launch(RedJobs& J, hipStream_t st) {
     if (J.njob == 1) {
         CFFM_LAUNCH(k_reduce_records, ((J.total[0] + 63) / 64), (1024), 0, st, J.part[0], J.nblk[0], J.stride[0], J.total[0], J.segs[0]);
     } else if (J.njob > 1) {
@@ -496,6 +519,7 @@ static void redq_flush(hipStream_t st) {
     }
     J.njob = 0;
 }
+static void redq_flush(hipStream_t st) { redq_launch(g_rq.jobs, st); }
 struct RedScope {
     hipStream_t st;
     explicit RedScope(hipStream_t s) : st(s) { g_red_parity ^= 1; g_rq.active = true; g_rq.bump = 0; g_rq.jobs.njob = 0; }
@@ -687,13 +711,14 @@ static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
 
 // the three pieces of the attention backward (the block backward puts the bias-gradient sum on its side stream)
 static int attn_bwd_fused(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst, const h16* bias, const float* ao,
-                          const float* dao, const float* lse, float* dqkv, float* dkv_part, float** dbp_out, int* ng_out, void* stream) {
+                          const float* dao, const float* lse, float* dqkv, float* dkv_part, float** dbp_out, int* ng_out, int par, void* stream) {
     PROF2(ST_ATTN_BWD_Q);
     int per;
     const int ng = attn_bwd_groups(g, &per);
     const long nb = (long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD;   // one bias-gradient tile set per window group
-    float* dbp = lib_scratch3((size_t)ng * nb);
+    float* dbp = lib_scratch3((size_t)2 * ng * nb);      // two sets: see scratch_layout (alt)
     REQUIRE(dbp, "attn_bwd: scratch allocation failed");
+    dbp += (size_t)(par ? 1 : 0) * ng * nb;
 #ifndef CFFM_EMU
     static bool granted = false;
     if (!granted) {
@@ -729,7 +754,7 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     REQUIRE(g && qkv16 && bias && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
     float* dbp;
     int ng;
-    TRY(attn_bwd_fused(g, qkv16, key_src, q_dst, bias, ao, dao, lse, dqkv, dkv_part, &dbp, &ng, stream));
+    TRY(attn_bwd_fused(g, qkv16, key_src, q_dst, bias, ao, dao, lse, dqkv, dkv_part, &dbp, &ng, 0, stream));
     TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, stream));
     TRY(attn_bwd_gather(g, inv_ptr, inv_idx, dkv_part, dqkv, stream));
     return 0;
@@ -1211,13 +1236,39 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                                const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
                                const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
-                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, void* stream);
+                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, void* stream);
+// The parameter-gradient tail of a block backward (record reductions, pooling-matrix backward), LAUNCHED LATE: its fork point is the end
+// of ln_pool_bwd (event fork[3]), but the launches happen only after the chain's next kernel has been launched (tail_flush), so that
+// under stream capture the chain's kernel is ln_pool_bwd's FIRST dependant and keeps its place on the graph's first stream (the graph
+// executor hands every further dependant of a node the next stream, see side_fork_mark).
+#ifndef CFFM_EMU
+static struct { bool has; RedJobs jobs; float* dM; const cffm_block_grads* gr; int parity; } g_tail = {false, {}, nullptr, nullptr, 0};
+static int tail_flush(hipStream_t st) {
+    if (!g_tail.has) return 0;
+    g_tail.has = false;
+    hipStream_t s3 = side_fork_take(st, 3);
+    if (s3 != st) (void)hipStreamWaitEvent(s3, g_side.tail_order, 0);   // the q|k|v bias records (column sum on the weight-gradient stream)
+    redq_launch(g_tail.jobs, s3);
+    CHECK_LAUNCH("block_backward reductions");
+    TRY(cffm_pool_matrix_bwd(g_tail.dM, g_tail.gr->pool_w, (void*)s3));
+    side_record(s3, st, g_side.tail_done[g_tail.parity]);
+    g_side.tail_pending[g_tail.parity] = true;
+    return 0;
+}
+#else
+static int tail_flush(hipStream_t) { return 0; }
+#endif
+static void tail_reset() {      // entry of a layer backward: nothing of a previous (failed) call is left to launch
+#ifndef CFFM_EMU
+    g_tail.has = false;
+#endif
+}
 int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                         const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
                         const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
                         float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, void* stream) {
     return block_backward_impl(g, p, gr, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_ref, dref_bs, accum_ref,
-                               dx_tgt, dtgt_bs, scratch, 0, stream);
+                               dx_tgt, dtgt_bs, scratch, 0, 0, stream);
 }
 // `defer` (layer backward, round 3): the call returns with this block's parameter-gradient tail (partial-slab sums, record reductions,
 // pooling-matrix backward, bias-table scatter) still running on the side streams; the caller's stream has only waited for what reads
@@ -1227,7 +1278,7 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                                const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
                                const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
-                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, void* stream) {
+                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, void* stream) {
     REQUIRE(g && p && gr && ws && dout && scratch, "block_backward: null");
     {
         static int defer_env = -1;   // CFFM_DEFER_JOIN=0: every block ends fully joined (round-2 behaviour; A/B measurements)
@@ -1238,14 +1289,16 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     cffm_block_ws_layout(g, &L);
     const Scratch S = scratch_layout(g);
     const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
-    float* dx1 = scratch + S.b;
+    par = (defer && par) ? 1 : 0;
+    const long altb = S.alt, altact = altb + up(NP * CFFM_C), altqkv = altact + up(NP * CFFM_HID), altbias = altqkv + up(NR * 768);
+    float* dx1 = scratch + (par ? altb : S.b);
     float* dz2 = scratch + S.dz2;
     float* dao = scratch + S.dao;
-    float* dact = scratch + S.dact;
-    float* dqkv = scratch + S.dqkv;
+    float* dact = scratch + (par ? altact : S.dact);
+    float* dqkv = scratch + (par ? altqkv : S.dqkv);
     float* dzall = scratch + S.dzall;
     float* dM = scratch + S.dM;
-    float* dbiasT = scratch + S.dbiasT;
+    float* dbiasT = scratch + (par ? altbias : S.dbiasT);
     RedScope reductions((hipStream_t)stream);   // the four parameter-gradient reductions below run as one launch (finish())
     hipStream_t st = (hipStream_t)stream;
     hipStream_t sa = st;
@@ -1254,6 +1307,11 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     if (g_side.tail_pending[g_red_parity]) {    // the reduction that last read this scope's record buffer (two blocks ago)
         side_wait(st, g_side.tail_done[g_red_parity]);
         g_side.tail_pending[g_red_parity] = false;
+    }
+    g_side.par = par;
+    if (g_side.dw_pending[par]) {               // the weight-gradient group that last read this scratch set (two blocks ago)
+        side_wait(st, g_side.dw_done[par]);
+        g_side.dw_pending[par] = false;
     }
 #endif
     const int sp = gemm_use_lib() ? 0 : 1;   // see block_forward_impl: zall / z2 / act / weights (and dh below) in split-4 storage
@@ -1288,6 +1346,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         TRY(cffm_mlp_bwd(dout, ws + L.hraw, p->fc1_b, ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, wfn + 768 * 256 + 256 * 256 + 1024 * 256,
                          wfn + 768 * 256 + 256 * 256, wfn + 768 * 256, dact, dx1, dao, gr->norm2_w, gr->norm2_b, gr->fc1_b, gr->fc2_b, gr->proj_b, NP,
                          stream));
+        TRY(tail_flush(st));    // the previous block's parameter-gradient tail, now that this block's first kernel is ln_pool_bwd's first dependant
         if (!one_group) {
             sa = side_fork(st, 0);
             void* stream_a = (void*)sa;
@@ -1340,29 +1399,52 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     // attention: the fused kernel and the dK/dV gather stay on the chain; the bias-gradient tile sum and its scatter into the six
     // tables go to the side stream (branch 1), the q|k|v bias column sum and the weight gradients of q|k|v / proj after the gather
     // (branch 2)
+    TRY(tail_flush(st));        // (forms of the block whose first kernel is not the fused Mlp backward)
     hipStream_t sb = st, s1 = st;
+    int bias_late = 0, late_ng = 0;
+    float* late_dbp = nullptr;
     {
         PROF(ST_ATTN_BWD);
         float* dbp;
         int ng;
 #ifndef CFFM_EMU
-        if (g_side.bias_pending) {   // the previous block's bias-gradient tile sum still owns the tile buffer / dbiasT
-            side_wait(st, g_side.bias_done);
-            g_side.bias_pending = false;
+        if (g_side.bias_pending[par]) {   // the bias-gradient tile sum of two blocks ago still owns this set's tile buffer / dbiasT
+            side_wait(st, g_side.bias_done[par]);
+            g_side.bias_pending[par] = false;
         }
 #endif
-        TRY(attn_bwd_fused(g, ws + L.qkv, key_src, q_dst, (const h16*)(ws + L.bias), ws + L.ao, dao, ws + L.lse, dqkv, scratch + S.dkvp, &dbp, &ng, stream));
+        TRY(attn_bwd_fused(g, ws + L.qkv, key_src, q_dst, (const h16*)(ws + L.bias), ws + L.ao, dao, ws + L.lse, dqkv, scratch + S.dkvp, &dbp, &ng, par, stream));
         // (side work first here, although that makes the chain change hardware queues under graph replay -- see side_fork_mark: with the
         //  chain launched first the executor parked these side kernels behind the NEXT block's chain and the step's tail grew:
         //  0.864 vs 0.849 ms per step, means of three alternating runs)
+        if (sp && (fork_order() & 4)) {
+            // no branch of its own: the bias-gradient tile sum and scatter follow the weight-gradient group on ITS stream (below), so
+            // the attention backward has ONE dependant and the chain stays on its hardware queue
+            TRY(attn_bwd_gather(g, inv_ptr, inv_idx, scratch + S.dkvp, dqkv, stream));
+            bias_late = 1; late_dbp = dbp; late_ng = ng;
+        } else if (sp && (fork_order() & 1)) {
+            side_fork_mark(st, 1);
+            TRY(attn_bwd_gather(g, inv_ptr, inv_idx, scratch + S.dkvp, dqkv, stream));
+            s1 = side_fork_take(st, 1);
+            TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, (void*)s1));
+            TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
+        } else {
         s1 = sp ? side_fork(st, 1) : st;
         TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, (void*)s1));
         TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
         TRY(attn_bwd_gather(g, inv_ptr, inv_idx, scratch + S.dkvp, dqkv, stream));
+        }
     }
     // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)
+    int dx_done = 0;
+    if (sp && (fork_order() & 2) && panel_qkv_on()) {     // chain first: the q|k|v input gradient is launched before the side work
+        side_fork_mark(st, 2);
+        PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
+        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st), "block_backward: q|k|v input-gradient gemm failed");
+        dx_done = 1;
+    }
     if (sp) {
-        sb = side_fork(st, 2);
+        sb = dx_done ? side_fork_take(st, 2) : side_fork(st, 2);
         void* stream_b = (void*)sb;
         TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream_b));
         if (one_group) {
@@ -1377,6 +1459,13 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             REQUIRE(!gemm_tn_group((const GemmTN*)wg4, 4, sb, pre4, sb == st ? lib_scratch : lib_scratch2, 480, dw_group_launched), "block_backward: weight-gradient gemm failed");
             sa = sb;
             side_mark(sa, st, 0);
+            if (bias_late) {
+                PROF(ST_ATTN_BWD);
+                s1 = sb;
+                TRY(attn_bwd_bias_sum(late_dbp, late_ng, dbiasT, (void*)s1));
+                TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
+                bias_late = 0;
+            }
         } else {
         const cffm_wgrad wgb[2] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C}, {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
         const GemmTNPre preb[2] = {{0, 1, nullptr}, {0, 0, nullptr}};
@@ -1385,11 +1474,19 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             PROF(ST_GEMM); PROF2(ST_G_DW);
             REQUIRE(!gemm_tn_group((const GemmTN*)wgb, 2, sb, preb, sb == st ? lib_scratch : lib_scratch2, 320, dw_group_launched), "block_backward: weight-gradient gemm failed");
         }
+        if (bias_late) {
+            PROF(ST_ATTN_BWD);
+            s1 = sb;
+            TRY(attn_bwd_bias_sum(late_dbp, late_ng, dbiasT, (void*)s1));
+            TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
+            bias_late = 0;
+        }
         }
     } else {
         TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
     }
-    if (sp && panel_qkv_on()) {
+    if (dx_done) {
+    } else if (sp && panel_qkv_on()) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
         REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st), "block_backward: q|k|v input-gradient gemm failed");
     } else {
@@ -1404,11 +1501,30 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         TRY(cffm_linear_bwd_weight_group(wg, 4, stream));
     }
     if (!one_group || dx_tgt == dout) side_join(sa, st, 0);    // fc2's weight gradient has read dout before an in-place ln_pool_bwd overwrites it
+#ifndef CFFM_EMU
+    if (g_side.dw_pending[par ^ 1] && g_side.dw_dout[par ^ 1] == dx_tgt) {   // (depth >= 3: the block before still reads its dout = our dx_tgt)
+        side_wait(st, g_side.dw_done[par ^ 1]);
+        g_side.dw_pending[par ^ 1] = false;
+    }
+#endif
     // CFFA
     TRY(cffm_ln_pool_bwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1,
                          dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, gr->norm1_w, gr->norm1_b, dM, gr->pool_b, stream));
     // the record reductions (every block-partial record of this backward is written by now) and the pooling-matrix backward:
     // parameter gradients only -> side stream (branch 3); the caller's stream then waits for the side stream once
+#ifndef CFFM_EMU
+    if (defer && sp && sb != st && s1 == sb && g_side.on && (fork_order() & 32)) {
+        side_fork_mark(st, 3);
+        (void)hipEventRecord(g_side.tail_order, sb);
+        g_tail.has = true; g_tail.jobs = g_rq.jobs; g_tail.dM = dM; g_tail.gr = gr; g_tail.parity = g_red_parity;
+        g_rq.jobs.njob = 0; g_rq.active = false;
+        g_side.dw_pending[par] = true;
+        g_side.dw_dout[par] = dout;
+        side_record(s1, st, g_side.bias_done[par]);
+        g_side.bias_pending[par] = true;
+        return 0;
+    }
+#endif
     hipStream_t s3 = sp ? side_fork(st, 3) : st;
     if (sp && sb != st && s3 != st) side_order(sb, s3);     // the q|k|v bias records come from branch 2's column sum
     if (sp && s1 != st && s3 != st && s1 != s3) side_order(s1, s3);   // (four side streams: branch 1 joins through branch 3)
@@ -1417,9 +1533,12 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     TRY(cffm_pool_matrix_bwd(dM, gr->pool_w, (void*)s3));
 #ifndef CFFM_EMU
     if (defer && sp && sb != st && s3 != st) {
-        side_wait(st, g_side.dw_done);                  // the weight-gradient GEMMs have read dqkv / dh / dout / dx1 and the saved activations
-        side_record(s1, st, g_side.bias_done);
-        g_side.bias_pending = s1 != st;
+        // (no wait for the weight-gradient GEMMs: the next block works in the other scratch set; whoever reuses THIS set, or writes
+        //  the `dout` they read, waits for dw_done[par] then)
+        g_side.dw_pending[par] = true;
+        g_side.dw_dout[par] = dout;
+        side_record(s1, st, g_side.bias_done[par]);
+        g_side.bias_pending[par] = s1 != st;
         side_record(s3, st, g_side.tail_done[g_red_parity]);
         g_side.tail_pending[g_red_parity] = true;
         return 0;
@@ -1840,6 +1959,7 @@ int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_par
     const Scratch S = scratch_layout(g);
     const long HW = g->HW, img = HW * CFFM_C;
     const float* blk0 = saved + up((long)g->B * 4 * img);
+    tail_reset();
     for (int i = depth - 1; i >= 0; --i) {
         const float* ws = blk0 + (long)i * L.total;
         const float* tgt = (i == 0) ? x_rows + 3 * img : blk0 + (long)(i - 1) * L.total + L.x2;
@@ -1851,8 +1971,9 @@ int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_par
         // the last block reads the caller's gradient directly
         const float* dout = (i == depth - 1) ? dy_rows : scratch + (((depth - 1 - i) & 1) ? S.a2 : S.a);
         TRY(block_backward_impl(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_rows,
-                                4 * img, i != depth - 1, dtgt, dtgt_bs, scratch, 1, stream));
+                                4 * img, i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
     }
+    TRY(tail_flush((hipStream_t)stream));
     side_join_all((hipStream_t)stream);
     return 0;
 }
@@ -1925,6 +2046,7 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
     float* dxs = scratch + S.dxs;   // NHWC gradient stack [B,4,HW,C]
     REQUIRE(dy_bs >= img, "layer_backward: dy batch stride %ld < %ld", dy_bs, img);
     if (first_block == depth - 1) TRY(cffm_transpose(dy_tgt_nchw, scratch + S.a, g->B, CFFM_C, (int)HW, dy_bs, img, stream));
+    tail_reset();
     for (int i = first_block; i >= last_block; --i) {
         const float* ws = blk0 + (long)i * L.total;
         const float* tgt = (i == 0) ? xs + 3 * img : blk0 + (long)(i - 1) * L.total + L.x2;
@@ -1936,10 +2058,11 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
         float* dtgt = (i == 0) ? dxs + 3 * img : scratch + (((depth - i) & 1) ? S.a2 : S.a);
         const long dtgt_bs = (i == 0) ? 4 * img : img;
         TRY(block_backward_impl(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dcur, dxs, 4 * img,
-                                i != depth - 1, dtgt, dtgt_bs, scratch, 1, stream));
+                                i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
     }
     // (dy_full: the upstream gradient of the whole [B,4,C,H,W] output -- its pass-through frames 0..2 join dx in the same pass)
     if (last_block == 0) TRY(transpose_add(dxs, dx_nchw, g->B * 4, (int)HW, CFFM_C, img, img, dy_full, 4, 3, stream));
+    TRY(tail_flush((hipStream_t)stream));
     side_join_all((hipStream_t)stream);   // every parameter gradient of the range is complete behind this point of the stream
     return 0;
 }
