@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 4
+#define CFFM_ABI_VERSION 5
 
 typedef struct cffm_geom {
     int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
@@ -358,6 +358,7 @@ int cffm_adamw_step_dev(const cffm_adamw_chunk* chunks /* device */, int nchunks
  *   state  [nrows][4] float : t, lr_t/(1-b1^t), 1/sqrt(1-b2^t), 1-lr_t*wd -- t advanced by the call (zero-initialise, or seed
  *                              with the step count of a resumed run)
  * grad_base as in cffm_adamw_step_dev. */
+#define CFFM_ADAMW_TICKETS 65
 typedef struct {
     float* p;
     const float* g;
@@ -366,9 +367,12 @@ typedef struct {
     int n;              /* 1..CFFM_ADAMW_CHUNK elements */
     int row;            /* row of consts / sched / state */
 } cffm_adamw_chunk2;
-/* active_rows (device, [nrows] ints, or NULL = every row): only rows that own a chunk of this call advance their step count */
+/* active_rows (device, [nrows] ints, or NULL = every row): only rows that own a chunk of this call advance their step count.
+ * ticket (device int[CFFM_ADAMW_TICKETS], zero before the first call, or NULL): with tickets the step count is advanced INSIDE the update
+ * launch (one kernel; the workgroup that finishes last stores the new state) -- same results as the two-launch form used without.
+ * sched is read by the device when the launch runs: it may be device memory or pinned, device-visible host memory. */
 int cffm_adamw_step_rows(const cffm_adamw_chunk2* chunks /* device */, int nchunks, const float* grad_base, float* state,
-                         const float* sched, const double* consts, int nrows, const int* active_rows, void* stream);
+                         const float* sched, const double* consts, int nrows, const int* active_rows, int* ticket, void* stream);
 
 #ifdef __cplusplus
 }

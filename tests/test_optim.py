@@ -43,6 +43,38 @@ def test_adamw_emulated():
         run_adamw(torch.device('cpu'))
 
 
+def run_adamw_fused_tick_equals_two_launches(device, steps=7):
+    """cffm_adamw_step_rows with tickets (the step count advanced inside the update launch, whole chunks prefetched before the row's
+    factors are worked out) and without (tick kernel + update kernel): the same parameters and moments, bit for bit, and the same
+    device-side step count -- also when a parameter sits out steps (its row must not advance)."""
+    gen = torch.Generator().manual_seed(15)
+    base = [torch.randn(*s, generator=gen) for s in SHAPES]
+    opts, params = [], []
+    for fused in (True, False):
+        ps = [torch.nn.Parameter(t.clone().to(device)) for t in base]
+        o = V.optim.AdamW([{'params': ps[:3], 'lr': 2e-3}, {'params': ps[3:], 'weight_decay': 0.0}], lr=1e-3, weight_decay=0.02)
+        o.fused_tick = fused
+        o.set_poly_schedule(max_iters=50, power=1.0, min_lr=0.0, warmup_iters=3, warmup_ratio=1e-3)
+        opts.append(o)
+        params.append(ps)
+    for it in range(steps):
+        gs = [torch.randn(t.shape, generator=gen) for t in base]
+        for o, ps in zip(opts, params):
+            for i, (q, g) in enumerate(zip(ps, gs)):
+                q.grad = None if (i == 1 and it % 3 == 1) else g.clone().to(device)
+            o.step()
+    for a, b in zip(*params):
+        assert torch.equal(a.detach(), b.detach())
+        assert torch.equal(opts[0].state[a]['exp_avg_sq'], opts[1].state[b]['exp_avg_sq'])
+    assert opts[0].state_dict()['state'][1]['step'] == opts[1].state_dict()['state'][1]['step'] == steps - 2
+    assert opts[0].device_step_count() == opts[1].device_step_count() == steps
+
+
+def test_adamw_fused_tick_equals_two_launches_emulated():
+    with emu.active():
+        run_adamw_fused_tick_equals_two_launches(torch.device('cpu'))
+
+
 def run_adamw_shared_buffer(device, steps=5):
     """Gradients that alias ONE buffer (what the layer's backward produces): the table holds offsets, the buffer may move."""
     gen = torch.Generator().manual_seed(6)
@@ -289,6 +321,7 @@ def test_adamw_gpu():
     run_adamw_shared_buffer(torch.device('cuda:0'), steps=6)
     run_adamw_resume(torch.device('cuda:0'))
     run_adamw_groups_and_schedule(torch.device('cuda:0'))
+    run_adamw_fused_tick_equals_two_launches(torch.device('cuda:0'))
 
 
 @pytest.mark.gpu

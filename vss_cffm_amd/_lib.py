@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, ci, cl, cd, cf = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
 
@@ -109,7 +109,7 @@ SIGNATURES = {
     'cffm_upce_maps_bwd': (ci, [vp, vp, vp, vp, vp, vp, C.c_float, vp, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, ci, ci, vp]),
     'cffm_adamw_step': (ci, [vp, ci, cd, cd, cd, cd, cd, ci, vp]),
     'cffm_adamw_step_dev': (ci, [vp, ci, vp, cd, cd, cd, cd, cd, vp, vp]),
-    'cffm_adamw_step_rows': (ci, [vp, ci, vp, vp, vp, vp, ci, vp, vp]),
+    'cffm_adamw_step_rows': (ci, [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
 }
 
 

@@ -97,22 +97,20 @@ __device__ __forceinline__ void cell_geom(int g, int& grp, int& u, int& v, int& 
 struct PoolW { const float* w[4]; };  // pool_layers.0, pool_layers_clips.{0,1,2} weights
 struct PoolWG { float* w[4]; };
 
+// entry (cell g, window pixel i) of the pooling matrix
+__device__ __forceinline__ float pool_matrix_entry(const PoolW& pw, int g, int i) {
+    const int py = i / 7, px = i % 7;
+    int grp, u, v, wsg;
+    cell_geom(g, grp, u, v, wsg);
+    if (grp < 2) return pw.w[grp][i];
+    float m = 0.f;
+    for (int a = 0; a < wsg; ++a)
+        for (int b = 0; b < wsg; ++b)
+            m += pw.w[grp][a * wsg + b] * bil_tap(wsg * u + a, py) * bil_tap(wsg * v + b, px);
+    return m;
+}
 __device__ __forceinline__ void pool_matrix_body(const PoolW& pw, float* __restrict__ M) {
-    for (int e = threadIdx.x; e < CFFM_NCELL * CFFM_WA; e += 256) {
-        const int g = e / CFFM_WA, i = e % CFFM_WA, py = i / 7, px = i % 7;
-        int grp, u, v, wsg;
-        cell_geom(g, grp, u, v, wsg);
-        float m;
-        if (grp < 2) {
-            m = pw.w[grp][i];
-        } else {
-            m = 0.f;
-            for (int a = 0; a < wsg; ++a)
-                for (int b = 0; b < wsg; ++b)
-                    m += pw.w[grp][a * wsg + b] * bil_tap(wsg * u + a, py) * bil_tap(wsg * v + b, px);
-        }
-        M[e] = m;
-    }
+    for (int e = threadIdx.x; e < CFFM_NCELL * CFFM_WA; e += 256) M[e] = pool_matrix_entry(pw, e / CFFM_WA, e % CFFM_WA);
 }
 
 __global__ void __launch_bounds__(256) k_pool_matrix(PoolW pw, float* __restrict__ M) { pool_matrix_body(pw, M); }
@@ -186,7 +184,7 @@ __device__ __forceinline__ int frame_group(int frame) { return frame == 3 ? 0 : 
 __global__ void __launch_bounds__(LNP_THREADS, 6) k_ln_pool_fwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
                                                       const float* __restrict__ x_tgt, long tgt_bs,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ M, PoolB pb,
+                                                      const float* __restrict__ M /* or NULL: built here from pw */, PoolW pw, PoolB pb,
                                                       float* __restrict__ zall, float* __restrict__ mean_out,
                                                       float* __restrict__ rstd_out, int split /* zall rows in split-4 storage */) {
     __shared__ float sM[9 * CFFM_WA];
@@ -196,7 +194,8 @@ __global__ void __launch_bounds__(LNP_THREADS, 6) k_ln_pool_fwd(Geo G, const flo
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int g0, ncell;
     frame_cells(frame, g0, ncell);
-    for (int e = threadIdx.x; e < ncell * CFFM_WA; e += LNP_THREADS) sM[e] = M[g0 * CFFM_WA + e];
+    // (M == NULL: the first block of a layer forward, so that this kernel does not wait for the side-stream parameter prep)
+    for (int e = threadIdx.x; e < ncell * CFFM_WA; e += LNP_THREADS) sM[e] = M ? M[g0 * CFFM_WA + e] : pool_matrix_entry(pw, g0 + e / CFFM_WA, e % CFFM_WA);
     __syncthreads();
     const float* xf = (frame == 3) ? x_tgt + (long)b * tgt_bs : x_ref + (long)b * ref_bs + (long)frame * G.HW * CFFM_C;
     const f32x4 gm = *(const f32x4*)(gamma + 4 * lane), bt = *(const f32x4*)(beta + 4 * lane);

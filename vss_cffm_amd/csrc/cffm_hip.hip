@@ -318,7 +318,7 @@ struct SideStream {
                                 // 1 / 3 (the small kernels) do not queue behind each other
 #ifndef CFFM_EMU
     hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[2] = {nullptr, nullptr}, order = nullptr, tail_order = nullptr;
+    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[2] = {nullptr, nullptr}, order = nullptr, tail_order = nullptr, cs_order = nullptr;
     // deferred join of a block backward (layer_backward_impl): what the NEXT block has to wait for
     hipEvent_t dw_done[2] = {nullptr, nullptr}, bias_done[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, join_all[4] = {nullptr, nullptr, nullptr, nullptr};
     bool bias_pending[2] = {false, false}, dw_pending[2] = {false, false}, tail_pending[2] = {false, false};
@@ -358,7 +358,8 @@ static bool side_init(hipStream_t main) {
         auto mk = [&](hipStream_t* st_) { return (low ? hipStreamCreateWithPriority(st_, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(st_, hipStreamNonBlocking)) == hipSuccess; };
         if (!(e && e[0] == '0') && mk(&g_side.st[0]) && mk(&g_side.st[1]) && mk(&g_side.st[2]) && mk(&g_side.st[3])) {
             bool ok = hipEventCreateWithFlags(&g_side.order, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&g_side.tail_order, hipEventDisableTiming) == hipSuccess;
+                      hipEventCreateWithFlags(&g_side.tail_order, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&g_side.cs_order, hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 2; ++i) ok = ok && hipEventCreateWithFlags(&g_side.tail_done[i], hipEventDisableTiming) == hipSuccess;
@@ -380,20 +381,22 @@ static bool side_init(hipStream_t main) {
 // sooner).  Launched eagerly the side stream really runs beside the chain and `split` wins (0.886 vs 0.911 ms per step); a replayed
 // HIP graph executes its branches almost serially, so there the cheaper `one` wins (0.927 vs 0.950).  Default: by whether the
 // caller's stream is being captured; CFFM_DW_GROUP=one|split forces a form.
-// How the side work of a block backward is attached to the chain (bit mask; default 38 = 2 | 4 | 32, the rest for A/B measurements).
+// How the side work of a block backward is attached to the chain (bit mask; default 35 = 1 | 2 | 32, the rest for A/B measurements).
 // Under stream capture the graph executor (ROCm 7.2) gives a node's FIRST-captured dependant the node's own stream and every further
 // dependant the next of its (four) streams, depth first -- so whatever is launched first behind a fork stays on the chain's stream,
 // and side branches that reach the same stream number run one after the other in topological order.  The chain must therefore be
 // launched first at every fork and must never wait for a side branch inside the step:
-//   bit 0  the dK/dV gather is launched before the bias-tile sum of the attention backward        (superseded by bit 2)
+//   bit 0  the dK/dV gather is launched before the bias-tile sum of the attention backward
 //   bit 1  the q|k|v input-gradient GEMM is launched before the column sum / weight-gradient group
 //   bit 2  the bias-tile sum + scatter get no branch of their own: they follow the weight-gradient group on its stream
 //   bit 5  the record reductions + pooling-matrix backward are launched only after the NEXT chain kernel (tail_flush)
 // Measured (B = 2, depth 2, replayed graph, same box): 0 -> 0.830-0.833 ms per step, 4 -> 0.808-0.810, 38 (with the two scratch sets
-// of scratch_layout, so that no block waits for the previous block's weight gradients) -> 0.798-0.811 against 0.821-0.848 for 4.
+// of scratch_layout, so that no block waits for the previous block's weight gradients) -> 0.798-0.811 against 0.821-0.848 for 4;
+// 35 (the bias-tile sum early again, now that every side branch lands on the same graph stream in launch order: it runs in the idle
+// stretch beside the gather instead of behind the weight gradients on the step's tail) -> 0.773-0.785 against 0.783-0.786 for 38.
 static int fork_order() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_FORK_ORDER"); v = e ? atoi(e) : 38; }
+    if (v < 0) { const char* e = getenv("CFFM_FORK_ORDER"); v = e ? atoi(e) : 35; }
     return v;
 }
 static int dw_one_group(hipStream_t st) {
@@ -605,13 +608,14 @@ int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream)
 // functions always write plain fp32, the block orchestration asks for split-4 when the hand-written GEMMs are in use
 static int ln_pool_fwd_impl(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
                             const float* gamma, const float* beta, const float* M, const float* const pool_b[4],
-                            float* zall, float* mean, float* rstd, int split, void* stream) {
+                            float* zall, float* mean, float* rstd, int split, void* stream, const float* const* pool_w = nullptr) {
     PROF(ST_LN_POOL_FWD);
     REQUIRE(g && x_ref && x_tgt && zall, "ln_pool_fwd: null");
     PoolB pb;
-    for (int i = 0; i < 4; ++i) pb.b[i] = pool_b[i];
+    PoolW pw;
+    for (int i = 0; i < 4; ++i) { pb.b[i] = pool_b[i]; pw.w[i] = pool_w ? pool_w[i] : nullptr; }
     CFFM_LAUNCH(k_ln_pool_fwd, (g->nW, 4, g->B), (LNP_THREADS), 0, (hipStream_t)stream, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma,
-                beta, M, pb, zall, mean, rstd, split);
+                beta, pool_w ? nullptr : M, pw, pb, zall, mean, rstd, split);
     CHECK_LAUNCH("ln_pool_fwd");
     return 0;
 }
@@ -962,13 +966,18 @@ int cffm_adamw_step_dev(const cffm_adamw_chunk* chunks, int nchunks, const float
 }
 
 int cffm_adamw_step_rows(const cffm_adamw_chunk2* chunks, int nchunks, const float* grad_base, float* state, const float* sched,
-                         const double* consts, int nrows, const int* active_rows, void* stream) {
+                         const double* consts, int nrows, const int* active_rows, int* ticket, void* stream) {
     static_assert(sizeof(cffm_adamw_chunk2) == sizeof(AdamwChunk2), "chunk layout");
     if (nchunks <= 0) return 0;
     REQUIRE(chunks && state && sched && consts && nrows >= 1, "adamw_step_rows: null table or no rows");
     PROF(ST_ADAMW);
-    CFFM_LAUNCH(k_adamw_tick_rows, ((unsigned)((nrows + 63) / 64)), (64), 0, (hipStream_t)stream, state, sched, consts, nrows, active_rows);
-    CFFM_LAUNCH(k_adamw_rows, ((unsigned)nchunks), (256), 0, (hipStream_t)stream, (const AdamwChunk2*)chunks, grad_base, (const float*)state, consts);
+    if (ticket) {
+        CFFM_LAUNCH(k_adamw_rows_tick, ((unsigned)nchunks), (256), 0, (hipStream_t)stream, (const AdamwChunk2*)chunks, grad_base, state, sched, consts,
+                    nrows, active_rows, ticket);
+    } else {
+        CFFM_LAUNCH(k_adamw_tick_rows, ((unsigned)((nrows + 63) / 64)), (64), 0, (hipStream_t)stream, state, sched, consts, nrows, active_rows);
+        CFFM_LAUNCH(k_adamw_rows, ((unsigned)nchunks), (256), 0, (hipStream_t)stream, (const AdamwChunk2*)chunks, grad_base, (const float*)state, consts);
+    }
     CHECK_LAUNCH("adamw_rows");
     return 0;
 }
@@ -1170,6 +1179,7 @@ int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const flo
     return block_forward_impl(g, p, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, ws, scratch, stream);
 }
 // the block after its parameter-only inputs (ws.bias, ws.biasT, ws.M) have been prepared
+static struct { bool pending; hipStream_t side; } g_prep_join = {false, nullptr};
 static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, const float* x_ref, long ref_bs,
                               const float* x_tgt, long tgt_bs, const int* key_src, const int* q_dst, float* ws,
                               float* scratch, void* stream) {
@@ -1183,8 +1193,15 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     // which the attention backward also reads.  CFFM_GEMM=lib (rocBLAS cross-check) keeps everything plain fp32.
     const int sp = gemm_use_lib() ? 0 : 1;
     const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
+    // (a pending join with the side-stream parameter prep -- layer_forward_impl -- is taken AFTER this launch: the kernel builds its
+    //  pooling-matrix rows from the raw weights then, and the chain's first kernel does not wait for another stream)
+    const bool late_join = g_prep_join.pending;
     TRY(ln_pool_fwd_impl(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, p->pool_b, ws + L.zall,
-                         ws + L.mean1, ws + L.rstd1, sp, stream));
+                         ws + L.mean1, ws + L.rstd1, sp, stream, late_join ? p->pool_w : nullptr));
+    if (late_join) {
+        g_prep_join.pending = false;
+        side_join(g_prep_join.side, st, 0);
+    }
     if (sp && panel_qkv_on()) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
         REQUIRE(!panel_qkv_fwd(ws + L.zall, ws + L.w_frag, p->qkv_b, (h16*)(ws + L.qkv), NR, st), "block_forward: qkv gemm failed");
@@ -1243,21 +1260,33 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
 // executor hands every further dependant of a node the next stream, see side_fork_mark).
 #ifndef CFFM_EMU
 static struct { bool has; RedJobs jobs; float* dM; const cffm_block_grads* gr; int parity; } g_tail = {false, {}, nullptr, nullptr, 0};
-static int tail_flush(hipStream_t st) {
+// on_main (end of a layer backward): the optimizer is what waits for these gradients, so they are the chain now -- launched on the
+// caller's stream itself, in front of everything else that follows the last ln_pool_bwd
+static int tail_flush(hipStream_t st, bool on_main = false) {
     if (!g_tail.has) return 0;
     g_tail.has = false;
-    hipStream_t s3 = side_fork_take(st, 3);
-    if (s3 != st) (void)hipStreamWaitEvent(s3, g_side.tail_order, 0);   // the q|k|v bias records (column sum on the weight-gradient stream)
+    hipStream_t s3 = on_main ? st : side_fork_take(st, 3);
+    // the q|k|v bias records come from the column sum on the weight-gradient stream.  On a side stream the tail waits for that stream's
+    // whole block (tail_order: the graph executor then queues it right behind the block's side work; waiting for the column sum alone
+    // it was queued behind the NEXT block's side work); on the caller's stream only for the column sum (cs_order)
+    (void)hipStreamWaitEvent(s3, on_main ? g_side.cs_order : g_side.tail_order, 0);
     redq_launch(g_tail.jobs, s3);
     CHECK_LAUNCH("block_backward reductions");
     TRY(cffm_pool_matrix_bwd(g_tail.dM, g_tail.gr->pool_w, (void*)s3));
-    side_record(s3, st, g_side.tail_done[g_tail.parity]);
-    g_side.tail_pending[g_tail.parity] = true;
+    if (s3 != st) {
+        side_record(s3, st, g_side.tail_done[g_tail.parity]);
+        g_side.tail_pending[g_tail.parity] = true;
+    }
     return 0;
 }
 #else
-static int tail_flush(hipStream_t) { return 0; }
+static int tail_flush(hipStream_t, bool = false) { return 0; }
 #endif
+static bool tail_on_main() {     // CFFM_TAIL_MAIN=0: the last block's tail on the side stream like every other block's (A/B)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFFM_TAIL_MAIN"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
 static void tail_reset() {      // entry of a layer backward: nothing of a previous (failed) call is left to launch
 #ifndef CFFM_EMU
     g_tail.has = false;
@@ -1447,6 +1476,9 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         sb = dx_done ? side_fork_take(st, 2) : side_fork(st, 2);
         void* stream_b = (void*)sb;
         TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream_b));
+#ifndef CFFM_EMU
+        if (sb != st) (void)hipEventRecord(g_side.cs_order, sb);
+#endif
         if (one_group) {
             // ALL four weight gradients as one grouped launch (~480 workgroups with one slice length, one partial-sum launch: 59 us
             // where two groups of two take 2 x 53), on the side stream beside q|k|v's input gradient and the CFFA backward; every
@@ -1513,8 +1545,9 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     // the record reductions (every block-partial record of this backward is written by now) and the pooling-matrix backward:
     // parameter gradients only -> side stream (branch 3); the caller's stream then waits for the side stream once
 #ifndef CFFM_EMU
-    if (defer && sp && sb != st && s1 == sb && g_side.on && (fork_order() & 32)) {
+    if (defer && sp && sb != st && s1 != st && g_side.on && (fork_order() & 32)) {
         side_fork_mark(st, 3);
+        if (s1 != sb) side_order(s1, sb);
         (void)hipEventRecord(g_side.tail_order, sb);
         g_tail.has = true; g_tail.jobs = g_rq.jobs; g_tail.dM = dM; g_tail.gr = gr; g_tail.parity = g_red_parity;
         g_rq.jobs.njob = 0; g_rq.active = false;
@@ -1973,7 +2006,7 @@ int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_par
         TRY(block_backward_impl(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_rows,
                                 4 * img, i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
     }
-    TRY(tail_flush((hipStream_t)stream));
+    TRY(tail_flush((hipStream_t)stream, tail_on_main()));
     side_join_all((hipStream_t)stream);
     return 0;
 }
@@ -1998,7 +2031,13 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
     hipStream_t sd = side_fork_take(st, 0);
     TRY(param_prep(params, depth, blk0, L.total, L, (void*)sd));
     side_mark(sd, st, 0);
-    side_join(sd, st, 0);
+    {
+        static int early = -1;           // CFFM_PREP_JOIN=early: join in front of the first block (A/B)
+        if (early < 0) { const char* e = getenv("CFFM_PREP_JOIN"); early = (e && e[0] == 'e') ? 1 : 0; }
+        g_prep_join.pending = sd != st && !early;      // joined behind the first block's ln_pool_fwd (block_forward_impl)
+        g_prep_join.side = sd;
+        if (!g_prep_join.pending) side_join(sd, st, 0);
+    }
 #ifndef CFFM_EMU
     g_side.used = 0;   // (that was this call's only side branch, joined here)
 #endif
@@ -2061,7 +2100,14 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
                                 i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
     }
     // (dy_full: the upstream gradient of the whole [B,4,C,H,W] output -- its pass-through frames 0..2 join dx in the same pass)
-    if (last_block == 0) TRY(transpose_add(dxs, dx_nchw, g->B * 4, (int)HW, CFFM_C, img, img, dy_full, 4, 3, stream));
+    if (last_block == 0) {
+        // the last block's parameter-gradient tail stays on the caller's stream, in front of the output transpose: no fork behind the
+        // last ln_pool_bwd at all (the transpose on a side stream of its own was queued AHEAD of the blocks' side work by the graph
+        // executor and held it up until the chain had finished: 0.95 ms per step)
+        hipStream_t st = (hipStream_t)stream;
+        if (tail_on_main()) TRY(tail_flush(st, true));
+        TRY(transpose_add(dxs, dx_nchw, g->B * 4, (int)HW, CFFM_C, img, img, dy_full, 4, 3, stream));
+    }
     TRY(tail_flush((hipStream_t)stream));
     side_join_all((hipStream_t)stream);   // every parameter gradient of the range is complete behind this point of the stream
     return 0;

@@ -176,6 +176,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 #define gridDim (emu::g_blk->gdim)
 
 static inline void __syncthreads() { emu::block_barrier(); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 template <class T>
 static inline T __shfl(T v, int src, int width = 64) {

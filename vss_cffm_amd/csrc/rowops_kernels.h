@@ -567,30 +567,59 @@ struct AdamwChunk2 { float* p; const float* g; float* m; float* v; int n; int ro
 // `active` (or NULL = every row): rows that own a chunk of THIS step's table.  A row whose parameters got no gradient this step keeps
 // its step count -- torch's per-parameter step does not advance either -- so its bias correction and schedule iteration stay right
 // when it next takes part (a parameter with gradients on 3 of 8 steps was off by 3.8e-2 when every row ticked).
-__global__ void k_adamw_tick_rows(float* __restrict__ state, const float* __restrict__ sched, const double* __restrict__ consts, int nrows,
-                                  const int* __restrict__ active) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows || (active && !active[r])) return;
+// b^t for an integer-valued t >= 0 by squaring: ~40 multiplications where pow() is several hundred double-precision instructions --
+// with the tick folded into the update launch every workgroup evaluates this on ONE lane before its threads can start (libm pow: the
+// update launch took 27 us instead of 11).  Within ~1e-14 of pow(), far below the float rounding of the factors derived from it.
+__device__ __forceinline__ double adamw_ipow(double b, double t) {
+    long n = (long)t;
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= b;
+        b *= b;
+        n >>= 1;
+    }
+    return r;
+}
+// the four state values of row r after its next step (t, lr_t / (1 - b1^t), 1 / sqrt(1 - b2^t), 1 - lr_t wd)
+__device__ __forceinline__ void adamw_next_state(const float* __restrict__ state, const float* __restrict__ sched, const double* __restrict__ consts,
+                                                 int r, float out[4]) {
     const double* c = consts + (long)ADAMW_NCONST * r;
     const double t = (double)state[4 * r] + 1.0, wd = (double)sched[2 * r + 1];
     double lr = (double)sched[2 * r];
     if (c[3] == 1.0) {                      // poly decay with linear warm-up, iteration it = t - 1 - first
         const double it = t - 1.0 - c[9], max_iters = c[4], min_lr = c[6], wi = c[7];
         const double frac = it < max_iters ? 1.0 - it / max_iters : 0.0;
-        lr = (lr - min_lr) * pow(frac, c[5]) + min_lr;
+        lr = (lr - min_lr) * (c[5] == 1.0 ? frac : pow(frac, c[5])) + min_lr;
         if (it < wi) lr *= 1.0 - (1.0 - it / wi) * (1.0 - c[8]);
         if (it < 0.0) lr = 0.0;
     }
-    state[4 * r] = (float)t;
-    state[4 * r + 1] = (float)(lr / (1.0 - pow(c[0], t)));
-    state[4 * r + 2] = (float)(1.0 / sqrt(1.0 - pow(c[1], t)));
-    state[4 * r + 3] = (float)(1.0 - lr * wd);
+    out[0] = (float)t;
+    out[1] = (float)(lr / (1.0 - adamw_ipow(c[0], t)));
+    out[2] = (float)(1.0 / sqrt(1.0 - adamw_ipow(c[1], t)));
+    out[3] = (float)(1.0 - lr * wd);
 }
-__global__ void __launch_bounds__(256) k_adamw_rows(const AdamwChunk2* __restrict__ chunks, const float* __restrict__ grad_base,
-                                                     const float* __restrict__ state, const double* __restrict__ consts) {
-    AdamwChunk2 c = chunks[blockIdx.x];
+__global__ void k_adamw_tick_rows(float* __restrict__ state, const float* __restrict__ sched, const double* __restrict__ consts, int nrows,
+                                  const int* __restrict__ active) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows || (active && !active[r])) return;
+    float o[4];
+    adamw_next_state(state, sched, consts, r, o);
+    state[4 * r] = o[0]; state[4 * r + 1] = o[1]; state[4 * r + 2] = o[2]; state[4 * r + 3] = o[3];
+}
+// one element of the update; no FMA contraction, so that every caller rounds the same way whatever the surrounding code looks like
+// (the prefetching form of k_adamw_rows_tick and the loop below must agree bit for bit)
+__device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g, float beta1, float omb1, float beta2, float omb2, float decay,
+                                           float step_size, float inv_sqrt_bc2, float eps) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+    m = beta1 * m + omb1 * g;
+    v = beta2 * v + omb2 * g * g;
+    p = p * decay - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+}
+__device__ __forceinline__ void adamw_update_chunk(AdamwChunk2 c, const float* __restrict__ grad_base, float step_size, float inv_sqrt_bc2,
+                                                   float decay, const double* __restrict__ consts) {
     if (grad_base) c.g = (const float*)((const char*)grad_base + (uintptr_t)c.g);
-    const float step_size = state[4 * c.row + 1], inv_sqrt_bc2 = state[4 * c.row + 2], decay = state[4 * c.row + 3];
     const double b1 = consts[ADAMW_NCONST * c.row], b2 = consts[ADAMW_NCONST * c.row + 1];
     const float beta1 = (float)b1, beta2 = (float)b2, omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2), eps = (float)consts[ADAMW_NCONST * c.row + 2];
     const bool vec = (((uintptr_t)c.p | (uintptr_t)c.g | (uintptr_t)c.m | (uintptr_t)c.v) & 15) == 0;
@@ -600,16 +629,84 @@ __global__ void __launch_bounds__(256) k_adamw_rows(const AdamwChunk2* __restric
         const f32x4 g = ((const f32x4*)c.g)[e];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            m[k] = beta1 * m[k] + omb1 * g[k];
-            v[k] = beta2 * v[k] + omb2 * g[k] * g[k];
-            p[k] = p[k] * decay - step_size * (m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps));
+            float pk = p[k], mk = m[k], vk = v[k];
+            adamw_elem(pk, mk, vk, g[k], beta1, omb1, beta2, omb2, decay, step_size, inv_sqrt_bc2, eps);
+            p[k] = pk; m[k] = mk; v[k] = vk;
         }
         ((f32x4*)c.p)[e] = p; ((f32x4*)c.m)[e] = m; ((f32x4*)c.v)[e] = v;
     }
     for (int e = 4 * n4 + threadIdx.x; e < c.n; e += 256) {
-        const float g = c.g[e];
-        const float m = beta1 * c.m[e] + omb1 * g, v = beta2 * c.v[e] + omb2 * g * g;
-        c.m[e] = m; c.v[e] = v;
-        c.p[e] = c.p[e] * decay - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+        float pk = c.p[e], mk = c.m[e], vk = c.v[e];
+        adamw_elem(pk, mk, vk, c.g[e], beta1, omb1, beta2, omb2, decay, step_size, inv_sqrt_bc2, eps);
+        c.m[e] = mk; c.v[e] = vk; c.p[e] = pk;
     }
+}
+__global__ void __launch_bounds__(256) k_adamw_rows(const AdamwChunk2* __restrict__ chunks, const float* __restrict__ grad_base,
+                                                     const float* __restrict__ state, const double* __restrict__ consts) {
+    const AdamwChunk2 c = chunks[blockIdx.x];
+    adamw_update_chunk(c, grad_base, state[4 * c.row + 1], state[4 * c.row + 2], state[4 * c.row + 3], consts);
+}
+// The same update with the step-count tick folded in (one launch instead of two on the tail of a training step): every workgroup
+// derives its row's factors from the state BEFORE the step (adamw_next_state: the arithmetic of k_adamw_tick_rows, so the results are
+// bit-identical); the workgroup that draws the last ticket -- all others have read the state by then -- stores the advanced state of
+// the active rows; the tickets are back at zero for the next launch.
+__global__ void __launch_bounds__(256) k_adamw_rows_tick(const AdamwChunk2* __restrict__ chunks, const float* __restrict__ grad_base,
+                                                          float* __restrict__ state, const float* __restrict__ sched,
+                                                          const double* __restrict__ consts, int nrows, const int* __restrict__ active,
+                                                          int* __restrict__ ticket) {
+    __shared__ float sc[4];
+    __shared__ int last;
+    AdamwChunk2 c = chunks[blockIdx.x];
+    const bool full = c.n == 2048 && (((uintptr_t)c.p | (uintptr_t)(grad_base ? (const float*)((const char*)grad_base + (uintptr_t)c.g) : c.g) | (uintptr_t)c.m | (uintptr_t)c.v) & 15) == 0;
+    if (full) {
+        // a whole aligned chunk (all but the last of a tensor): its 8 KB per operand are requested BEFORE lane 0 works out the row's
+        // factors (double-precision divisions and a square root on one lane: ~2 us that every thread of the workgroup would wait out)
+        if (grad_base) c.g = (const float*)((const char*)grad_base + (uintptr_t)c.g);
+        const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
+        f32x4 p0 = ((const f32x4*)c.p)[e0], m0 = ((const f32x4*)c.m)[e0], v0 = ((const f32x4*)c.v)[e0], p1 = ((const f32x4*)c.p)[e1],
+              m1 = ((const f32x4*)c.m)[e1], v1 = ((const f32x4*)c.v)[e1];
+        const f32x4 g0 = ((const f32x4*)c.g)[e0], g1 = ((const f32x4*)c.g)[e1];
+        if (threadIdx.x == 0) adamw_next_state(state, sched, consts, c.row, sc);
+        __syncthreads();
+        const float step_size = sc[1], inv_sqrt_bc2 = sc[2], decay = sc[3];
+        const double b1 = consts[ADAMW_NCONST * c.row], b2 = consts[ADAMW_NCONST * c.row + 1];
+        const float beta1 = (float)b1, beta2 = (float)b2, omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2), eps = (float)consts[ADAMW_NCONST * c.row + 2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = p0[k], mk = m0[k], vk = v0[k];
+            adamw_elem(pk, mk, vk, g0[k], beta1, omb1, beta2, omb2, decay, step_size, inv_sqrt_bc2, eps);
+            p0[k] = pk; m0[k] = mk; v0[k] = vk;
+            pk = p1[k]; mk = m1[k]; vk = v1[k];
+            adamw_elem(pk, mk, vk, g1[k], beta1, omb1, beta2, omb2, decay, step_size, inv_sqrt_bc2, eps);
+            p1[k] = pk; m1[k] = mk; v1[k] = vk;
+        }
+        ((f32x4*)c.p)[e0] = p0; ((f32x4*)c.m)[e0] = m0; ((f32x4*)c.v)[e0] = v0;
+        ((f32x4*)c.p)[e1] = p1; ((f32x4*)c.m)[e1] = m1; ((f32x4*)c.v)[e1] = v1;
+    } else {
+        if (threadIdx.x == 0) adamw_next_state(state, sched, consts, c.row, sc);
+        __syncthreads();
+        adamw_update_chunk(c, grad_base, sc[1], sc[2], sc[3], consts);
+    }
+    // (no fence: the state values were consumed above, so those loads are complete before the ticket is drawn, and nothing this
+    //  workgroup wrote is read by another one -- a device-scope fence here would write back the XCD's whole L2 per workgroup: 80 us)
+    // Tickets in two levels (ticket[1 + slot], slot = workgroup % 64, then ticket[0]): ~2000 device-scope atomics on ONE address cost
+    // more than the update itself (the launch took 25 us instead of 11).
+    if (threadIdx.x == 0) {
+        const int slot = blockIdx.x & 63, quota = ((int)gridDim.x - slot + 63) / 64, nslots = (int)gridDim.x < 64 ? (int)gridDim.x : 64;
+        int l = 0;
+        if (atomicAdd(ticket + 1 + slot, 1) == quota - 1) {
+            ticket[1 + slot] = 0;
+            l = atomicAdd(ticket, 1) == nslots - 1;
+        }
+        last = l;
+    }
+    __syncthreads();
+    if (!last) return;
+    for (int r = threadIdx.x; r < nrows; r += 256) {
+        if (active && !active[r]) continue;
+        float o[4];
+        adamw_next_state(state, sched, consts, r, o);
+        state[4 * r] = o[0]; state[4 * r + 1] = o[1]; state[4 * r + 2] = o[2]; state[4 * r + 3] = o[3];
+    }
+    if (threadIdx.x == 0) *ticket = 0;
 }

@@ -8,13 +8,14 @@ into 2048-element chunks listed in one device table, and a single kernel (``cffm
 walks the table with one workgroup per chunk.  A chunk names the ROW of three small device tables it is updated with:
 
 * ``consts`` (beta1, beta2, eps) -- written when the row is made;
-* ``sched`` (lr, weight decay) -- a device copy of a pinned host mirror that ``step()`` fills from ``param_groups``.  The
-  copy is issued by ``step()`` on the current stream, so when the training step is captured in a HIP graph it becomes a
-  memcpy node of that graph: a host-side LR scheduler changes ``param_groups[i]['lr']`` and calls ``refresh_hyper()``
-  (a host write, no launch) between replays; the reference's own schedule (poly decay + linear warm-up) can instead be
-  evaluated on the device from the step count (``set_poly_schedule``): no host write, nothing to order;
-* ``state`` (step count t and the factors derived from it) -- advanced on the device by a one-wave kernel in front of the
-  update, so every replay of a captured step uses the right bias correction.  ``state[p]['step']`` is the host-side
+* ``sched`` (lr, weight decay) -- a pinned host mirror that ``step()`` fills from ``param_groups``.  Eager steps copy it to
+  the device on the current stream; a step captured in a HIP graph reads the mirror itself when a replay executes it
+  (``zero_copy_sched``; False: a memcpy node of the graph): a host-side LR scheduler changes ``param_groups[i]['lr']`` and
+  calls ``refresh_hyper()`` (a host write, no launch) between replays; the reference's own schedule (poly decay + linear
+  warm-up) can instead be evaluated on the device from the step count (``set_poly_schedule``): no host write, nothing to order;
+* ``state`` (step count t and the factors derived from it) -- advanced on the device inside the update launch (``fused_tick``:
+  the last workgroup to finish stores it; False: a one-wave kernel in front of the update), so every replay of a captured step
+  uses the right bias correction.  ``state[p]['step']`` is the host-side
   mirror; it does not advance during graph replays and is re-read from the device by ``state_dict()``.
 
 A row is a (parameter group, step count) pair: parameters that first receive a gradient later than the rest of their group
@@ -29,6 +30,7 @@ moments), and ``load_state_dict`` / ``add_param_group`` drop every cached table 
 No CPU path: the moments and the tables live on the parameters' device and the step fails loudly without the HIP library.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -51,6 +53,7 @@ class _DeviceRows:
         self.schedule = None      # device-side schedule fields (consts[3:10]) given to rows made later
         self.inflight = []        # pinned staging buffers of eager-mode `sched` copies that may still be queued
         self.members = {}         # row -> ids of the parameters updated with it
+        self.ticket = torch.zeros(65, dtype=torch.int32, device=device)   # workgroup tickets of the fused tick + update launch (CFFM_ADAMW_TICKETS)
 
     def row_for(self, gi, step, group):
         for r, (g, t) in enumerate(self.rows):
@@ -104,6 +107,11 @@ class _DeviceRows:
 
 
 class AdamW(torch.optim.Optimizer):
+    # step count advanced inside the update launch (include/cffm_hip.h, cffm_adamw_step_rows `ticket`); CFFM_ADAMW_FUSED=0: two launches
+    fused_tick = os.environ.get('CFFM_ADAMW_FUSED', '1') != '0'
+    # captured steps read (lr, weight decay) from the pinned host mirror directly instead of through a memcpy node (CFFM_ADAMW_ZEROCOPY=0)
+    zero_copy_sched = os.environ.get('CFFM_ADAMW_ZEROCOPY', '1') != '0'
+
     def __init__(self, params, lr=6e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError('invalid AdamW hyper-parameters')
@@ -282,7 +290,13 @@ class AdamW(torch.optim.Optimizer):
             self.refresh_hyper()
             capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
             now = dr.sched_host.clone() if not capturing else None
-            if capturing:
+            sched_ptr = None
+            if capturing and self.zero_copy_sched:
+                # the update kernel reads the pinned mirror itself when a replay executes it (what the memcpy node below did, without
+                # the node: 4 us of copy + two dependent-launch gaps on the tail of every step)
+                sched_ptr = dr.sched_host.data_ptr()
+                dr.sched_sent = None
+            elif capturing:
                 dr.sched.copy_(dr.sched_host, non_blocking=True)     # a memcpy node: replays re-read the mirror
                 dr.sched_sent = None
             elif dr.sched_sent is None or not torch.equal(now, dr.sched_sent):
@@ -298,8 +312,9 @@ class AdamW(torch.optim.Optimizer):
             tab, active, gbase = self._table(dr, ps, rows)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == 'cuda' else C.c_void_p(0)
             _lib.check(lib.cffm_adamw_step_rows(C.c_void_p(tab.data_ptr()), tab.shape[0], C.c_void_p(gbase),
-                                                C.c_void_p(dr.state.data_ptr()), C.c_void_p(dr.sched.data_ptr()),
-                                                C.c_void_p(dr.consts.data_ptr()), len(dr.rows), C.c_void_p(active.data_ptr()), stream), lib)
+                                                C.c_void_p(dr.state.data_ptr()), C.c_void_p(sched_ptr or dr.sched.data_ptr()),
+                                                C.c_void_p(dr.consts.data_ptr()), len(dr.rows), C.c_void_p(active.data_ptr()),
+                                                C.c_void_p(dr.ticket.data_ptr()) if self.fused_tick else None, stream), lib)
         return loss
 
     def device_step_count(self, group=0):
