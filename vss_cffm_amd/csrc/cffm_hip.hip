@@ -1051,7 +1051,7 @@ static int panel_mt(long M) {
 extern "C++" {
 template <int MT, int NTW, bool A_PRE, int EPI>
 static int panel_gemm_launch(const float* A, int lda, long M, int K, const float* wf, float* Cout, int ldc, const float* bias, void* aux,
-                             hipStream_t st) {
+                             hipStream_t st, float* colrec = nullptr) {
     auto kern = k_panel_gemm<MT, NTW, 2, 4, A_PRE, EPI>;
 #ifndef CFFM_EMU
     static bool granted = false;
@@ -1060,7 +1060,7 @@ static int panel_gemm_launch(const float* A, int lda, long M, int K, const float
         granted = true;
     }
 #endif
-    CFFM_LAUNCH(kern, ((unsigned)((M + 16 * MT - 1) / (16 * MT))), (PNL_THREADS), PNL_LDS(MT), st, A, lda, (int)M, K, (const f32x4*)wf, Cout, ldc, bias, aux);
+    CFFM_LAUNCH(kern, ((unsigned)((M + 16 * MT - 1) / (16 * MT))), (PNL_THREADS), PNL_LDS(MT), st, A, lda, (int)M, K, (const f32x4*)wf, Cout, ldc, bias, aux, colrec);
     return 0;
 }
 }  // extern "C++"
@@ -1069,13 +1069,20 @@ static int panel_qkv_fwd(const float* x_s, const float* wf, const float* b, h16*
     return panel_mt(M) == 3 ? panel_gemm_launch<3, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st)
                             : panel_gemm_launch<2, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st);
 }
-// dx[M][256] = dqkv[M][768] W, W fragment-ordered (input-gradient form)
-static int panel_qkv_dx(const float* dqkv, const float* wfn, float* dx, long M, hipStream_t st) {
-    return panel_mt(M) == 3 ? panel_gemm_launch<3, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st)
-                            : panel_gemm_launch<2, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st);
+// dx[M][256] = dqkv[M][768] W, W fragment-ordered (input-gradient form); colrec (or NULL): panel_qkv_records(M) records of 768
+// column sums of dqkv (the q|k|v bias gradient before its reduction)
+static long panel_qkv_records(long M) { return (M + 16 * panel_mt(M) - 1) / (16 * panel_mt(M)); }
+static int panel_qkv_dx(const float* dqkv, const float* wfn, float* dx, long M, hipStream_t st, float* colrec = nullptr) {
+    return panel_mt(M) == 3 ? panel_gemm_launch<3, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st, colrec)
+                            : panel_gemm_launch<2, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st, colrec);
 }
 // CFFM_PANEL_QKV=0: the q|k|v Linear keeps the tiled GEMMs (A/B: 0.8843 tiled vs 0.8729 ms per step as row panels, means of three
 // alternating runs with the activation stored)
+static int qkv_colrec_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CFFM_QKV_COLREC"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
 static int panel_qkv_on() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("CFFM_PANEL_QKV"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -1259,7 +1266,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
 // under stream capture the chain's kernel is ln_pool_bwd's FIRST dependant and keeps its place on the graph's first stream (the graph
 // executor hands every further dependant of a node the next stream, see side_fork_mark).
 #ifndef CFFM_EMU
-static struct { bool has; RedJobs jobs; float* dM; const cffm_block_grads* gr; int parity; } g_tail = {false, {}, nullptr, nullptr, 0};
+static struct { bool has, cs; RedJobs jobs; float* dM; const cffm_block_grads* gr; int parity; } g_tail = {false, false, {}, nullptr, nullptr, 0};
 // on_main (end of a layer backward): the optimizer is what waits for these gradients, so they are the chain now -- launched on the
 // caller's stream itself, in front of everything else that follows the last ln_pool_bwd
 static int tail_flush(hipStream_t st, bool on_main = false) {
@@ -1269,7 +1276,9 @@ static int tail_flush(hipStream_t st, bool on_main = false) {
     // the q|k|v bias records come from the column sum on the weight-gradient stream.  On a side stream the tail waits for that stream's
     // whole block (tail_order: the graph executor then queues it right behind the block's side work; waiting for the column sum alone
     // it was queued behind the NEXT block's side work); on the caller's stream only for the column sum (cs_order)
-    (void)hipStreamWaitEvent(s3, on_main ? g_side.cs_order : g_side.tail_order, 0);
+    if (!on_main) (void)hipStreamWaitEvent(s3, g_side.tail_order, 0);
+    else if (g_tail.cs) (void)hipStreamWaitEvent(s3, g_side.cs_order, 0);
+    g_tail.cs = false;
     redq_launch(g_tail.jobs, s3);
     CHECK_LAUNCH("block_backward reductions");
     TRY(cffm_pool_matrix_bwd(g_tail.dM, g_tail.gr->pool_w, (void*)s3));
@@ -1466,19 +1475,33 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     }
     // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)
     int dx_done = 0;
+    // the q|k|v bias gradient = column sums of dqkv: as records out of the row-panel input-gradient GEMM, which stages every row of
+    // dqkv anyway (CFFM_QKV_COLREC=0: the separate column-sum pass over the 66 MB on the side stream, as before)
+    float* qkv_rec = nullptr;
+    if (sp && panel_qkv_on() && qkv_colrec_on()) {
+        const long nrec = panel_qkv_records(NR);
+        qkv_rec = red_scratch((size_t)nrec * 768, st);
+        REQUIRE(qkv_rec, "block_backward: scratch allocation failed");
+        RedSegs segs;
+        segs.nseg = 0;
+        seg_add(segs, 0, 768, gr->qkv_b, 0);
+        reduce_records(qkv_rec, (int)nrec, 768, 768, segs, st);
+    }
     if (sp && (fork_order() & 2) && panel_qkv_on()) {     // chain first: the q|k|v input gradient is launched before the side work
         side_fork_mark(st, 2);
         PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
-        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st), "block_backward: q|k|v input-gradient gemm failed");
+        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st, qkv_rec), "block_backward: q|k|v input-gradient gemm failed");
         dx_done = 1;
     }
     if (sp) {
         sb = dx_done ? side_fork_take(st, 2) : side_fork(st, 2);
         void* stream_b = (void*)sb;
-        TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream_b));
+        if (!qkv_rec) {
+            TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream_b));
 #ifndef CFFM_EMU
-        if (sb != st) (void)hipEventRecord(g_side.cs_order, sb);
+            if (sb != st) { (void)hipEventRecord(g_side.cs_order, sb); g_tail.cs = true; }
 #endif
+        }
         if (one_group) {
             // ALL four weight gradients as one grouped launch (~480 workgroups with one slice length, one partial-sum launch: 59 us
             // where two groups of two take 2 x 53), on the side stream beside q|k|v's input gradient and the CFFA backward; every
@@ -1520,7 +1543,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     if (dx_done) {
     } else if (sp && panel_qkv_on()) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
-        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st), "block_backward: q|k|v input-gradient gemm failed");
+        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st, qkv_rec), "block_backward: q|k|v input-gradient gemm failed");
     } else {
         DX_GEMM(ST_G_QKV_DX, false, dqkv, p->qkv_w, wq_s, dzall, NR, 768, CFFM_C);
     }

@@ -26,7 +26,7 @@
 // adjacent k-chunks) cover the 16 bank quads exactly once (checked exhaustively in tests/test_geometry.py)
 __device__ __forceinline__ int pnl_off(int row, int chunk) { return row * PNL_KC + (((chunk ^ row) & 15) << 3) + ((chunk & 16) << 3); }
 #define PNL_IMG(MT) (16 * (MT) * PNL_KC)                       // bf16 elements of one image
-#define PNL_LDS(MT) (2 * 2 * PNL_IMG(MT) * 2)                  // bytes: double-buffered {hi, lo}
+#define PNL_LDS(MT) (2 * 2 * PNL_IMG(MT) * 2 + 2 * PNL_THREADS * 16)   // bytes: double-buffered {hi, lo} + the column-sum exchange (k_panel_gemm colrec)
 
 // index (in 16-byte units) of the fragment of output tile jt, k-step ks, half h (0 hi, 1 lo) in a fragment-ordered weight
 __device__ __host__ __forceinline__ long pnl_frag_unit(int jt, int ks, int h, int KS) { return ((long)(jt * KS + ks) * 2 + h) * 64; }
@@ -188,9 +188,26 @@ __device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT,
 template <int MT, int NTW, int NT, int D, bool A_PRE, int EPI>
 __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restrict__ A, int lda, int M, int K, const f32x4* __restrict__ Wf,
                                                             float* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                                            void* __restrict__ aux = nullptr) {
+                                                            void* __restrict__ aux = nullptr, float* __restrict__ colrec = nullptr) {
     CFFM_DYN_SMEM(smem);
     bf16* img = (bf16*)smem;     // [buf][hi | lo][16 MT][256]
+    // colrec (fp32 A only): record blockIdx.x [K] = the column sums of this workgroup's 16 MT rows of A -- the bias gradient of the
+    // Linear whose output gradient A is, out of the registers the panel is staged through (no second pass over A).  A thread stages
+    // the same four columns of 2 MT rows (pnl_stage_load); the eight waves' partial sums meet in LDS behind the chunk's barrier
+    f32x4* csum = (f32x4*)(img + 4 * PNL_IMG(MT));     // [2][8 waves][64 lanes]
+#define PNL_COLSUM_PUT(c_)                                                                        \
+    if (!A_PRE && colrec) {                                                                       \
+        f32x4 s_ = sr.v[0];                                                                       \
+        _Pragma("unroll") for (int it = 1; it < 2 * MT; ++it) s_ += sr.v[it];                     \
+        csum[((c_) & 1) * PNL_THREADS + tid] = s_;                                                \
+    }
+#define PNL_COLSUM_GET(c_)                                                                        \
+    if (!A_PRE && colrec && wave == ((c_) & 7)) {                                                 \
+        const f32x4* p_ = csum + ((c_) & 1) * PNL_THREADS + lane;                                 \
+        f32x4 t_ = p_[0];                                                                         \
+        _Pragma("unroll") for (int w = 1; w < PNL_WAVES; ++w) t_ += p_[64 * w];                   \
+        *(f32x4*)(colrec + (long)blockIdx.x * K + (c_) * PNL_KC + 4 * lane) = t_;                 \
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * 16 * MT;
     const int NCH = K / PNL_KC, KS = K / 32, N = PNL_WAVES * NTW * 16;
@@ -212,18 +229,23 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
     PnlStage<MT> sr;
     pnl_stage_load<MT>(sr, rsa, lda, m0, 0, tid);
     pnl_stage_store<MT, A_PRE>(sr, img, img + PNL_IMG(MT), tid);
+    PNL_COLSUM_PUT(0)
     if (NCH > 1) pnl_stage_load<MT>(sr, rsa, lda, m0, PNL_KC, tid);
     pnl_lds_barrier();
     for (int c = 0; c < NCH; ++c) {
+        PNL_COLSUM_GET(c)
         const bf16* hi = img + (c & 1) * 2 * PNL_IMG(MT);
         pnl_chunk_mma<MT, NTW, NT, D>(acc, ring, hi, hi + PNL_IMG(MT), st, jt0, 8 * c, l15, g, st, jt0, 8 * (c + 1));
         if (c + 1 < NCH) {
             bf16* nx = img + ((c + 1) & 1) * 2 * PNL_IMG(MT);
             pnl_stage_store<MT, A_PRE>(sr, nx, nx + PNL_IMG(MT), tid);
+            PNL_COLSUM_PUT(c + 1)
             if (c + 2 < NCH) pnl_stage_load<MT>(sr, rsa, lda, m0, (c + 2) * PNL_KC, tid);
             pnl_lds_barrier();
         }
     }
+#undef PNL_COLSUM_PUT
+#undef PNL_COLSUM_GET
     // epilogue: acc[t][i][r] = C[m0 + 16 i + l15][16 (jt0 + t) + 4 g + r]
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
