@@ -44,3 +44,13 @@ print('kernel time per step (all streams): %.1f us over %d steps' % (tot / 1e3 /
 for r in st[:26]:
     print('%-60s %5s calls %8.1f us avg %5.1f %% %7.1f us/step' % (r['Name'][:60], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot, float(r['TotalDurationNs']) / 1e3 / nstep))
 PY
+python - <<'PY'
+# per-launch durations of the kernels that run once per block, in launch order (block 0 / block 1 alternate in the forward)
+import csv, glob
+f = glob.glob('/tmp/bp/**/*kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+for key in ('k_mlp_fwd', 'k_mlp_bwd', 'k_cfm_attn_fwd', 'k_cfm_attn_bwd', 'k_ln_pool_fwd', 'k_ln_pool_bwd'):
+    d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if key in r['Kernel_Name']][-24:]
+    print('%-16s' % key, ' '.join('%.0f' % x for x in d))
+PY

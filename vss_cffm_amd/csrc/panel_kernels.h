@@ -181,6 +181,28 @@ __device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT,
     }
 }
 
+// L2 warm-up of a fragment-ordered weight at the start of a fused kernel.  Every workgroup streams ALL of the block's weights (2.4 MB);
+// when nobody has read them since k_param_prep wrote them at the start of the step they sit in HBM, and the B ring (D k-steps = 16 KB
+// per wave in flight) cannot cover that latency: the second block's fused forward took 62 us against 42 for the first, whose weights
+// had just been written (round-3 timeline; with the second block pointed at the FIRST block's weights both took 42; same-box A/B of
+// the whole step: 0.758-0.771 ms without the warm-up, 0.715-0.731 with it; the fused backward 64 -> 51-55 us).  So the
+// workgroups that share an L2 (blockIdx.x % 8: workgroups go round-robin over the 8 XCDs) each request one 16-byte word of a
+// different 128-byte line -- one load per thread and weight, all in flight together with the first panel -- which pulls the whole
+// weight into that XCD's L2 (and the memory-side cache) one round trip after the kernel starts.  A hint only: grids under 128
+// workgroups do not cover every line.  The loaded words are XOR-ed into a value that is kept (a never-taken store at the end of the
+// kernel) so that the loads cannot be dropped.
+__device__ __forceinline__ uint32_t pnl_l2_touch(const void* w, long bytes, int tid) {
+    const long nlines = bytes >> 7;
+    const int nsl = (int)(gridDim.x >> 3) > 0 ? (int)(gridDim.x >> 3) : 1, rank = (int)(blockIdx.x >> 3) % nsl;
+    const long per = (nlines + nsl - 1) / nsl, l = rank * per + tid;
+    return (tid < per && l < nlines) ? *(const uint32_t*)((const char*)w + (l << 7)) : 0u;
+}
+#ifndef PNL_TOUCH
+#define PNL_TOUCH 1
+#endif
+#ifndef PNL_TOUCH_GEMM
+#define PNL_TOUCH_GEMM 0   // the plain panel GEMMs (q|k|v: 0.75 MB of weights): no difference measured (0.719-0.727 with, 0.715-0.731 without)
+#endif
 // ---- plain panel GEMM: C[M][N] = A[M][K] W^T (+ bias), W in fragment order (NT or NN form decides what "W^T" means) ---------
 // grid = ceil(M / (16 MT)) workgroups of 512 threads; N = 8 waves x NTW tiles x 16; K a multiple of 256.
 // EPI: 0 plain fp32 (+bias) | 3 q|k|v: nothing in C; aux (h16 [M][ldc]) = f16(raw + bias), features < 256 (the q third) also times
@@ -228,6 +250,12 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
     pnl_pin_vmem();
     PnlStage<MT> sr;
     pnl_stage_load<MT>(sr, rsa, lda, m0, 0, tid);
+    uint32_t touch = 0;
+    if (PNL_TOUCH_GEMM) {      // L2 warm-up of the weight (pnl_l2_touch, defined below with the fused kernels)
+        pnl_pin_vmem();
+        touch = pnl_l2_touch(Wf, (long)N * K * 4, tid);
+        pnl_pin_vmem();
+    }
     pnl_stage_store<MT, A_PRE>(sr, img, img + PNL_IMG(MT), tid);
     PNL_COLSUM_PUT(0)
     if (NCH > 1) pnl_stage_load<MT>(sr, rsa, lda, m0, PNL_KC, tid);
@@ -267,6 +295,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
             if (m < M) *(f32x4*)(C + (long)m * ldc + n) = acc[t][i] + bv;
         }
     }
+    if (PNL_TOUCH_GEMM && M < 0) *(volatile uint32_t*)aux = touch;     // (never taken: keeps the warm-up load)
 }
 
 // =====================================================================================================================
@@ -324,11 +353,22 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
     PnlRing<2, D> ring;
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) pnl_ring_load<2, D>(ring, s, sp, 2 * wave, s);
+    uint32_t touch = 0;
     pnl_pin_vmem();
     {
         PnlStage<MT> sr;
         pnl_stage_load<MT>(sr, buf_make(a.ao, (uint32_t)((long)NP * 256 * 4)), 256, m0, 0, tid);
-        pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+        if (PNL_TOUCH) {     // behind the panel's loads in the memory queue: staging does not wait for them
+            pnl_pin_vmem();
+            const uint32_t t0 = pnl_l2_touch(a.w1, 1024L * 256 * 4, tid), t1 = pnl_l2_touch(a.w2, 1024L * 256 * 4, tid);
+            uint32_t t2 = 0;
+            if (PNL_TOUCH & 2) t2 = pnl_l2_touch(a.wp, 256L * 256 * 4, tid);
+            pnl_pin_vmem();
+            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+            touch = t0 ^ t1 ^ t2;
+        } else {
+            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+        }
     }
     pnl_lds_barrier();
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -457,6 +497,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
         for (int i = 0; i < MT; ++i)
             if (PNL_ST(valid[i])) *(f32x4*)(a.x2 + mrow[i] * 256 + n) = x1v[t][i] + acc2[t][i] + bv;
     }
+    if (PNL_TOUCH && a.NP < 0) a.mean2[tid] = (float)touch;     // (never taken: keeps the warm-up loads)
 }
 
 struct MlpBwdArgs {
@@ -487,12 +528,21 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
     PnlRing<2, D> ring;
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) pnl_ring_load<2, D>(ring, s, s2, 2 * wave, s);
+    uint32_t touch = 0;
     pnl_pin_vmem();
     const buf_t rs_dout = buf_make(a.dout, (uint32_t)((long)NP * 256 * 4));
     {
         PnlStage<MT> sr;
         pnl_stage_load<MT>(sr, rs_dout, 256, m0, 0, tid);
-        pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+        if (PNL_TOUCH) {     // see pnl_l2_touch; behind the panel's loads in the memory queue
+            pnl_pin_vmem();
+            const uint32_t t0 = pnl_l2_touch(a.w2n, 1024L * 256 * 4, tid), t1 = pnl_l2_touch(a.w1n, 1024L * 256 * 4, tid), t2 = pnl_l2_touch(a.wpn, 256L * 256 * 4, tid);
+            pnl_pin_vmem();
+            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+            touch = t0 ^ t1 ^ t2;
+        } else {
+            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+        }
     }
     pnl_lds_barrier();
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -643,6 +693,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
         for (int i = 0; i < MT; ++i)
             if (PNL_ST(valid[i])) *(f32x4*)(a.dao + mrow[i] * 256 + n) = dq[t][i];
     }
+    if (PNL_TOUCH && a.NP < 0) a.dao[tid] = (float)touch;       // (never taken: keeps the warm-up loads)
 }
 
 #ifdef CFFM_EXPERIMENTS   // measured and rejected (DESIGN.md section 3, round-3 dead ends): kept for scripts/r03_mlp_bench.hip only
