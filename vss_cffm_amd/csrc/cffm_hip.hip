@@ -394,7 +394,7 @@ static bool side_init(hipStream_t main) {
 // sooner).  Launched eagerly the side stream really runs beside the chain and `split` wins (0.886 vs 0.911 ms per step); a replayed
 // HIP graph executes its branches almost serially, so there the cheaper `one` wins (0.927 vs 0.950).  Default: by whether the
 // caller's stream is being captured; CFFM_DW_GROUP=one|split forces a form.
-// How the side work of a block backward is attached to the chain (bit mask; default 35 = 1 | 2 | 32, the rest for A/B measurements).
+// How the side work of a block backward is attached to the chain (bit mask; default 38 = 2 | 4 | 32, the rest for A/B measurements).
 // Under stream capture the graph executor (ROCm 7.2) gives a node's FIRST-captured dependant the node's own stream and every further
 // dependant the next of its (four) streams, depth first -- so whatever is launched first behind a fork stays on the chain's stream,
 // and side branches that reach the same stream number run one after the other in topological order.  The chain must therefore be
@@ -406,10 +406,12 @@ static bool side_init(hipStream_t main) {
 // Measured (B = 2, depth 2, replayed graph, same box): 0 -> 0.830-0.833 ms per step, 4 -> 0.808-0.810, 38 (with the two scratch sets
 // of scratch_layout, so that no block waits for the previous block's weight gradients) -> 0.798-0.811 against 0.821-0.848 for 4;
 // 35 (the bias-tile sum early again, now that every side branch lands on the same graph stream in launch order: it runs in the idle
-// stretch beside the gather instead of behind the weight gradients on the step's tail) -> 0.773-0.785 against 0.783-0.786 for 38.
+// stretch beside the gather instead of behind the weight gradients on the step's tail) -> 0.773-0.785 against 0.783-0.786 for 38; with
+// the last block's tail on the caller's stream and the L2 warm-up of the fused kernels 38 is ahead again (one fork less on the chain:
+// a node with a dependant on another stream costs its same-stream successor ~5 us): 0.724-0.728 against 0.732-0.737 for 35.
 static int fork_order() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_FORK_ORDER"); v = e ? atoi(e) : 35; }
+    if (v < 0) { const char* e = getenv("CFFM_FORK_ORDER"); v = e ? atoi(e) : 38; }
     return v;
 }
 static int dw_one_group(hipStream_t st) {
