@@ -1284,10 +1284,21 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
 static struct { bool has, cs; RedJobs jobs; float* dM; const cffm_block_grads* gr; int parity; } g_tail = {false, false, {}, nullptr, nullptr, 0};
 // on_main (end of a layer backward): the optimizer is what waits for these gradients, so they are the chain now -- launched on the
 // caller's stream itself, in front of everything else that follows the last ln_pool_bwd
-static int tail_flush(hipStream_t st, bool on_main = false) {
+// `on` (fork_order bit 6): a side stream that is already ordered behind the ln_pool_bwd in question (the NEXT block's weight-gradient
+// stream, forked behind that block's gather): no fork of its own, so ln_pool_bwd keeps a single dependant
+static int tail_flush(hipStream_t st, bool on_main = false, hipStream_t on = nullptr) {
     if (!g_tail.has) return 0;
     g_tail.has = false;
-    hipStream_t s3 = on_main ? st : side_fork_take(st, 3);
+    hipStream_t s3 = on_main ? st : (on ? on : side_fork_take(st, 3));
+    if (on && !on_main) {
+        g_tail.cs = false;
+        redq_launch(g_tail.jobs, s3);
+        CHECK_LAUNCH("block_backward reductions");
+        TRY(cffm_pool_matrix_bwd(g_tail.dM, g_tail.gr->pool_w, (void*)s3));
+        side_record(s3, st, g_side.tail_done[g_tail.parity]);
+        g_side.tail_pending[g_tail.parity] = true;
+        return 0;
+    }
     // the q|k|v bias records come from the column sum on the weight-gradient stream.  On a side stream the tail waits for that stream's
     // whole block (tail_order: the graph executor then queues it right behind the block's side work; waiting for the column sum alone
     // it was queued behind the NEXT block's side work); on the caller's stream only for the column sum (cs_order)
@@ -1304,7 +1315,7 @@ static int tail_flush(hipStream_t st, bool on_main = false) {
     return 0;
 }
 #else
-static int tail_flush(hipStream_t, bool = false) { return 0; }
+static int tail_flush(hipStream_t, bool = false, hipStream_t = nullptr) { return 0; }
 #endif
 static bool tail_on_main() {     // CFFM_TAIL_MAIN=0: the last block's tail on the side stream like every other block's (A/B)
     static int v = -1;
@@ -1399,7 +1410,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         TRY(cffm_mlp_bwd(dout, ws + L.hraw, p->fc1_b, ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, wfn + 768 * 256 + 256 * 256 + 1024 * 256,
                          wfn + 768 * 256 + 256 * 256, wfn + 768 * 256, dact, dx1, dao, gr->norm2_w, gr->norm2_b, gr->fc1_b, gr->fc2_b, gr->proj_b, NP,
                          stream));
-        TRY(tail_flush(st));    // the previous block's parameter-gradient tail, now that this block's first kernel is ln_pool_bwd's first dependant
+        if (!(fork_order() & 64)) TRY(tail_flush(st));    // the previous block's parameter-gradient tail, now that this block's first kernel is ln_pool_bwd's first dependant
         if (!one_group) {
             sa = side_fork(st, 0);
             void* stream_a = (void*)sa;
@@ -1452,7 +1463,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     // attention: the fused kernel and the dK/dV gather stay on the chain; the bias-gradient tile sum and its scatter into the six
     // tables go to the side stream (branch 1), the q|k|v bias column sum and the weight gradients of q|k|v / proj after the gather
     // (branch 2)
-    TRY(tail_flush(st));        // (forms of the block whose first kernel is not the fused Mlp backward)
+    if (!(fork_order() & 64)) TRY(tail_flush(st));        // (forms of the block whose first kernel is not the fused Mlp backward)
     hipStream_t sb = st, s1 = st;
     int bias_late = 0, late_ng = 0;
     float* late_dbp = nullptr;
@@ -1536,6 +1547,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
                 TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
                 bias_late = 0;
             }
+            if ((fork_order() & 64) && sb != st) TRY(tail_flush(st, false, sb));   // the PREVIOUS block's record reductions: no fork of their own
         } else {
         const cffm_wgrad wgb[2] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C}, {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
         const GemmTNPre preb[2] = {{0, 1, nullptr}, {0, 0, nullptr}};
@@ -1584,6 +1596,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     // parameter gradients only -> side stream (branch 3); the caller's stream then waits for the side stream once
 #ifndef CFFM_EMU
     if (defer && sp && sb != st && s1 != st && g_side.on && (fork_order() & 32)) {
+        if (g_tail.has) TRY(tail_flush(st));    // (an earlier block's tail nobody has launched yet: before its slot is reused)
         side_fork_mark(st, 3);
         if (s1 != sb) side_order(s1, sb);
         (void)hipEventRecord(g_side.tail_order, sb);
