@@ -426,8 +426,11 @@ def main():
             # ONE timed launch of the roofline kernel per captured step (the first block's): an event pair around a kernel of the
             # chain keeps the executor from dispatching its neighbours back to back (~10 us per pair, measured: 0.765 ms per step
             # without pairs, 0.789 with one around each of the DEPTH launches)
+            # (N > 1 with the collectives captured inside: the event nodes belong into THAT graph, captured further down -- pairs
+            #  recorded in a graph that is never replayed cannot be read)
+            try_coll = multi and os.environ.get('CFFM_BENCH_GRAPH_COLLECTIVES', '1') != '0' and dist.get_backend() == 'nccl'
             lib.cffm_profile_sample_every(DEPTH if with_events else 1)
-            lib.cffm_profile_enable(attn_bit if with_events else 0)
+            lib.cffm_profile_enable(attn_bit if (with_events and not try_coll) else 0)
             try:
                 if not multi:
                     ga = torch.cuda.CUDAGraph()
@@ -461,12 +464,16 @@ def main():
                 lib.cffm_profile_collect(ms_buf, n_buf)
             red = V.distributed.BlockwiseReducer(single_rank_too=force1)
             upper = lp.flat[lp.per_block:] if DEPTH > 1 else lp.flat
-            if os.environ.get('CFFM_BENCH_GRAPH_COLLECTIVES', '1') != '0' and dist.get_backend() == 'nccl':
+            if try_coll:
                 # default at N > 1: the whole step INCLUDING the RCCL all-reduces as ONE graph -- one graph launch
                 # instead of three + two host-issued collectives (~0.06 ms per step with one rank).  A capture that fails on ANY rank
                 # sends EVERY rank back to the three-graph form above: the ranks agree on the outcome with an (eager) all-reduce, so
                 # nobody replays a graph whose peers are missing.  CFFM_BENCH_GRAPH_COLLECTIVES=0 skips the attempt.
                 ok, g1 = 1, None
+                if with_events:
+                    lib.cffm_profile_collect_graph(ms_buf, n_buf, 1)
+                    lib.cffm_profile_sample_every(DEPTH)
+                    lib.cffm_profile_enable(attn_bit)
                 try:
                     g1 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, pool=ga.pool()):
@@ -483,6 +490,10 @@ def main():
                     ok = 0
                     sys.stderr.write('bench.py: rank %d: capturing the collectives failed (%s); every rank falls back to three graphs\n' % (rank, str(e).splitlines()[0][:120] if str(e) else type(e).__name__))
                     torch.cuda.synchronize(dev)
+                finally:
+                    lib.cffm_profile_enable(0)
+                    lib.cffm_profile_sample_every(1)
+                    lib.cffm_profile_collect(ms_buf, n_buf)
                 agree = torch.tensor([ok], device=dev, dtype=torch.int32)
                 dist.all_reduce(agree, op=dist.ReduceOp.MIN)
                 if int(agree.item()) == 1:
