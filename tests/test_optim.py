@@ -325,18 +325,21 @@ def test_adamw_gpu():
 
 
 @pytest.mark.gpu
-def test_training_step_captured_in_a_graph_matches_eager():
+@pytest.mark.parametrize('depth', [1, 3])
+def test_training_step_captured_in_a_graph_matches_eager(depth):
     """forward + backward + AdamW captured once in a torch.cuda.CUDAGraph: three replays == three eager steps
-    (the optimizer's step count lives on the device, so the bias correction advances inside the replays)."""
+    (the optimizer's step count lives on the device, so the bias correction advances inside the replays).  depth 3: the blocks of the
+    backward alternate between the two scratch sets, their parameter-gradient tails are launched behind the next block's first kernel
+    and the side work runs on the library's four capture streams -- the replayed graph must still compute what the eager launches do."""
     from oracle import recipe as R
     dev = torch.device('cuda:0')
-    st = R.layer_state(1, seed=31)
+    st = R.layer_state(depth, seed=31)
     x = R.synth_input('gx', (1, 4, 256, 14, 14), seed=32).to(dev)
     gy = torch.zeros(1, 4, 256, 14, 14, device=dev)
     gy[:, -1] = R.synth_input('gg', (1, 256, 14, 14), seed=33, scale=1e-3).to(dev)
 
     def make():
-        m = V.BasicLayer3d3(dim=256, depth=1, num_heads=8, window_size=7, expand_size=3, pool_method='fc', focal_level=2,
+        m = V.BasicLayer3d3(dim=256, depth=depth, num_heads=8, window_size=7, expand_size=3, pool_method='fc', focal_level=2,
                             focal_window=5, focal_l_clips=[1, 2, 3], focal_kernel_clips=[7, 5, 3])
         m.load_state_dict(st, strict=False)
         m.to(dev)
