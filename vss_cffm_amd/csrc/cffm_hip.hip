@@ -1502,7 +1502,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)
     int dx_done = 0;
     // the q|k|v bias gradient = column sums of dqkv: as records out of the row-panel input-gradient GEMM, which stages every row of
-    // dqkv anyway (CFFM_QKV_COLREC=0: the separate column-sum pass over the 66 MB on the side stream, as before)
+    // dqkv anyway (CFFM_QKV_COLREC=0: the separate column-sum pass over the 32 MB on the side stream, as before)
     float* qkv_rec = nullptr;
     if (sp && panel_qkv_on() && qkv_colrec_on()) {
         const long nrec = panel_qkv_records(NR);
