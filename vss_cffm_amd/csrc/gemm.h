@@ -210,12 +210,18 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
 #ifndef CFFM_EMU
     static bool granted = false;
     if (!granted) {
-        if (hipFuncSetAttribute((const void*)k_gemm_group_tt, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS(128, 128, 32)) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_gemm_group_tt, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS(128, 128, 32) + 16384) != hipSuccess)
             return -1;
         granted = true;
     }
 #endif
-    CFFM_LAUNCH(k_gemm_group_tt, ((unsigned)wg), (256), GEMM_LDS(128, 128, 32), st, G);
+    // 8 KB more LDS than the tiles need: ONE workgroup of the group per CU instead of two.  Two fill a CU's LDS exactly, and the CFFA
+    // backward that runs beside the group in a block backward (69 KB per workgroup) then finds no slot until the group's workgroups
+    // finish; with one per CU the two kernels really share the CUs: the group 62 -> 70 us, k_ln_pool_bwd 85 -> 77, step 0.717-0.730 ->
+    // 0.713-0.722 ms (same box, three alternating runs; 256 / 384 / 512 workgroups instead of 480: slower).  CFFM_DW_LDS_PAD=0: two per CU.
+    static int lds_pad = -1;
+    if (lds_pad < 0) { const char* e = getenv("CFFM_DW_LDS_PAD"); lds_pad = e ? atoi(e) : 8192; if (lds_pad < 0 || lds_pad > 16384) lds_pad = 8192; }
+    CFFM_LAUNCH(k_gemm_group_tt, ((unsigned)wg), (256), GEMM_LDS(128, 128, 32) + lds_pad, st, G);
     if (after_gemm) after_gemm(st);
     if (nsum) {
         Sg.cnt = nsum;
