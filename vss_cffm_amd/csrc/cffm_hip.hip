@@ -260,9 +260,9 @@ static Scratch scratch_layout(const cffm_geom* g) {
     s.dkvp = p; p += up(B * g->nW * ((long)CFFM_NKEY_PAD * 256 + CFFM_HEADS));   // f16 partial rows + their (window, head) scales
     // second copies of what a block's side work (weight-gradient GEMMs, column sums, bias-tile sum) still reads after the chain has
     // moved on to the next block: blocks alternate between the two sets (block_backward_impl `par`), so the next block's chain never
-    // waits for the side streams.  Offsets relative to `alt`: b | dact | dqkv | dbiasT
+    // waits for the side streams.  Offsets relative to `alt`: b | dact | dqkv | dbiasT | dM
     s.alt = p;
-    p += up(B * HW * CFFM_C) + up(B * HW * CFFM_HID) + up(B * RC * 768) + up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
+    p += up(B * HW * CFFM_C) + up(B * HW * CFFM_HID) + up(B * RC * 768) + up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD) + up(CFFM_NCELL * CFFM_WA);
     s.total = p;
     return s;
 }
@@ -1355,13 +1355,16 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
     par = (defer && par) ? 1 : 0;
     const long altb = S.alt, altact = altb + up(NP * CFFM_C), altqkv = altact + up(NP * CFFM_HID), altbias = altqkv + up(NR * 768);
+    const long altdM = altbias + up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     float* dx1 = scratch + (par ? altb : S.b);
     float* dz2 = scratch + S.dz2;
     float* dao = scratch + S.dao;
     float* dact = scratch + (par ? altact : S.dact);
     float* dqkv = scratch + (par ? altqkv : S.dqkv);
     float* dzall = scratch + S.dzall;
-    float* dM = scratch + S.dM;
+    // (dM too: a block's record reductions + pooling-matrix backward may still run on the side stream when the NEXT block's run -- the last
+    //  block's even on the caller's stream; found by the depth-3 captured-step test at 14 x 14, where the kernels are short enough to collide)
+    float* dM = scratch + (par ? altdM : S.dM);
     float* dbiasT = scratch + (par ? altbias : S.dbiasT);
     RedScope reductions((hipStream_t)stream);   // the four parameter-gradient reductions below run as one launch (finish())
     hipStream_t st = (hipStream_t)stream;
