@@ -200,6 +200,9 @@ __device__ __forceinline__ uint32_t pnl_l2_touch(const void* w, long bytes, int 
 #ifndef PNL_TOUCH
 #define PNL_TOUCH 1
 #endif
+#ifndef PNL_STAGE_OUT
+#define PNL_STAGE_OUT 1   // plain panel GEMMs: output rows assembled in LDS and stored whole (k_panel_gemm epilogue)
+#endif
 #ifndef PNL_TOUCH_GEMM
 #define PNL_TOUCH_GEMM 0   // the plain panel GEMMs (q|k|v: 0.75 MB of weights): no difference measured (0.719-0.727 with, 0.715-0.731 without)
 #endif
@@ -275,6 +278,43 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
 #undef PNL_COLSUM_PUT
 #undef PNL_COLSUM_GET
     // epilogue: acc[t][i][r] = C[m0 + 16 i + l15][16 (jt0 + t) + 4 g + r]
+    if (PNL_STAGE_OUT && !(PNL_ABLATE & 4) && (EPI == 0 || EPI == 3)) {
+        // Through LDS: a lane of the MFMA C layout owns 4 consecutive features of one row, so a store instruction writes 16 rows x 32 B
+        // (f16 q|k|v) or x 64 B (fp32) -- short runs that drain at about half the rate of whole rows (the q|k|v forward spent 8 of its
+        // 20 us on its 15.9 MB of stores).  The panel's output [16 MT rows][N] is assembled in the (now free) image buffers, rows padded by
+        // 32 B against bank conflicts, and leaves as 16-byte units in row order: every wave instruction writes 1 KiB of one or two rows.
+        constexpr int ESZ = (EPI == 3) ? 2 : 4, NCOL = PNL_WAVES * NTW * 16, ROWB = NCOL * ESZ + 32, UPR = NCOL * ESZ / 16;
+        static_assert(16 * MT * ROWB <= PNL_LDS(MT), "panel output does not fit the image buffers");
+        char* out = (char*)smem;
+        __syncthreads();               // every wave has read its last fragments
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int n = 16 * (jt0 + t) + 4 * g;
+            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (bias) bv = *(const f32x4*)(bias + n);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                char* q = out + (16 * i + l15) * ROWB + n * ESZ;
+                if (EPI == 3) {
+                    const float sc = n < CFFM_C ? 0.17677669529663687f : 1.f;
+                    typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+                    h16x4 o;
+                    for (int e = 0; e < 4; ++e) o[e] = (h16)((acc[t][i][e] + bv[e]) * sc);
+                    *(h16x4*)q = o;
+                } else {
+                    *(f32x4*)q = acc[t][i] + bv;
+                }
+            }
+        }
+        __syncthreads();
+        char* dst = (EPI == 3) ? (char*)aux : (char*)C;
+        for (int u = tid; u < 16 * MT * UPR; u += PNL_THREADS) {
+            const int r = u / UPR, c = u % UPR;
+            if (m0 + r < M) *(f32x4*)(dst + ((long)(m0 + r) * ldc) * ESZ + 16 * c) = *(const f32x4*)(out + r * ROWB + 16 * c);
+        }
+        if (PNL_TOUCH_GEMM && M < 0) *(volatile uint32_t*)aux = touch;
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int n = 16 * (jt0 + t) + 4 * g;
