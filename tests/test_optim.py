@@ -70,6 +70,29 @@ def run_adamw_fused_tick_equals_two_launches(device, steps=7):
     assert opts[0].device_step_count() == opts[1].device_step_count() == steps
 
 
+def run_adamw_tiny_grids(device):
+    """the ticket logic of the one-launch update at grids below its 64 ticket slots: 1, 2 and 65 chunks"""
+    for shapes in ([(5,)], [(3,), (2, 2)], [(2048 * 64 + 7,)]):
+        gen = torch.Generator().manual_seed(21)
+        ref = [torch.nn.Parameter(torch.randn(*s, generator=gen)) for s in shapes]
+        mine = [torch.nn.Parameter(p.detach().clone().to(device)) for p in ref]
+        o_ref, o_mine = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.05), V.optim.AdamW(mine, lr=1e-2, weight_decay=0.05)
+        for _ in range(4):
+            for p, q in zip(ref, mine):
+                g = torch.randn(p.shape, generator=gen)
+                p.grad, q.grad = g.clone(), g.clone().to(device)
+            o_ref.step()
+            o_mine.step()
+        assert o_mine.device_step_count() == 4
+        for p, q in zip(ref, mine):
+            torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_adamw_tiny_grids_emulated():
+    with emu.active():
+        run_adamw_tiny_grids(torch.device('cpu'))
+
+
 def test_adamw_fused_tick_equals_two_launches_emulated():
     with emu.active():
         run_adamw_fused_tick_equals_two_launches(torch.device('cpu'))
@@ -322,6 +345,7 @@ def test_adamw_gpu():
     run_adamw_resume(torch.device('cuda:0'))
     run_adamw_groups_and_schedule(torch.device('cuda:0'))
     run_adamw_fused_tick_equals_two_launches(torch.device('cuda:0'))
+    run_adamw_tiny_grids(torch.device('cuda:0'))
 
 
 @pytest.mark.gpu
