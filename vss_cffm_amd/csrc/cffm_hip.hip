@@ -1322,9 +1322,10 @@ static bool tail_on_main() {     // CFFM_TAIL_MAIN=0: the last block's tail on t
     if (v < 0) { const char* e = getenv("CFFM_TAIL_MAIN"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
-static void tail_reset() {      // entry of a layer backward: nothing of a previous (failed) call is left to launch
+static void tail_reset() {      // entry of a layer backward: nothing of a previous (failed) call is left to launch or to wait for
 #ifndef CFFM_EMU
-    g_tail.has = false;
+    g_tail.has = g_tail.cs = false;
+    for (int i = 0; i < 2; ++i) g_side.dw_pending[i] = g_side.bias_pending[i] = g_side.tail_pending[i] = false;   // (a call that returned normally ended in side_join_all)
 #endif
 }
 int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
