@@ -12,7 +12,7 @@ f = glob.glob('/tmp/bp/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last 6 steps: a step starts at each k_param_prep
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_param_prep')]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_param_prep') or r['Kernel_Name'].startswith('k_transpose_prep')]
 try:
     j = json.loads(open('gpurun_out/r03_trace_%s.json' % tag).read().strip().splitlines()[-1])
     print('bench under rocprof: %.4f ms/step' % j['ms_per_step'])

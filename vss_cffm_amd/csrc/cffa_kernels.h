@@ -23,19 +23,19 @@
 // copy_dst (may be NULL): laid out like src; image z is ALSO copied there unchanged unless z % add_mod == add_skip (the layer
 // forward's first transpose: the three pass-through frames of the reference's output, cffm_transformer.py:826, leave with the read
 // that the transpose does anyway -- round 2 ran a separate 44 MB copy kernel beside it).
-__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, float* __restrict__ dst,
-                                                    int rows, int cols, long src_bs, long dst_bs,
-                                                    const float* __restrict__ addend, int add_mod, int add_skip,
-                                                    float* __restrict__ copy_dst = nullptr) {
+__device__ __forceinline__ void transpose_body(const float* __restrict__ src, float* __restrict__ dst,
+                                               int rows, int cols, long src_bs, long dst_bs,
+                                               const float* __restrict__ addend, int add_mod, int add_skip,
+                                               float* __restrict__ copy_dst, int bx, int by, int bz) {
     __shared__ float tile[64][65];   // tile[c][r]; odd stride: the scalar LDS accesses below are at most 2-way conflicted
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const float* s = src + (long)blockIdx.z * src_bs;
-    float* d = dst + (long)blockIdx.z * dst_bs;
+    const int r0 = by * 64, c0 = bx * 64;
+    const float* s = src + (long)bz * src_bs;
+    float* d = dst + (long)bz * dst_bs;
     const int q = threadIdx.x & 15, p = threadIdx.x >> 4;
     const bool vin = (cols % 4 == 0) && (src_bs % 4 == 0) && (((uintptr_t)src & 15) == 0);
     const bool vout = (rows % 4 == 0) && (dst_bs % 4 == 0) && (((uintptr_t)dst & 15) == 0) && (((uintptr_t)addend & 15) == 0);
-    const float* ad = (addend && ((int)blockIdx.z % add_mod) != add_skip) ? addend + (long)blockIdx.z * dst_bs : nullptr;
-    float* cp = (copy_dst && ((int)blockIdx.z % add_mod) != add_skip) ? copy_dst + (long)blockIdx.z * src_bs : nullptr;
+    const float* ad = (addend && (bz % add_mod) != add_skip) ? addend + (long)bz * dst_bs : nullptr;
+    float* cp = (copy_dst && (bz % add_mod) != add_skip) ? copy_dst + (long)bz * src_bs : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + p + 16 * k, c = c0 + 4 * q;
@@ -65,6 +65,12 @@ __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src
                     if (r + e < rows) d[(long)c * rows + r + e] = v[e] + (ad ? ad[(long)c * rows + r + e] : 0.f);
         }
     }
+}
+__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, float* __restrict__ dst,
+                                                    int rows, int cols, long src_bs, long dst_bs,
+                                                    const float* __restrict__ addend, int add_mod, int add_skip,
+                                                    float* __restrict__ copy_dst = nullptr) {
+    transpose_body(src, dst, rows, cols, src_bs, dst_bs, addend, add_mod, add_skip, copy_dst, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // dst[z][0..n4) = src[z][0..n4) (16-byte units, batch strides in floats): the pass-through frames of the layer output

@@ -1164,25 +1164,29 @@ int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const fl
 
 // ------------------------------------------------------------------------------------------- block
 // bias tiles + pooling matrices of `n` blocks (workspaces ws0 + i*ws_stride) in ceil(n / PREP_MAXD) launches
+static int prep_args(PrepArgs& a, const cffm_block_params* params, int d0, int nd, float* ws0, long ws_stride, const cffm_block_ws& L) {
+    const int nb = (CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD + 255) / 256;
+    for (int d = 0; d < PREP_MAXD; ++d) {
+        const cffm_block_params& p = params[d0 + (d < nd ? d : 0)];
+        float* ws = ws0 + (long)(d0 + (d < nd ? d : 0)) * ws_stride;
+        a.t[d].own = p.rpb_own; a.t[d].ring = p.rpb_ring;
+        for (int i = 0; i < 4; ++i) { a.t[d].pool[i] = p.rpb_pool[i]; a.pw[d].w[i] = p.pool_w[i]; }
+        a.bias[d] = ws + L.bias; a.M[d] = ws + L.M;
+        a.w[d][0] = p.qkv_w; a.w[d][1] = p.proj_w; a.w[d][2] = p.fc1_w; a.w[d][3] = p.fc2_w;
+        a.w_s[d] = ws + L.w_split;
+        a.w_f[d] = ws + L.w_frag;
+    }
+    a.nbias = nb;
+    a.pack = gemm_use_lib() ? 0 : 1;
+    return nb + 1 + (a.pack ? PREP_WBLOCKS + PREP_FBLOCKS : 0);      // workgroups per block
+}
 static int param_prep(const cffm_block_params* params, int n, float* ws0, long ws_stride, const cffm_block_ws& L, void* stream) {
     PROF(ST_BIAS_ASM);
-    const int nb = (CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD + 255) / 256;
     for (int d0 = 0; d0 < n; d0 += PREP_MAXD) {
         const int nd = (n - d0 < PREP_MAXD) ? n - d0 : PREP_MAXD;
         PrepArgs a;
-        for (int d = 0; d < PREP_MAXD; ++d) {
-            const cffm_block_params& p = params[d0 + (d < nd ? d : 0)];
-            float* ws = ws0 + (long)(d0 + (d < nd ? d : 0)) * ws_stride;
-            a.t[d].own = p.rpb_own; a.t[d].ring = p.rpb_ring;
-            for (int i = 0; i < 4; ++i) { a.t[d].pool[i] = p.rpb_pool[i]; a.pw[d].w[i] = p.pool_w[i]; }
-            a.bias[d] = ws + L.bias; a.M[d] = ws + L.M;
-            a.w[d][0] = p.qkv_w; a.w[d][1] = p.proj_w; a.w[d][2] = p.fc1_w; a.w[d][3] = p.fc2_w;
-            a.w_s[d] = ws + L.w_split;
-            a.w_f[d] = ws + L.w_frag;
-        }
-        a.nbias = nb;
-        a.pack = gemm_use_lib() ? 0 : 1;
-        CFFM_LAUNCH(k_param_prep, (nb + 1 + (a.pack ? PREP_WBLOCKS + PREP_FBLOCKS : 0), nd), (256), 0, (hipStream_t)stream, a);
+        const int pnx = prep_args(a, params, d0, nd, ws0, ws_stride, L);
+        CFFM_LAUNCH(k_param_prep, (pnx, nd), (256), 0, (hipStream_t)stream, a);
     }
     CHECK_LAUNCH("param_prep");
     return 0;
@@ -2080,6 +2084,20 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
     // the parameter-derived tables do not depend on x: they are built on the side stream while the input is transposed
     hipStream_t st = (hipStream_t)stream;
     side_init(st);
+    static int fused_prep = -1;      // CFFM_PREP_FUSED=0: the prep on the side stream beside the transpose (A/B)
+    if (fused_prep < 0) { const char* e = getenv("CFFM_PREP_FUSED"); fused_prep = (e && e[0] == '0') ? 0 : 1; }
+    if (fused_prep && depth <= PREP_MAXD) {
+        // ONE launch: the input transpose (frames 0..2 also copied to y_full) + the parameter prep of every block (k_transpose_prep)
+        PROF(ST_TRANSPOSE);
+        PrepArgs a;
+        const int pnx = prep_args(a, params, 0, depth, blk0, L.total, L);
+        TrArgs T;
+        T.src = x_nchw; T.dst = xs; T.rows = CFFM_C; T.cols = (int)HW; T.src_bs = img; T.dst_bs = img; T.add_mod = 4; T.add_skip = 3; T.copy_dst = y_full;
+        T.gx = ((int)HW + 63) / 64; T.gy = (CFFM_C + 63) / 64; T.gz = g->B * 4;
+        CFFM_LAUNCH(k_transpose_prep, ((unsigned)(T.gx * T.gy * T.gz + pnx * depth)), (256), 0, st, T, a, pnx);
+        CHECK_LAUNCH("transpose + param_prep");
+        g_prep_join.pending = false;
+    } else {
     side_fork_mark(st, 0);
     // NCHW -> NHWC of the four frames; frames 0..2 also go to y_full as they are (the reference's pass-through frames) with the same read
     TRY(transpose_add(x_nchw, xs, g->B * 4, CFFM_C, (int)HW, img, img, nullptr, 4, 3, stream, y_full));
@@ -2092,6 +2110,7 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
         g_prep_join.pending = sd != st && !early;      // joined behind the first block's ln_pool_fwd (block_forward_impl)
         g_prep_join.side = sd;
         if (!g_prep_join.pending) side_join(sd, st, 0);
+    }
     }
 #ifndef CFFM_EMU
     g_side.used = 0;   // (that was this call's only side branch, joined here)

@@ -56,8 +56,8 @@ __device__ __forceinline__ int bias_locate(int h, int q, int n, int& off) {
 __device__ __forceinline__ long biash_index(int h, int q, int n) {
     return ((long)((h * 4 + (q >> 4)) * 19 + (n >> 4)) * 32 + (((n >> 3) & 1) * 16 + (q & 15))) * 8 + (n & 7);
 }
-__device__ __forceinline__ void bias_assemble_body(const BiasTables& t, float* __restrict__ bias, h16* __restrict__ biasH) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void bias_assemble_body(const BiasTables& t, float* __restrict__ bias, h16* __restrict__ biasH, int bx) {
+    const int e = bx * 256 + threadIdx.x;
     if (e >= CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD) return;
     const int n = e % CFFM_NKEY_PAD, q = (e / CFFM_NKEY_PAD) % CFFM_NQ_PAD, h = e / (CFFM_NKEY_PAD * CFFM_NQ_PAD);
     float v = 0.f;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void bias_assemble_body(const BiasTables& t, float* _
     if (biasH) biasH[biash_index(h, q, n)] = (h16)v;
 }
 __global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __restrict__ bias, h16* __restrict__ biasH) {
-    bias_assemble_body(t, bias, biasH);
+    bias_assemble_body(t, bias, biasH, blockIdx.x);
 }
 // Everything a layer's blocks derive from parameters alone (dense bias tiles, composed pooling matrices), for up to
 // PREP_MAXD blocks in one launch: grid (bias workgroups + 1, blocks), the last workgroup of a row builds the pooling matrix.
@@ -93,9 +93,8 @@ struct PrepArgs {
     float* w_f[PREP_MAXD];
     int nbias, pack;
 };
-__global__ void __launch_bounds__(256) k_param_prep(PrepArgs a) {
-    const int d = blockIdx.y, bx = blockIdx.x;
-    if (bx < a.nbias) { bias_assemble_body(a.t[d], nullptr, (h16*)a.bias[d]); return; }
+__device__ __forceinline__ void param_prep_body(const PrepArgs& a, int bx, int d) {
+    if (bx < a.nbias) { bias_assemble_body(a.t[d], nullptr, (h16*)a.bias[d], bx); return; }
     if (bx == a.nbias) { pool_matrix_body(a.pw[d], a.M[d]); return; }
     if (!a.pack) return;
     const long n4[4] = {768 * 256 / 4, 256 * 256 / 4, 1024 * 256 / 4, 256 * 1024 / 4};
@@ -120,6 +119,22 @@ __global__ void __launch_bounds__(256) k_param_prep(PrepArgs a) {
         if (e >= off && e < off + n4[k]) ((f32x4*)a.w_s[d])[e] = split4_pack(((const f32x4*)a.w[d][k])[e - off]);
         off += n4[k];
     }
+}
+__global__ void __launch_bounds__(256) k_param_prep(PrepArgs a) { param_prep_body(a, blockIdx.x, blockIdx.y); }
+// The layer forward's input transpose and the parameter prep of its blocks as ONE launch (round 3): the prep used to run beside the
+// transpose on a side stream, and the join of that stream in front of the first q|k|v GEMM cost the chain ~5 us under graph replay
+// although the prep had long finished.  1-D grid: the transpose's workgroups first, then pnx x (blocks) of the prep.
+struct TrArgs { const float* src; float* dst; int rows, cols; long src_bs, dst_bs; int add_mod, add_skip; float* copy_dst; int gx, gy, gz; };
+__global__ void __launch_bounds__(256) k_transpose_prep(TrArgs T, PrepArgs a, int pnx) {
+    const int nt = T.gx * T.gy * T.gz;
+    int b = blockIdx.x;
+    if (b < nt) {
+        transpose_body(T.src, T.dst, T.rows, T.cols, T.src_bs, T.dst_bs, nullptr, T.add_mod, T.add_skip, T.copy_dst, b % T.gx, (b / T.gx) % T.gy,
+                       b / (T.gx * T.gy));
+        return;
+    }
+    b -= nt;
+    param_prep_body(a, b % pnx, b / pnx);
 }
 
 // dbiasT [8][304][64] (key-major, as the attention backward accumulates it) -> the six tables.
