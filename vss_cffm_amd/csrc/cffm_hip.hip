@@ -1177,7 +1177,9 @@ static int prep_args(PrepArgs& a, const cffm_block_params* params, int d0, int n
         a.w_f[d] = ws + L.w_frag;
     }
     a.nbias = nb;
-    a.pack = gemm_use_lib() ? 0 : 1;
+    // pack: 0 nothing (library GEMMs) | 1 split-4 copy + fragment-ordered copies | 2 fragment-ordered copies only -- every Linear of the
+    // block runs as a row-panel kernel then and nobody reads the split-4 copy (3 MB read + 3 MB written per block saved)
+    a.pack = gemm_use_lib() ? 0 : ((panel_on() && panel_qkv_on()) ? 2 : 1);
     return nb + 1 + (a.pack ? PREP_WBLOCKS + PREP_FBLOCKS : 0);      // workgroups per block
 }
 static int param_prep(const cffm_block_params* params, int n, float* ws0, long ws_stride, const cffm_block_ws& L, void* stream) {

@@ -112,6 +112,7 @@ __device__ __forceinline__ void param_prep_body(const PrepArgs& a, int bx, int d
         }
         return;
     }
+    if (a.pack == 2) return;                                   // (split-4 copy not wanted: see prep_args)
     long e = (long)(bx - a.nbias - 1) * 256 + threadIdx.x;   // float4 index into the concatenated weights
     long off = 0;
 #pragma unroll
