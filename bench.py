@@ -121,7 +121,7 @@ def roofline_kernels(stages, b, nw, hw):
             rd = b * (nr // b * 768 * 2 + 2 * hw * 256 * 4)
             wr = b * (hw * 256 * 4) + b * nw * 304 * 512 * 2 + 54 * 8 * 64 * 304 * 4
             out[name].update({'hbm_bytes': int(rd + wr), 'hbm_write_bytes': int(wr), 'hbm_frac': round((rd + wr) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
-    out['note'] = ('HIP-event intervals of the separate instrumented pass (each includes ~2-3 us of event-record cost); GEMM peak = 2500/3 TF '
+    out['note'] = ('HIP-event intervals of the separate instrumented pass, every kernel on one stream (each includes ~2-3 us of event-record cost); GEMM peak = 2500/3 TF '
                    '(three bf16 MFMA products per fp32 product), attention backward against the f16 MFMA peak, row kernels against 8 TB/s')
     return out
 
@@ -635,12 +635,16 @@ def main():
         except Exception as e:   # noqa: BLE001  (calibration only: the raw interval is still reported)
             sys.stderr.write('bench.py: event-pair calibration failed: %s\n' % e)
             null_ms, null_n = 0.0, 0
-        # separate instrumented pass: every stage, not part of `value` (all ranks step: all-reduces inside)
+        # separate instrumented pass: every stage, not part of `value` (all ranks step: all-reduces inside).  The library's side streams
+        # are switched off for it: each interval then times ONE kernel with the chip to itself (with them on, e.g. the attention
+        # backward was measured while the eager path's weight-gradient GEMMs ran beside it: 72 us for a 45 us kernel)
+        side_was = lib.cffm_side_streams(0)
         lib.cffm_profile_enable(-1 if rank == 0 else 0)
         for _ in range(bsteps):
             eager_step()
         torch.cuda.synchronize(dev)
         lib.cffm_profile_enable(0)
+        lib.cffm_side_streams(side_was)
         lib.cffm_profile_collect(ms_buf, n_buf)
         all_ms, all_n = list(ms_buf), list(n_buf)
     with torch.no_grad():

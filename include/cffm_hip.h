@@ -72,6 +72,7 @@ long cffm_layer_scratch_floats(const cffm_geom* g);
 /* ---- optional per-stage HIP-event timing on the caller's stream (bench.py's live roofline numbers) ---- */
 int cffm_profile_enable(long long stage_mask); /* bit i = stage i; 0 off; -1 all (perturbs: two event records per launch) */
 int cffm_profile_sample_every(int period); /* time every period-th launch of an enabled stage only (1 = all; counted from the next cffm_profile_enable) */
+int cffm_side_streams(int on); /* 0: parameter-gradient work stays on the caller's stream (per-kernel timing); returns the previous setting */
 int cffm_profile_stage_count(void);
 int cffm_profile_null_pair(void* stream); /* stage "event_pair_null": two event records with nothing between (the interval's own cost) */
 const char* cffm_profile_stage_name(int i);

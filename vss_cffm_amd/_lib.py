@@ -43,6 +43,7 @@ SIGNATURES = {
     'cffm_layer_scratch_floats': (cl, [GP]),
     'cffm_profile_enable': (ci, [C.c_longlong]),
     'cffm_profile_sample_every': (ci, [ci]),
+    'cffm_side_streams': (ci, [ci]),
     'cffm_profile_stage_count': (ci, []),
     'cffm_profile_null_pair': (ci, [vp]),
     'cffm_profile_stage_name': (C.c_char_p, [ci]),

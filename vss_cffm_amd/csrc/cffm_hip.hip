@@ -116,6 +116,7 @@ struct ProfScope {
 #define PROF2(stage) (void)0
 #endif
 
+static bool g_side_off = false;     // cffm_side_streams(0): everything on the caller's stream (per-kernel timing passes)
 extern "C" {
 // mask: bit i enables stage i (cffm_profile_stage_name); 0 = off, -1 = every stage.  Each timed launch costs two event
 // records on the stream (~2 us of GPU time), so timing every stage perturbs a ~1.5 ms step by ~25 %: bench.py times only
@@ -145,6 +146,14 @@ int cffm_profile_null_pair(void* stream) {
 #endif
     (void)stream;
     return 0;
+}
+// on = 0: the library's side streams are not used until switched on again -- every kernel of a block backward then runs on the caller's
+// stream, one after the other (bench.py's per-kernel pass: an interval measured while another stream's GEMMs share the chip says
+// little about the kernel).  Returns the previous setting.  Not to be changed while a stream is being captured.
+int cffm_side_streams(int on) {
+    const int was = g_side_off ? 0 : 1;
+    g_side_off = on == 0;
+    return was;
 }
 int cffm_profile_stage_count(void) { return ST_COUNT; }
 const char* cffm_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? k_stage_names[i] : ""; }
@@ -384,7 +393,7 @@ static bool side_init(hipStream_t main) {
         (void)hipGetLastError();
 #endif
     }
-    g_side.on = state == 1;
+    g_side.on = state == 1 && !g_side_off;
     g_side.ns = forced_ns ? forced_ns : (stream_is_capturing(main) ? 4 : 1);
     return g_side.on;
 }
