@@ -39,19 +39,47 @@ def test_row_space_is_64_rows_per_window():
     assert key_src.max() < 64 * 81
 
 
-@pytest.mark.parametrize('h0,w0', [(8, 8), (13, 30), (60, 60)])
-def test_inverse_tables_are_the_inverse(h0, w0):
+@pytest.mark.parametrize('h0,w0', [(7, 7), (5, 20), (8, 8), (14, 21), (13, 30), (60, 60), (64, 64), (60, 108)])
+def test_key_owner_tables_partition_every_reading_of_every_key(h0, w0):
+    """geometry.ko_tables (the key-owner role of the attention backward): every row of the token-row space is owned by exactly one
+    unit; every valid (window, slot) entry of key_src appears in exactly one (unit, pass, layer, key) and names that unit's row;
+    a pass = (reader window, query half), so every reading appears once per half; the 8 per-wave pass ranges tile the unit's passes; the unit count is what the library
+    assumes (cffm_hip.hip ko_units: one per window + 16-cell units of the two stride-1 pooled grids)."""
     key_src, _ = G.tables(h0, w0)
-    inv_ptr, inv_idx = G.inverse_tables(h0, w0)
+    ko, ks = G.ko_tables(h0, w0)
     nw = key_src.shape[0]
-    assert inv_ptr.shape == (64 * nw + 1,) and inv_ptr[-1] == (key_src >= 0).sum() == inv_idx.size
-    flat = key_src.reshape(-1)
-    for row in (0, 48, 49 * nw, 50 * nw + nw // 2, 64 * nw - 1):
-        got = sorted(inv_idx[inv_ptr[row]:inv_ptr[row + 1]].tolist())
-        assert got == sorted(np.nonzero(flat == row)[0].tolist())
-    # some pooled cells are read by nobody (e.g. the last row of the stride-3 grid, off-centre unfold): their
-    # gradient is zero, the gather pass writes zeros for them
-    assert (np.diff(inv_ptr) >= 0).all() and (np.diff(inv_ptr)[:49 * nw] >= 1).all()
+    nu, ou, op, orow, ns = [int(v) for v in ko[:5]]
+    assert nu == nw + 2 * ((nw + 15) // 16) and ns == ks.size and ks.dtype == np.int16 and ko.dtype == np.int32
+    seen = np.zeros((2,) + key_src.shape, np.int32)
+    owned = np.zeros(64 * nw, np.int32)
+    nxt = None
+    costs = []
+    for u in range(nu):
+        rec = ko[ou + 12 * u: ou + 12 * u + 12]
+        rows = ko[rec[0]: rec[0] + 64]
+        assert rec[0] == orow + 64 * u and 1 <= rec[1] <= 4 and (rows[16 * rec[1]:] == -1).all()
+        owned[rows[rows >= 0]] += 1
+        assert (np.diff(rec[2:11]) >= 0).all() and (nxt is None or rec[2] == nxt)       # 8 per-wave pass ranges
+        nxt = rec[10]
+        costs.append(rec[11])
+        for pi in range(rec[2], rec[10]):
+            w, nlp, so, qp = [int(v) for v in ko[op + 4 * pi: op + 4 * pi + 4]]
+            assert so % 64 == 0 and 0 <= w < nw and qp in (0, 1)
+            nl_max = max((nlp >> (4 * t)) & 15 for t in range(4))
+            sl = ks[so: so + 64 * nl_max].reshape(nl_max, 16, 4)
+            for t in range(4):
+                nl = (nlp >> (4 * t)) & 15
+                assert (sl[nl:, :, t] == -1).all()
+                for l in range(nl):
+                    for k in range(16):
+                        n = int(sl[l, k, t])
+                        if n >= 0:
+                            assert key_src[w, n] == rows[16 * t + k]
+                            seen[qp, w, n] += 1
+    assert (owned == 1).all()
+    for qp in (0, 1):                                    # every reading of every key once per query half
+        assert (seen[qp][key_src >= 0] == 1).all() and (seen[qp][key_src < 0] == 0).all()
+    assert costs == sorted(costs, reverse=True)          # long units first: they are dispatched first
 
 
 def test_lds_row_swizzle_is_conflict_free_for_both_read_patterns():

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp, ci, cl, cd, cf = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     'cffm_bias_scatter': (ci, [vp, vp, vp, P4, vp]),
     'cffm_linear_qkv_fwd': (ci, [vp, vp, vp, vp, cl, vp]),
     'cffm_attn_fwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp]),
+    'cffm_attn_bwd_ws_floats': (cl, [GP]),
     'cffm_attn_bwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_linear_fwd': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bias_fwd': (ci, [vp, vp, vp, vp, cl, ci, ci, vp]),

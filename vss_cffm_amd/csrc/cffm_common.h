@@ -14,7 +14,7 @@
 // "off" here, so libcffm_hip.so contains exactly the kernels bench.py runs.
 #ifndef CFFM_EXPERIMENTS
 #if defined(GEMM_ABLATE) || defined(FWD_ABLATE) || defined(BWD_ABLATE) || defined(LNPB_ABLATE) || defined(PNL_ABLATE) || defined(FWD_DMA) || \
-    defined(VFLAG_RD) || defined(FWD_TIMING) || defined(BWD_TIMING) || defined(UPCE_ABLATE)
+    defined(VFLAG_RD) || defined(FWD_TIMING) || defined(BWD_TIMING) || defined(UPCE_ABLATE) || defined(BWD_K_ABLATE) || defined(BWD_Q_ABLATE)
 #error "profiling switches need -DCFFM_EXPERIMENTS"
 #endif
 #endif
@@ -30,6 +30,10 @@
 #define CFFM_NQ_PAD 64
 #define CFFM_NCELL 15      // pooled cells per window: 1 (target) + 1 + 4 + 9
 #define CFFM_HID 1024
+// the dense position bias of a block in its two f16 layouts, one after the other (rowops_kernels.h bias_assemble_body):
+// biasH = MFMA B-operand fragments [8][4][10 tile pairs][64][8] (forward, query-owner backward), biasKT = key-major [8][304][64] (key-owner backward)
+#define BIASH_HALFS (CFFM_HEADS * 4 * 10 * 512)
+#define BIASKT_HALFS (CFFM_HEADS * CFFM_NKEY_PAD * CFFM_NQ_PAD)
 #define CFFM_LN_EPS 1e-5f
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -228,12 +232,20 @@ static inline float buf_ld4(buf_t r, uint32_t voff, uint32_t soff) {
     buf_ld_bytes(r, voff, soff, &t, 1);
     return t;
 }
+static inline f32x2 buf_ld8(buf_t r, uint32_t voff, uint32_t soff) {
+    float t[2];
+    buf_ld_bytes(r, voff, soff, t, 2);
+    return (f32x2){t[0], t[1]};
+}
 static inline void buf_st16(buf_t r, f32x4 v, uint32_t voff, uint32_t soff) {   // out-of-range stores are dropped
     if (soff <= r.n && (uint64_t)voff + 16 <= (uint64_t)(r.n - soff)) __builtin_memcpy(const_cast<char*>(r.p) + soff + voff, &v, 16);
 }
 static inline void buf_st16_pair(buf_t r, f32x4 v0, f32x4 v1, uint32_t voff, uint32_t soff0, uint32_t soff1) {
     buf_st16(r, v0, voff, soff0);
     buf_st16(r, v1, voff, soff1);
+}
+static inline void buf_st4(buf_t r, float v, uint32_t voff, uint32_t soff) {
+    if (soff <= r.n && (uint64_t)voff + 4 <= (uint64_t)(r.n - soff)) __builtin_memcpy(const_cast<char*>(r.p) + soff + voff, &v, 4);
 }
 static inline void buf_st8(buf_t r, f32x2 v, uint32_t voff, uint32_t soff) {
     if (soff <= r.n && (uint64_t)voff + 8 <= (uint64_t)(r.n - soff)) __builtin_memcpy(const_cast<char*>(r.p) + soff + voff, &v, 8);
@@ -253,6 +265,11 @@ __device__ __forceinline__ f32x4 buf_ld16(buf_t r, uint32_t voff, uint32_t soff)
 __device__ __forceinline__ float buf_ld4(buf_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+__device__ __forceinline__ f32x2 buf_ld8(buf_t r, uint32_t voff, uint32_t soff) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __builtin_bit_cast(f32x2, v);
+}
 // 16-byte store: per-lane VGPR offset + uniform (scalar) offset -- no 64-bit per-lane address arithmetic, which the compiler
 // otherwise hoists out of unrolled loops as one VGPR pair per distinct destination
 // HAZARD (measured on MI355X, ROCm 7.2): a buffer_store_dwordx4 with an SGPR offset still reads its data VGPRs for a cycle
@@ -264,6 +281,9 @@ __device__ __forceinline__ void buf_st16(buf_t r, f32x4 v, uint32_t voff, uint32
     u4 w;
     __builtin_memcpy(&w, &v, 16);
     __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st4(buf_t r, float v, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
 }
 __device__ __forceinline__ void buf_st8(buf_t r, f32x2 v, uint32_t voff, uint32_t soff) {   // (8-byte stores are not subject to the hazard)
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));

@@ -73,25 +73,41 @@ __device__ __forceinline__ f16x8 att_tr_frag(const f16* img, int r0, int c0, int
     return cat_f16x4(a, b);
 }
 
+// The same with the lane-dependent part of the address precomputed: for r0 a multiple of 16 the row swizzle depends only on the lane
+// (ATT_SWZ looks at row bits 2..3, r0 contributes bits >= 4), so element offset = 32 r0 + att_tr_lane(c0, lane) (+ 512 for the second
+// half).  The persistent kernels keep the two per-lane constants (c0 = 0, 16) in registers instead of re-deriving -- or, worse,
+// hoisting -- one address per tile.
+__device__ __forceinline__ int att_tr_lane(int c0, int lane) {
+    const int i = lane & 15, row = 4 * (lane >> 4) + (i >> 2), col = c0 + 4 * (i & 3);
+    return ATT_ROW(row, col >> 3) + (col & 7);
+}
+__device__ __forceinline__ f16x8 att_tr_frag_at(const f16* img_r0, int lane_off, bool clamp_second = false) {
+    const f16x4 a = lds_tr4(img_r0 + lane_off);
+    const f16x4 b = lds_tr4(img_r0 + lane_off + (clamp_second ? 0 : 16 * ATT_KS_STRIDE));
+    return cat_f16x4(a, b);
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 // Position bias on the matrix pipe.  `biasH` (k_bias_assemble): the head's additive bias as f16 B-operand fragments,
-// [8 heads][4 waves][19 key tiles][32 lanes][8]: lane 16 g + j (g < 2) holds bias(query 16 wave + j, keys 16 t + 8 g .. + 7); the
-// upper 32 lanes contribute zeros (out-of-range buffer offset: no traffic).  With Sel[i][k-slot] = [k-slot == i] (16 x 32, one
-// constant register quad per lane) the product Sel * B is the [16 keys x 16 queries] bias tile in exactly the C layout of the
-// S^T = K Q^T tiles, so S^T = mfma(K, Q, mfma(Sel, B, mask)): the bias costs 512 bytes per (wave, tile) instead of 1 KB of fp32
-// C-in and no VALU instruction (the mask of the pooled tiles rides in as the first C-in).  Round 1 read a query-major fp32
-// [8][64][304] table, 16 cache lines per quarter-wave; the fragment-ordered fp32 table of the first round-2 version halved the
-// kernel's texture-address work but still moved 78 KB per workgroup, two thirds of its L2 traffic.
-__device__ __forceinline__ f16x8 bias_sel_frag(int lane) {
+// [8 heads][4 waves][10 key-tile pairs][64 lanes][8]: lane 16 g + j holds bias(query 16 wave + j, keys 16 t + 8 (g & 1) .. + 7) of
+// tile t = 2 p + (g >> 1) -- k-slots 0..15 of the fragment carry tile 2 p, k-slots 16..31 tile 2 p + 1 (round 4; rounds 2-3 kept one
+// tile per fragment and let the upper 32 lanes read zeros: twice the registers for the same bytes).  With the two constant
+// selector matrices Sel0[i][k] = [k == i], Sel1[i][k] = [k == 16 + i] (16 x 32, one register quad per lane each) the product
+// Sel_(t & 1) * B is the [16 keys x 16 queries] bias tile of key tile t in exactly the C layout of the S^T = K Q^T tiles, so
+// S^T = mfma(K, Q, mfma(Sel, B, mask)): the bias costs 512 bytes per (wave, tile) instead of 1 KB of fp32 C-in and no VALU
+// instruction (the mask of the pooled tiles rides in as the first C-in), and a wave's whole bias is 10 fragments = 40 VGPRs.
+// Round 1 read a query-major fp32 [8][64][304] table, 16 cache lines per quarter-wave; the fragment-ordered fp32 table of the first
+// round-2 version halved the kernel's texture-address work but still moved 78 KB per workgroup, two thirds of its L2 traffic.
+__device__ __forceinline__ f16x8 bias_sel_frag(int lane, int odd) {
     const int g = lane >> 4, l15 = lane & 15;
     f16x8 a;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = (g < 2 && 8 * g + e == l15) ? (f16)1.f : (f16)0.f;
+    for (int e = 0; e < 8; ++e) a[e] = ((g >> 1) == odd && 8 * (g & 1) + e == l15) ? (f16)1.f : (f16)0.f;
     return a;
 }
-__device__ __forceinline__ buf_t biash_rsrc(const h16* biasH) { return buf_make(biasH, (uint32_t)(CFFM_HEADS * 4 * 19 * 256 * 2)); }
-__device__ __forceinline__ uint32_t biash_voff(int lane) { return lane < 32 ? 16u * (uint32_t)lane : BUF_OOB; }
-__device__ __forceinline__ uint32_t biash_soff(int h, int wave, int t) { return (uint32_t)(((h * 4 + wave) * 19 + t) * 512); }
+__device__ __forceinline__ buf_t biash_rsrc(const h16* biasH) { return buf_make(biasH, (uint32_t)(BIASH_HALFS * 2)); }
+__device__ __forceinline__ uint32_t biash_voff(int lane) { return 16u * (uint32_t)lane; }
+__device__ __forceinline__ uint32_t biash_soff(int h, int wave, int p) { return (uint32_t)(((h * 4 + wave) * 10 + p) * 1024); }
 
 // A window's K / V rows on their way from the f16 q|k|v rows to LDS, held in registers so that the gather of window w+1
 // can be in flight while window w is multiplied (kv_load: key-table entries, then the 16-byte row segments; kv_store:
@@ -171,9 +187,6 @@ __device__ __forceinline__ void stage_kv(buf_t rs_qkv, uint32_t soff_k, const in
 }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads
-#ifndef FWD_BIAS_EARLY
-#define FWD_BIAS_EARLY 8
-#endif
 #ifndef FWD_DMA
 #define FWD_DMA 0   // 1: stage K / V by LDS-DMA (buffer_load ... lds) instead of through registers: measured 15.0 vs 14.5 us -- the
 #endif              //    staging is bound by the L2 -> CU burst of all resident workgroups (scripts/r02_fwd_timing.py), not by the ds_write pass
@@ -251,9 +264,9 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
     // the wave's 19 bias fragments (L2-resident f16 table)
     const buf_t rs_bias = biash_rsrc(biasH);
     const uint32_t bvoff = (FWD_ABLATE & 1) ? BUF_OOB : biash_voff(lane);
-    f16x8 bh[19];
+    f16x8 bh[10];
 #pragma unroll
-    for (int t = 0; t < 19; ++t) bh[t] = buf_ld_h8(rs_bias, bvoff, biash_soff(h, wave, t));
+    for (int t = 0; t < 10; ++t) bh[t] = buf_ld_h8(rs_bias, bvoff, biash_soff(h, wave, t));
     FWD_STAMP(1);
     FWD_STAMP(2);
 #else
@@ -267,14 +280,12 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
                                   (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
     const buf_t rs_bias = biash_rsrc(biasH);
     const uint32_t bvoff = (FWD_ABLATE & 1) ? BUF_OOB : biash_voff(lane);
-    f16x8 bh[19];
+    f16x8 bh[10];
 #pragma unroll
-    for (int t = 0; t < FWD_BIAS_EARLY; ++t) bh[t] = buf_ld_h8(rs_bias, bvoff, biash_soff(h, wave, t));
+    for (int t = 0; t < 10; ++t) bh[t] = buf_ld_h8(rs_bias, bvoff, biash_soff(h, wave, t));
     FWD_STAMP(1);
     kv_store<256>(kv, Ks, Vs, vflag, tid);
     FWD_STAMP(2);
-#pragma unroll
-    for (int t = FWD_BIAS_EARLY; t < 19; ++t) bh[t] = buf_ld_h8(rs_bias, bvoff, biash_soff(h, wave, t));
 #endif
     __syncthreads();
     FWD_STAMP(3);
@@ -284,14 +295,14 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
     // pipe (Sel * B, see bias_sel_frag) with the mask of the tiles that can hold an absent key (the pooled groups, keys >= 181:
     // own and ring keys always exist) as ITS C-in; exp(s - m) is 2^(s log2e - m log2e), one FMA feeding v_exp_f32; the row sums
     // come out of the matrix pipe too (a constant all-ones A operand next to V^T: 10 more MFMAs instead of 76 adds).
-    const f16x8 sel = bias_sel_frag(lane);
+    const f16x8 sel0 = bias_sel_frag(lane, 0), sel1 = bias_sel_frag(lane, 1);
     f32x4 s[19];
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 19; ++t) {
         const f16x8 kf = *(const f16x8*)(Ks + ATT_ROW((16 * t + l15), g));
         const f32x4 c0 = (16 * t + 15 >= CFFM_FIRST_POOLED_KEY) ? vflag4(vflag, 16 * t + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 acc = mfma16x16x32_f16(kf, qfrag, mfma16x16x32_f16(sel, bh[t], c0));   // K Q^T + bias + mask
+        const f32x4 acc = mfma16x16x32_f16(kf, qfrag, mfma16x16x32_f16((t & 1) ? sel1 : sel0, bh[t >> 1], c0));   // K Q^T + bias + mask
         s[t] = acc;
         m = fmaxf(fmaxf(m, acc[0]), fmaxf(fmaxf(acc[1], acc[2]), acc[3]));    // (two v_max3_f32)
     }
@@ -339,390 +350,4 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
         *(f32x4*)(orow + 16) = o[1] * inv;
     }
     FWD_STAMP(6);
-}
-
-#ifdef CFFM_EXPERIMENTS   // measured and rejected (17.2 us at two per CU, spills at three): not in the product library
-// ---- forward, persistent form -------------------------------------------------------------------------------------------
-// grid (8 heads, NG window groups), FWP_OCC workgroups per CU.  The same mathematics as k_cfm_attn_fwd; what changes is where the
-// latencies go.  The one-shot kernel's workgroups all start together and run their phases in lockstep (everybody waits for its
-// gathers, then everybody multiplies), and its 1296 workgroups take two rounds on 1024 slots, the second at a quarter of the
-// occupancy.  Here a workgroup walks `per_group` windows of one head: the head's 19 bias tiles are loaded ONCE and stay in
-// registers, the key-table entries arrive two windows ahead and the K/V rows one window ahead (KvTab / KvRegs), so window i+1's
-// gather latency hides behind window i's arithmetic, and the groups are sized so that the grid fits the chip in ONE round with
-// every workgroup doing the same number of windows.
-#ifndef FWP_OCC
-#define FWP_OCC 3
-#endif
-#define ATT_FWP_LDS ((CFFM_NKEY_PAD + ATT_VROWS) * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
-__global__ void __launch_bounds__(256, FWP_OCC) k_cfm_attn_fwd_p(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
-                                                                const int* __restrict__ q_dst, const h16* __restrict__ biasH,
-                                                                float* __restrict__ ao, float* __restrict__ lse_out, int per_group) {
-    CFFM_DYN_SMEM(smem);
-    f16* Ks = (f16*)smem;
-    f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
-    float* vflag = (float*)(Vs + ATT_VROWS * ATT_KS_STRIDE);
-    const int h = blockIdx.x, grp = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-    const int g = lane >> 4, l15 = lane & 15;
-    const int qcol = 16 * wave + l15;
-    const int wb0 = grp * per_group;
-    const int wb1 = (wb0 + per_group < G.B * G.nW) ? wb0 + per_group : G.B * G.nW;
-    const buf_t rs_bias = biash_rsrc(biasH);
-    const f16x8 sel = bias_sel_frag(lane);
-    f16x8 bT[19];
-#pragma unroll
-    for (int t = 0; t < 19; ++t) bT[t] = buf_ld_h8(rs_bias, biash_voff(lane), biash_soff(h, wave, t));
-    if (tid < 64) {    // 16 zero rows past key 303: the last PV k-step reads V rows 288..319 transposed
-        f16x8 z8;
-        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
-        *(f16x8*)(Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE + 8 * tid) = z8;
-    }
-    const buf_t rs_qkv = qkv_rsrc(G, qkv);
-    KvRegs<256> kv;
-    KvTab<256> tabn;
-    f16x8 qn;          // Q fragment of the window whose rows are in flight
-    int dstc = -1, dstn = -1;
-    auto qload = [&](int wbx) {
-        return buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)((wbx % G.nW) * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
-                         (uint32_t)(((long)(wbx / G.nW) * G.RC * 768 + h * CFFM_HD) * 2));
-    };
-    auto qdst = [&](int wbx) { return (qcol < CFFM_WA) ? q_dst[(wbx % G.nW) * CFFM_WA + qcol] : -1; };
-    if (wb0 < wb1) {
-        kv_load<256>(kv, rs_qkv, qkv_soff_k(G, wb0 / G.nW, h), key_src + (wb0 % G.nW) * CFFM_NKEY_PAD, tid);
-        qn = qload(wb0);
-        dstc = qdst(wb0);
-    }
-    if (wb0 + 1 < wb1) {
-        kv_tab_load<256>(tabn, key_src + ((wb0 + 1) % G.nW) * CFFM_NKEY_PAD, tid);
-        dstn = qdst(wb0 + 1);
-    }
-    f16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
-    for (int wb = wb0; wb < wb1; ++wb) {
-        const int b = wb / G.nW;
-        kv_store<256>(kv, Ks, Vs, vflag, tid);
-        const f16x8 qfrag = qn;
-        const int dst = dstc;
-        __syncthreads();
-        if (wb + 1 < wb1) {       // the next window's rows and Q fragment fly while this one is multiplied
-            kv_rows_load<256>(kv, tabn, rs_qkv, qkv_soff_k(G, (wb + 1) / G.nW, h), tid);
-            qn = qload(wb + 1);
-            dstc = dstn;
-        }
-        if (wb + 2 < wb1) {
-            kv_tab_load<256>(tabn, key_src + ((wb + 2) % G.nW) * CFFM_NKEY_PAD, tid);
-            dstn = qdst(wb + 2);
-        }
-        // S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column (see k_cfm_attn_fwd for the VALU budget)
-        f32x4 s[19];
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 19; ++t) {
-            const f16x8 kf = *(const f16x8*)(Ks + ATT_ROW((16 * t + l15), g));
-            const f32x4 c0 = (16 * t + 15 >= CFFM_FIRST_POOLED_KEY) ? vflag4(vflag, 16 * t + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            s[t] = mfma16x16x32_f16(kf, qfrag, mfma16x16x32_f16(sel, bT[t], c0));
-            m = fmaxf(fmaxf(m, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float m2 = m * CFFM_LOG2E;
-        f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, osum = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 10; ++kt) {
-            f16x4 ph[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = 2 * kt + u;
-                if (t < 19) {
-                    f32x4 p;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] = fast_exp2(fmaf(s[t < 19 ? t : 0][r], CFFM_LOG2E, -m2));
-                    ph[u] = to_f16x4(p);
-                } else {
-                    ph[u] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                }
-            }
-            const f16x8 pf = cat_f16x4(ph[0], ph[1]);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) o[mt] = mfma16x16x32_f16(att_tr_frag(Vs, 32 * kt, 16 * mt, lane), pf, o[mt]);
-            osum = mfma16x16x32_f16(ones, pf, osum);
-        }
-        const float l = osum[0];
-        // epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821)
-        if (g == 0) lse_out[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + qcol] = (qcol < CFFM_WA) ? m + logf(l) : 0.f;
-        if (dst >= 0) {
-            const float inv = 1.f / l;
-            float* orow = ao + ((long)b * G.HW + dst) * CFFM_C + h * CFFM_HD + 4 * g;
-            *(f32x4*)(orow) = o[0] * inv;
-            *(f32x4*)(orow + 16) = o[1] * inv;
-        }
-        __syncthreads();   // LDS is restaged for the next window
-    }
-}
-
-#endif  // CFFM_EXPERIMENTS
-
-// =====================================================================================================
-// Fused backward (round 2): ONE kernel does what k_cfm_attn_bwd_q + k_cfm_attn_bwd_kv did with two stagings, two S / dP
-// recomputations and two exp passes.  grid (8 heads, NG window groups), 256 threads = 4 waves x 16 queries, two workgroups
-// per CU (66 KB of LDS, <= 256 registers).  Per window, the 304 key slots are walked in 10 chunks of 32 keys:
-//   query-owner half (S^T orientation: C rows = keys, C columns = queries; a wave owns 16 queries):
-//       S^T = K Q^T + bias (+mask), dP^T = V dO^T, P = 2^(S log2e - LSE log2e), dS = P (dP - D);
-//       the head's bias gradient accumulates in registers over the whole window group (19 x 4 per lane);
-//       dQ^T += K^T dS^T with dS^T straight from the C registers (contraction over keys = C rows);
-//       P and dS (f16) are also written to a [64 queries][32 keys] exchange image in LDS;
-//   key-owner half (after ONE barrier; the exchange image is double-buffered): contraction over QUERIES, which the C layout of
-//       the S^T orientation cannot feed from registers -- the exchange image read back through the LDS transpose read can:
-//       wave (u, which): key tile 2 kt + u, dV^T = dO^T P (which = 0) or dK^T = Q^T dS (which = 1), both operands via
-//       att_tr_frag so that their k-slot <-> query maps agree; the finished 16-key x 32-channel tile goes to the window's
-//       partial rows (k_dkv_gather sums them per token row, deterministic).
-// dO is rescaled per window by a power of two so that every f16 gradient operand sits near 1 (training-size gradients of 1e-6
-// would flush to zero in f16); results are scaled back in f32.
-// =====================================================================================================
-#define ATT_BWD_XROWS 64
-#define ATT_BWD_LDS ((ATT_VROWS + CFFM_NKEY_PAD + 2 * 64 + 4 * ATT_BWD_XROWS) * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
-#ifdef BWD_TIMING   // profiling builds only: shader-clock stamps of wave 0 of workgroups (head 0, group 0 / 7 / 30), first window
-__device__ long long g_bwd_t[3 * 16];
-#define BWD_STAMP(i) do { if (tid == 0 && blockIdx.x == 0 && wb == wb0 && (grp == 0 || grp == 7 || grp == 30)) g_bwd_t[(grp == 0 ? 0 : grp == 7 ? 1 : 2) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define BWD_STAMP(i)
-#endif
-#ifndef BWD_ABLATE
-#define BWD_ABLATE 0   // profiling builds only: 1 no key-owner half, 2 no partial-row stores, 4 no exp
-#endif
-__global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
-                                                           const int* __restrict__ q_dst, const h16* __restrict__ biasH,
-                                                           const float* __restrict__ ao, const float* __restrict__ dao,
-                                                           const float* __restrict__ lse_in, float* __restrict__ dqkv,
-                                                           float* __restrict__ dbias_part, float* __restrict__ dkv_part, int per_group) {
-    CFFM_DYN_SMEM(smem);
-    f16* Ks = (f16*)smem;                                   // K rows (+16 zero rows: read transposed 32 keys at a time)
-    f16* Vs = Ks + ATT_VROWS * ATT_KS_STRIDE;
-    f16* Qs = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;           // 64 query rows
-    f16* dOs = Qs + 64 * ATT_KS_STRIDE;
-    f16* Xs = dOs + 64 * ATT_KS_STRIDE;                     // exchange images: [buffer 2][P | dS][64 queries][32 keys]
-    float* vflag = (float*)(Xs + 4 * ATT_BWD_XROWS * ATT_KS_STRIDE);
-    float* slse = vflag + CFFM_NKEY_PAD;                    // LSE * log2(e) per query
-    float* sD = slse + 64;                                  // rowsum(dO * O) * sc per query
-    float* smax = sD + 64;
-
-    const int h = blockIdx.x, grp = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-    const int g = lane >> 4, l15 = lane & 15;
-    const int qcol = 16 * wave + l15;
-    const float scale = 0.17677669529663687f;
-    const int wb0 = grp * per_group;
-    const int wb1 = (wb0 + per_group < G.B * G.nW) ? wb0 + per_group : G.B * G.nW;
-    // the bias tiles and the partial rows go through buffer resources: one 32-bit per-lane offset each, everything else is a
-    // scalar offset (with plain pointers the compiler hoists one 64-bit per-lane address per tile out of the unrolled loops
-    // and spills: 85 registers in the first version of this kernel)
-    const buf_t rs_bias = biash_rsrc(biasH);
-    const uint32_t bias_soff = biash_soff(h, wave, 0), bias_voff = biash_voff(lane);
-    const f16x8 sel = bias_sel_frag(lane);
-    // partial rows as f16 (row = 512 halfs: K | V x 8 heads x 32) in units of the window's power-of-two dO scale, which goes to
-    // part_scale[window][head]: half the bytes of fp32 rows on the way out and in k_dkv_gather
-    const buf_t rs_part = buf_make(dkv_part, (uint32_t)((long)G.B * G.nW * CFFM_NKEY_PAD * 512 * 2));
-    float* part_scale = dkv_part + (long)G.B * G.nW * CFFM_NKEY_PAD * 256;
-    const buf_t rs_qkv = qkv_rsrc(G, qkv);
-    const buf_t rs_ao = buf_make(ao, (uint32_t)((long)G.B * G.HW * CFFM_C * 4));
-    const buf_t rs_dao = buf_make(dao, (uint32_t)((long)G.B * G.HW * CFFM_C * 4));
-    const int srow = tid >> 2, sc4 = tid & 3;               // staging role: row (query) srow, 16-byte chunk sc4 of Q / 8 channels of dO, O
-
-    f32x4 dB[19];
-#pragma unroll
-    for (int t = 0; t < 19; ++t) dB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tid < 64) {
-        f16x8 z8;
-        for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
-        *(f16x8*)(Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE + 8 * tid) = z8;
-    }
-    KvTab<256> tab;
-    if (wb0 < wb1) kv_tab_load<256>(tab, key_src + (wb0 % G.nW) * CFFM_NKEY_PAD, tid);
-
-    for (int wb = wb0; wb < wb1; ++wb) {
-        const int w = wb % G.nW, b = wb / G.nW;
-        BWD_STAMP(0);
-        // ---- stage: K / V rows (table entries were fetched during the previous window), Q rows, dO / O rows -> D, |dO| maximum
-        KvRegs<256> kv;
-        kv_rows_load<256>(kv, tab, rs_qkv, qkv_soff_k(G, b, h), tid);
-        const int qd = (srow < CFFM_WA) ? q_dst[w * CFFM_WA + srow] : -1;
-        const f16x8 qrow = buf_ld_h8(rs_qkv, srow < CFFM_WA ? (uint32_t)(w * CFFM_WA + srow) * 1536u + 16u * sc4 : BUF_OOB,
-                                     (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
-        const uint32_t po = qd >= 0 ? (uint32_t)qd * (CFFM_C * 4u) + 32u * sc4 : BUF_OOB;
-        const uint32_t ps = (uint32_t)(((long)b * G.HW * CFFM_C + h * CFFM_HD) * 4);
-        f32x4 r0 = buf_ld16(rs_dao, po, ps), r1 = buf_ld16(rs_dao, po, ps + 16);
-        const f32x4 o0 = buf_ld16(rs_ao, po, ps), o1 = buf_ld16(rs_ao, po, ps + 16);
-        if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid] * CFFM_LOG2E;
-        if (wb + 1 < wb1) kv_tab_load<256>(tab, key_src + ((wb + 1) % G.nW) * CFFM_NKEY_PAD, tid);   // next window's entries
-        BWD_STAMP(1);
-        kv_store<256>(kv, Ks, Vs, vflag, tid);
-        *(f16x8*)(Qs + ATT_ROW(srow, sc4)) = qrow;
-        BWD_STAMP(2);
-        float d = (r0[0] * o0[0] + r0[1] * o0[1]) + (r0[2] * o0[2] + r0[3] * o0[3]) + (r1[0] * o1[0] + r1[1] * o1[1]) + (r1[2] * o1[2] + r1[3] * o1[3]);
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        float amax = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
-        amax = wave_max(amax);
-        if (lane == 0) smax[wave] = amax;
-        __syncthreads();
-        const float am = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-        int ex = 0;
-        if (am > 0.f) frexpf(am, &ex);
-        const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f, isc = 1.f / sc;   // max|dO * sc| in [1,2) over the window
-        if (sc4 == 0) sD[srow] = d * sc;
-        {
-            f16x8 dh;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { dh[e] = (f16)(r0[e] * sc); dh[4 + e] = (f16)(r1[e] * sc); }
-            *(f16x8*)(dOs + ATT_ROW(srow, sc4)) = dh;
-        }
-        __syncthreads();
-
-        BWD_STAMP(3);
-        const f16x8 qfrag = *(const f16x8*)(Qs + ATT_ROW(qcol, g));
-        const f16x8 dofrag = *(const f16x8*)(dOs + ATT_ROW(qcol, g));
-        const float lq2 = slse[qcol], Dq = sD[qcol];
-        f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-        const int ku = wave & 1, kwhich = wave >> 1;          // key-owner role of this wave
-        const f16* kimg = kwhich ? Qs : dOs;
-        const uint32_t part_voff = (uint32_t)(l15 * 1024 + ((kwhich ? 0 : 256) + h * CFFM_HD + 4 * g) * 2);
-        if (tid == 0) part_scale[(long)wb * CFFM_HEADS + h] = isc;
-
-        // Software pipeline over the 10 chunks: between two barriers a wave runs the key-owner half of chunk kt AND the
-        // query-owner half of chunk kt + 1 -- two independent dependency chains the scheduler interleaves (one chain alone
-        // leaves the wave parked on LDS / MFMA / exp latencies: the first version, one chain per barrier interval, ran at 45 %
-        // issue utilisation).  The bias tiles of a chunk are loaded one interval ahead, BEFORE the previous interval's
-        // partial-row stores (a load older than the stores never waits for them: gfx9's vmcnt counts both, in order).
-        f16x8 cb0 = buf_ld_h8(rs_bias, bias_voff, bias_soff), cb1 = buf_ld_h8(rs_bias, bias_voff, bias_soff + 512);
-        f16x8 nb0 = buf_ld_h8(rs_bias, bias_voff, bias_soff + 1024), nb1 = buf_ld_h8(rs_bias, bias_voff, bias_soff + 1536);
-#define BWD_QHALF(KT)                                                                                                                  \
-        {                                                                                                                               \
-            f16* Px_ = Xs + ((KT) & 1) * 2 * ATT_BWD_XROWS * ATT_KS_STRIDE;                                                             \
-            f16* Sx_ = Px_ + ATT_BWD_XROWS * ATT_KS_STRIDE;                                                                             \
-            f16x4 dsh[2];                                                                                                               \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                             \
-                const int t = 2 * (KT) + u;                                                                                             \
-                if (t < 19) {                                                                                                           \
-                    const f16x8 kf = *(const f16x8*)(Ks + ATT_ROW((16 * t + l15), g));                                                  \
-                    const f16x8 vf = *(const f16x8*)(Vs + ATT_ROW((16 * t + l15), g));                                                  \
-                    const f32x4 c0 = (16 * t + 15 >= CFFM_FIRST_POOLED_KEY) ? vflag4(vflag, 16 * t + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f}; \
-                    const f32x4 sv = mfma16x16x32_f16(kf, qfrag, mfma16x16x32_f16(sel, u ? cb1 : cb0, c0));                             \
-                    const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});                                         \
-                    f32x4 pr, ds;                                                                                                       \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                     \
-                        pr[r] = (BWD_ABLATE & 4) ? fmaf(sv[r], CFFM_LOG2E, -lq2) : fast_exp2(fmaf(sv[r], CFFM_LOG2E, -lq2));            \
-                        ds[r] = pr[r] * (dp[r] - Dq);                                                                                   \
-                    }                                                                                                                   \
-                    dB[t < 19 ? t : 0] += ds * isc;                                                                                     \
-                    dsh[u] = to_f16x4(ds);                                                                                              \
-                    /* exchange images: row = query, 8 bytes = keys 16u + 4g .. +3 of this chunk */                                     \
-                    *(f16x4*)(Px_ + ATT_ROW(qcol, 2 * u + (g >> 1)) + 4 * (g & 1)) = to_f16x4(pr);                                      \
-                    *(f16x4*)(Sx_ + ATT_ROW(qcol, 2 * u + (g >> 1)) + 4 * (g & 1)) = dsh[u];                                            \
-                } else {                                                                                                                \
-                    dsh[u] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};                                                           \
-                }                                                                                                                       \
-            }                                                                                                                           \
-            const f16x8 dsf = cat_f16x4(dsh[0], dsh[1]);                                                                                \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                            \
-                dq[mt] = mfma16x16x32_f16(att_tr_frag(Ks, 32 * (KT), 16 * mt, lane), dsf, dq[mt]);                                      \
-        }
-        BWD_QHALF(0)
-        BWD_STAMP(4);
-#pragma unroll
-        for (int kt = 0; kt < 10; ++kt) {
-            const f16* Px = Xs + (kt & 1) * 2 * ATT_BWD_XROWS * ATT_KS_STRIDE;
-            const f16* Sx = Px + ATT_BWD_XROWS * ATT_KS_STRIDE;
-            __syncthreads();   // chunk kt's P / dS images are complete (double-buffered: this buffer is rewritten only after the next barrier)
-            BWD_STAMP(5 + kt);
-            sched_fence();
-            // bias tiles: chunk kt + 1's become current, chunk kt + 2's go in flight
-            cb0 = nb0; cb1 = nb1;
-            if (2 * kt + 4 < 19) nb0 = buf_ld_h8(rs_bias, bias_voff, bias_soff + 512 * (2 * kt + 4));
-            if (2 * kt + 5 < 19) nb1 = buf_ld_h8(rs_bias, bias_voff, bias_soff + 512 * (2 * kt + 5));
-            // ---- query-owner half of the NEXT chunk (independent of the key-owner half below: interleaved by the scheduler)
-            if (kt + 1 < 10) BWD_QHALF(kt + 1)
-            // ---- key-owner half: wave (ku, kwhich) finishes key tile 2 kt + ku for dV (kwhich 0) or dK (kwhich 1)
-            const int tk = 2 * kt + ku;
-            if (tk < 19 && !(BWD_ABLATE & 1)) {
-                const f16* X = kwhich ? Sx : Px;
-                f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 xb = att_tr_frag(X, 32 * ks, 16 * ku, lane);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) acc[dt] = mfma16x16x32_f16(att_tr_frag(kimg, 32 * ks, 16 * dt, lane), xb, acc[dt]);
-                }
-                // tile [d = 16 dt + 4 g + r][key = l15]: every lane owns 16 contiguous bytes of a key row of this window's slot;
-                // present keys only (flag 0, -inf otherwise): an absent key's store goes out of range and is dropped
-                const int key = 16 * tk + l15;
-                if (!(BWD_ABLATE & 2)) {
-                    const uint32_t so = (uint32_t)(((long)wb * CFFM_NKEY_PAD + 16 * tk) * 1024);
-                    const uint32_t vo = vflag[key] == 0.f ? part_voff : BUF_OOB;
-                    buf_st8(rs_part, __builtin_bit_cast(f32x2, to_f16x4(acc[0])), vo, so);
-                    buf_st8(rs_part, __builtin_bit_cast(f32x2, to_f16x4(acc[1])), vo, so + 32);
-                }
-            }
-        }
-#undef BWD_QHALF
-        sched_fence();
-        BWD_STAMP(15);
-        if (qcol < CFFM_WA) {
-            float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
-            *(f32x4*)(drow) = dq[0] * (scale * isc);      // d(raw q): the stored q carries the 32^-0.5 factor
-            *(f32x4*)(drow + 16) = dq[1] * (scale * isc);
-        }
-        __syncthreads();  // LDS is restaged for the next window
-    }
-    // the group's bias gradient: one plain [304 keys][64 queries] tile per (group, head); k_sum_splits adds the groups
-    // (rows of padded queries / keys are exact zeros)
-    float* dst = dbias_part + (((long)grp * CFFM_HEADS + h) * CFFM_NKEY_PAD) * CFFM_NQ_PAD + qcol;
-#pragma unroll
-    for (int t = 0; t < 19; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(16 * t + 4 * g + r) * CFFM_NQ_PAD] = dB[t][r];
-}
-
-// dqkv[b][row][256..767] = sum over the (window, key slot) pairs that read `row` of the partial rows dkv_part[b*nW + window][slot]
-// (512 halfs each, in units of part_scale[window][head]); inv_ptr [RC+1], inv_idx [nnz] = CSR inverse of key_src (per clip).
-// One wave per token row, a lane owns 8 channels of one head; pooled rows also get their (unused) q third zeroed so the qkv
-// weight/bias gradient GEMMs see zeros there.  grid (ceil(RC/4), B).
-__global__ void __launch_bounds__(256) k_dkv_gather(Geo G, const int* __restrict__ inv_ptr, const int* __restrict__ inv_idx,
-                                                     const float* __restrict__ dkv_part, float* __restrict__ dqkv) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
-    if (row >= G.RC) return;
-    const int e0 = inv_ptr[row], e1 = inv_ptr[row + 1];
-    const h16* part = (const h16*)dkv_part + (long)b * G.nW * CFFM_NKEY_PAD * 512 + 8 * lane;
-    const float* scl = dkv_part + (long)G.B * G.nW * CFFM_NKEY_PAD * 256 + (long)b * G.nW * CFFM_HEADS + ((lane & 31) >> 2);
-    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    for (int eb = e0; eb < e1; eb += 64) {          // a row has at most 49 readers; the loop is for generality
-        const int n = (e1 - eb < 64) ? e1 - eb : 64;
-        const int mine = (lane < n) ? inv_idx[eb + lane] : 0;   // the whole reader list in one load
-        int e = 0;
-        for (; e + 3 < n; e += 4) {                 // 4 independent 16-B loads (+ their scales) in flight per lane
-            const int i0 = __shfl(mine, e, 64), i1 = __shfl(mine, e + 1, 64), i2 = __shfl(mine, e + 2, 64), i3 = __shfl(mine, e + 3, 64);
-            const h16x8 x0 = *(const h16x8*)(part + (long)i0 * 512), x1 = *(const h16x8*)(part + (long)i1 * 512);
-            const h16x8 x2 = *(const h16x8*)(part + (long)i2 * 512), x3 = *(const h16x8*)(part + (long)i3 * 512);
-            const float s0 = scl[(i0 / CFFM_NKEY_PAD) * CFFM_HEADS], s1 = scl[(i1 / CFFM_NKEY_PAD) * CFFM_HEADS];
-            const float s2 = scl[(i2 / CFFM_NKEY_PAD) * CFFM_HEADS], s3 = scl[(i3 / CFFM_NKEY_PAD) * CFFM_HEADS];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                a0[c] += ((float)x0[c] * s0 + (float)x1[c] * s1) + ((float)x2[c] * s2 + (float)x3[c] * s3);
-                a1[c] += ((float)x0[4 + c] * s0 + (float)x1[4 + c] * s1) + ((float)x2[4 + c] * s2 + (float)x3[4 + c] * s3);
-            }
-        }
-        for (; e < n; ++e) {
-            const int i0 = __shfl(mine, e, 64);
-            const h16x8 x0 = *(const h16x8*)(part + (long)i0 * 512);
-            const float s0 = scl[(i0 / CFFM_NKEY_PAD) * CFFM_HEADS];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { a0[c] += (float)x0[c] * s0; a1[c] += (float)x0[4 + c] * s0; }
-        }
-    }
-    float* drow = dqkv + ((long)b * G.RC + row) * 768;
-    *(f32x4*)(drow + 256 + 8 * lane) = a0;
-    *(f32x4*)(drow + 256 + 8 * lane + 4) = a1;
-    if (row >= CFFM_WA * G.nW) *(f32x4*)(drow + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
