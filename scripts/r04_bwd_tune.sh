@@ -17,3 +17,4 @@ python -m pytest tests/test_attn_bwd.py -x -q -m gpu 2>&1 | tail -2
 LIB=; run product X=1
 for l in $R/build/libcffm_x*.so; do [ -f $l ] && LIB=$l && run $(basename $l) X=1; done
 } 2>&1 | grep -v "^$\|amdgpu.ids" | tee gpurun_out/r04_bwd_tune_${1:-a}.txt
+{ LIB=$R/build/libcffm_exp.so; [ -f $LIB ] && for nk in 32 64 236; do run nk$nk CFFM_BWD_NK=$nk; done; } 2>&1 | grep -v "^$\|amdgpu.ids" | tee -a gpurun_out/r04_bwd_tune_${1:-a}.txt

@@ -41,45 +41,51 @@ def test_row_space_is_64_rows_per_window():
 
 @pytest.mark.parametrize('h0,w0', [(7, 7), (5, 20), (8, 8), (14, 21), (13, 30), (60, 60), (64, 64), (60, 108)])
 def test_key_owner_tables_partition_every_reading_of_every_key(h0, w0):
-    """geometry.ko_tables (the key-owner role of the attention backward): every row of the token-row space is owned by exactly one
-    unit; every valid (window, slot) entry of key_src appears in exactly one (unit, pass, layer, key) and names that unit's row;
-    a pass = (reader window, query half), so every reading appears once per half; the 8 per-wave pass ranges tile the unit's passes; the unit count is what the library
-    assumes (cffm_hip.hip ko_units: one per window + 16-cell units of the two stride-1 pooled grids)."""
+    """geometry.ko_tables (the key-owner kernel of the attention backward): every row of the token-row space is owned by exactly one
+    unit; every valid (window, slot) entry of key_src is multiplied exactly once per query half, by the job of the wave that holds
+    the key's tile, against the reader staged in the job's slot; main units: wave v = tile v, both halves; the unit count is what
+    the library's grid sizing assumes; long units come first."""
     key_src, _ = G.tables(h0, w0)
     ko, ks = G.ko_tables(h0, w0)
     nw = key_src.shape[0]
-    nu, ou, op, orow, ns = [int(v) for v in ko[:5]]
-    assert nu == nw + 2 * ((nw + 15) // 16) and ns == ks.size and ks.dtype == np.int16 and ko.dtype == np.int32
+    nu, ou, oi, orow, ns = [int(v) for v in ko[:5]]
+    assert nu == G.ko_unit_count(h0, w0) and ns == ks.size and ks.dtype == np.int16 and ko.dtype == np.int32
     seen = np.zeros((2,) + key_src.shape, np.int32)
     owned = np.zeros(64 * nw, np.int32)
-    nxt = None
-    costs = []
+    nxt, lengths = None, []
     for u in range(nu):
-        rec = ko[ou + 12 * u: ou + 12 * u + 12]
-        rows = ko[rec[0]: rec[0] + 64]
-        assert rec[0] == orow + 64 * u and 1 <= rec[1] <= 4 and (rows[16 * rec[1]:] == -1).all()
+        rows_off, ntile, kind, ib, ie, base = [int(v) for v in ko[ou + 8 * u: ou + 8 * u + 6]]
+        rows = ko[rows_off: rows_off + 64]
+        assert rows_off == orow + 64 * u and 1 <= ntile <= 4 and (rows[16 * ntile:] == -1).all() and (kind == 0 or ntile == 1)
         owned[rows[rows >= 0]] += 1
-        assert (np.diff(rec[2:11]) >= 0).all() and (nxt is None or rec[2] == nxt)       # 8 per-wave pass ranges
-        nxt = rec[10]
-        costs.append(rec[11])
-        for pi in range(rec[2], rec[10]):
-            w, nlp, so, qp = [int(v) for v in ko[op + 4 * pi: op + 4 * pi + 4]]
-            assert so % 64 == 0 and 0 <= w < nw and qp in (0, 1)
-            nl_max = max((nlp >> (4 * t)) & 15 for t in range(4))
-            sl = ks[so: so + 64 * nl_max].reshape(nl_max, 16, 4)
-            for t in range(4):
-                nl = (nlp >> (4 * t)) & 15
-                assert (sl[nl:, :, t] == -1).all()
-                for l in range(nl):
+        assert ie > ib and (nxt is None or ib == nxt) and base % 32 == 0
+        nxt = ie
+        lengths.append(ie - ib)
+        for i in range(ib, ie):
+            rec = ko[oi + 16 * i: oi + 16 * i + 16]
+            readers = (int(rec[0]), int(rec[1]))
+            assert 0 <= readers[0] < nw and -1 <= readers[1] < nw
+            for v in range(4):
+                fl = int(rec[4 + 3 * v])
+                if fl == 0:
+                    continue
+                rs, qpm, nl = fl & 3, (fl >> 2) & 3, fl >> 4
+                w = readers[rs]
+                assert rs < 2 and w >= 0 and nl >= 1 and (qpm == 3 if kind == 0 else qpm == 1 << (v & 1))
+                t = 0 if kind else v
+                blk = ks[base + ((i - ib) * 4 + v) * 32: base + ((i - ib) * 4 + v) * 32 + 32].reshape(16, 2)
+                assert nl <= 2 and (blk[:, nl:] == -1).all()
+                for sl in blk.T[:nl]:
                     for k in range(16):
-                        n = int(sl[l, k, t])
+                        n = int(sl[k])
                         if n >= 0:
                             assert key_src[w, n] == rows[16 * t + k]
-                            seen[qp, w, n] += 1
+                            for qp in (0, 1):
+                                seen[qp, w, n] += (qpm >> qp) & 1
     assert (owned == 1).all()
-    for qp in (0, 1):                                    # every reading of every key once per query half
+    for qp in (0, 1):
         assert (seen[qp][key_src >= 0] == 1).all() and (seen[qp][key_src < 0] == 0).all()
-    assert costs == sorted(costs, reverse=True)          # long units first: they are dispatched first
+    assert lengths == sorted(lengths, reverse=True)
 
 
 def test_lds_row_swizzle_is_conflict_free_for_both_read_patterns():

@@ -314,6 +314,42 @@ __device__ __forceinline__ void buf_ld16_lds(buf_t r, uint32_t voff, uint32_t so
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 #endif
+// the same, 4 bytes per lane (a row of 64 floats)
+#ifdef CFFM_EMU
+static inline void buf_ld4_lds(buf_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    const int lane = emu::lane_linear() & 63;
+    buf_ld_bytes(r, voff, soff, (char*)lds_wave_base + 4 * lane, 1);
+}
+#else
+__device__ __forceinline__ void buf_ld4_lds(buf_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff, soff, 0, 0);
+}
+#endif
+// LDS-DMA the compiler does not see (inline assembly, no memory clobber).  hipcc models the builtin above as a store to LDS of unknown
+// extent: behind it, the first LDS read it cannot prove disjoint -- the transposed reads of the OTHER buffer of a double-buffered
+// pipeline -- gets an s_waitcnt vmcnt(0) in front, i.e. the multiplication waits for the gather it was meant to hide (measured in the
+// key-owner kernel of the attention backward).  The caller orders these by hand: wait_vm0() + a barrier before anything reads the
+// destination, and a barrier between the last read of a buffer and the DMA that refills it.
+#ifdef CFFM_EMU
+typedef buf_t dma_t;
+static inline dma_t dma_make(const void* p, uint32_t bytes) { return buf_make(p, bytes); }
+static inline void dma_ld16(dma_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) { buf_ld16_lds(r, voff, soff, lds_wave_base); }
+static inline void dma_ld4(dma_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) { buf_ld4_lds(r, voff, soff, lds_wave_base); }
+#else
+typedef int dma_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_t dma_make(const void* p, uint32_t bytes) {      // raw buffer descriptor: base, stride 0, extent, gfx9 flags
+    const uint64_t a = (uint64_t)p;
+    return (dma_t){(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void dma_ld16(dma_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(l), "v"(voff), "s"(r), "s"(soff) : "m0");
+}
+__device__ __forceinline__ void dma_ld4(dma_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(l), "v"(voff), "s"(r), "s"(soff) : "m0");
+}
+#endif
 // 8 stored halfs through a buffer resource (zeros when out of range)
 __device__ __forceinline__ f16x8 buf_ld_h8(buf_t r, uint32_t voff, uint32_t soff) {
     const f32x4 raw = buf_ld16(r, voff, soff);

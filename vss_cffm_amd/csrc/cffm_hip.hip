@@ -708,16 +708,19 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     return 0;
 }
 
-// Workgroups of the attention backward: two kernels, every workgroup persistent, one per CU on 256 CUs = 32 per head: the query-owner
-// kernel (nq groups per head, per_group windows each), then the key-owner kernel (nk workgroups per head share the units round-robin).
+// Workgroups of the attention backward: two kernels, every workgroup persistent: the query-owner kernel (12 waves, one workgroup per
+// CU = 32 groups per head, per_group windows each), then the key-owner kernel (4 waves, four per CU = 128 per head sharing the units
+// round-robin).
 static void attn_bwd_split(const cffm_geom* g, int* nq, int* per_group, int* nk) {
-    const int total = g->B * g->nW, units = (g->nW + 2 * ((g->nW + 15) / 16)) * g->B;
+    // units of the geometry (geometry.ko_unit_count): one per window, 16-cell tiles of the two stride-1 pooled grids, 4 x 4 blocks of the stride-2 grid
+    const int total = g->B * g->nW, units = (g->nW + 2 * ((g->nW + 15) / 16) + ((2 * g->gy + 3) / 4) * ((2 * g->gx + 3) / 4)) * g->B;
     int q = total < 32 ? total : 32;
     *per_group = (total + q - 1) / q;
     *nq = (total + *per_group - 1) / *per_group;
-    *nk = units < 32 ? units : 32;
+    *nk = units < 128 ? units : 128;       // key-owner workgroups per head: 4 waves each, four per CU
 #ifdef CFFM_EXPERIMENTS   // timing of one kernel alone (results incomplete): CFFM_BWD_ONLY=q | k
-    { const char* e = getenv("CFFM_BWD_ONLY"); if (e && e[0] == 'q') *nk = 0; if (e && e[0] == 'k') *nq = 0; }
+    { const char* e = getenv("CFFM_BWD_ONLY"); if (e && e[0] == 'q') *nk = 0; if (e && e[0] == 'k') *nq = 0;
+      const char* s = getenv("CFFM_BWD_NK"); if (s && atoi(s) > 0 && *nk) *nk = atoi(s); }
 #endif
 }
 
