@@ -94,10 +94,10 @@ def roofline_kernels(stages, b, nw, hw):
         'gemm_dw_group': ('mfma', 2.0 * (nr * 768 * 256 + np_ * (2 * 1024 * 256 + 256 * 256))),
         # round 3: proj + residual + norm2 + fc1 + GELU + fc2 + residual in one row-panel launch, and the input-gradient chain back
         'mlp_fwd_fused': ('mfma', 2.0 * np_ * (256 * 256 + 2 * 256 * 1024)), 'mlp_bwd_fused': ('mfma', 2.0 * np_ * (256 * 256 + 2 * 256 * 1024)),
-        # attention backward (round 4: query-owner + key-owner roles in one launch): ALGORITHMIC products = S and dP once, dQ, dK, dV =
-        # 5 of 49 x 289 x 32 per (window, head); the second S / dP computation of the key owners is not counted as work
+        # attention backward: dS/dP recompute + dQ (query owners: 3 products), dK + dV + the S / dP recompute (key owners: 4)
+        # attention backward, fused (round 2): S and dP recomputed once, dQ, dK, dV = 5 products of 49 x 289 x 32 per (window, head)
         'attn_bwd_fused': ('mfma16', 5 * 2.0 * b * nw * 8 * 49 * 289 * 32),
-        'attn_bwd_prep': ('hbm', 4.0 * 2 * np_ * 256 + 2.0 * np_ * 256),
+        'attn_dkv_gather': ('hbm', 4.0 * (2 * nr * 512)),
         'ln_pool_fwd': ('hbm', 4.0 * (b * 4 * hw * 256 + nr * 256)), 'ln_pool_bwd': ('hbm', 4.0 * (2 * b * 4 * hw * 256 + nr * 256)),
         'residual_ln': ('hbm', 4.0 * 4 * np_ * 256), 'ln_bwd': ('hbm', 4.0 * 4 * np_ * 256),
         'transpose': ('hbm', None),
@@ -117,9 +117,9 @@ def roofline_kernels(stages, b, nw, hw):
             out[name] = {'bound': 'mfma', 'flops': int(work), 'avg_us': us, 'achieved_tflops': round(ach, 1), 'peak_tflops': round(peak, 1),
                          'frac': round(ach / peak, 4)}
         out[name]['ms_per_step'] = st['ms_per_step']
-        if name == 'attn_bwd_fused':   # also HBM-side: reads f16 q/k/v + f16 dO, writes dq|dk|dv (fp32, every row once) + bias-gradient tiles
-            rd = b * (nr // b * 768 * 2 + hw * 256 * 2)
-            wr = nr * 768 * 4 + 54 * 8 * 64 * 304 * 4
+        if name == 'attn_bwd_fused':   # also HBM-side: reads f16 q/k/v + O + dO, writes dQ + f16 dK/dV partial rows + bias-gradient tiles
+            rd = b * (nr // b * 768 * 2 + 2 * hw * 256 * 4)
+            wr = b * (hw * 256 * 4) + b * nw * 304 * 512 * 2 + 54 * 8 * 64 * 304 * 4
             out[name].update({'hbm_bytes': int(rd + wr), 'hbm_write_bytes': int(wr), 'hbm_frac': round((rd + wr) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
     out['note'] = ('HIP-event intervals of the separate instrumented pass, every kernel on one stream (each includes ~2-3 us of event-record cost); GEMM peak = 2500/3 TF '
                    '(three bf16 MFMA products per fp32 product), attention backward against the f16 MFMA peak, row kernels against 8 TB/s')

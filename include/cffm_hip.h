@@ -96,12 +96,11 @@ int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
                      float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs,
                      float* dgamma, float* dbeta, float* dM, float* const dpool_b[4], void* stream);
 /* the dense additive bias [8 heads][64 queries][304 keys] (cffm_transformer.py:536-587 gathers it from six tables) in two
- * layouts, each may be NULL: bias = query-major fp32 [8,64,304] (checks); biasH = what cffm_attn_fwd / cffm_attn_bwd read, ONE
- * buffer of 163840 + 155648 halfs holding
- *   f16 B-operand fragments [8 heads][4 waves][10 key-tile pairs][64 lanes][8], entry (h, wave, p, lane = 16 g + j, e) =
- *   bias(h, query 16 wave + j, key 16 (2 p + (g >> 1)) + 8 (g & 1) + e) (keys 304..319 = 0) -- the kernels add the bias on the
- *   matrix pipe (S^T tile t = K Q^T + Sel_(t & 1) * B) from one contiguous 1 KiB load per (wave, tile pair) -- followed by
- *   the same values key-major, biasKT [8 heads][304 key slots][64 queries] f16, which the key-owner role of cffm_attn_bwd reads. */
+ * layouts, each may be NULL: bias = query-major fp32 [8,64,304] (checks); biasH = what cffm_attn_fwd / cffm_attn_bwd read: f16
+ * B-operand fragments [8 heads][4 waves][10 key-tile pairs][64 lanes][8], entry (h, wave, p, lane = 16 g + j, e) = bias(h, query
+ * 16 wave + j, key 16 (2 p + (g >> 1)) + 8 (g & 1) + e), keys 304..319 = 0 -- the kernels add the bias on the matrix pipe
+ * (S^T tile t = K Q^T + Sel_(t & 1) * B) from one contiguous 1 KiB load per (wave, tile pair).  (8*4*10*512 halfs = 320 KB; ABI 6:
+ * tile pairs, ABI <= 5 kept one tile per fragment.) */
 int cffm_bias_assemble(const float* own, const float* ring, const float* const pool[4], float* bias, void* biasH, void* stream);
 int cffm_bias_scatter(const float* dbiasT, float* down, float* dring, float* const dpool[4], void* stream);
 /* qkv16 [B*RC,768] f16 = zall w^T + b with the q third times 32^-0.5 (cffm_linear_qkv_fwd) */
@@ -110,18 +109,13 @@ int cffm_linear_qkv_fwd(const float* zall, const float* w /*[768,256]*/, const f
 int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src /*[nW,304]*/, const int* q_dst /*[nW,49]*/,
                   const void* biasH /* f16 fragments, see cffm_bias_assemble */, float* ao /*[B*HW,256]*/, float* lse /*[B*nW*8,64]*/,
                   void* stream);
-/* Backward of the attention (autograd of cffm_transformer.py:364-606).  ABI 6: no partial key rows and no gather
- * pass any more.  One launch with two roles: query-owner workgroups (dq, the bias gradient) and key-owner workgroups that own up to
- * 64 key rows each and walk the windows that read them (dk, dv written once, in place).
- * ko_unit (int32) / ko_slot (int16, passed as const int*): the key-owner tables of the geometry (vss_cffm_amd/geometry.py
- * ko_tables: units, their key rows, the reader windows of each unit as per-wave pass lists, and per pass the key slot under which
- * the reader sees every key); cffm_bias_assemble's biasH buffer must carry the key-major table behind the fragments (see there);
- * bwd_ws: scratch of cffm_attn_bwd_ws_floats(g) floats (dO as f16 rows per (window, head), D = rowsum(dO * O), scales). */
-long cffm_attn_bwd_ws_floats(const cffm_geom* g);
+/* inv_ptr [RC+1] / inv_idx: CSR inverse of key_src (token row -> the window*304+slot pairs reading it);
+ * dkv_part: scratch of B*nW*(304*256 + 8) floats: the per-window dK/dV rows the gather pass sums, kept as f16 [B*nW*304][512]
+ * in units of a per-(window, head) power-of-two scale, followed by those scales */
 int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst,
-                  const int* ko_unit, const int* ko_slot, const void* biasH, const float* ao,
+                  const int* inv_ptr, const int* inv_idx, const void* biasH, const float* ao,
                   const float* dao, const float* lse, float* dqkv /*[B*RC,768] fp32: d(zall w^T), overwritten*/,
-                  float* dbiasT /*[8,304,64], overwritten*/, float* bwd_ws, void* stream);
+                  float* dbiasT /*[8,304,64], overwritten*/, float* dkv_part, void* stream);
 /* y[M,N] = x[M,K] w[N,K]^T ;  dx[M,K] = dy[M,N] w[N,K] ;  dw[N,K] = dy[M,N]^T x[M,K]   (row-major, no bias) */
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream);
 /* y[M,N] = x[M,K] w[N,K]^T + b[N]   (a 1x1 convolution on channels-last token rows: the head's classifiers, cffm_head.py:121,147) */
@@ -237,7 +231,7 @@ int cffm_block_forward(const cffm_geom* g, const cffm_block_params* p, const flo
                        float* scratch, void* stream);
 int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                         const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
-                        const int* q_dst, const int* ko_unit, const int* ko_slot, const float* ws,
+                        const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws,
                         const float* dout /*[B*HW,256]*/,
                         float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs,
                         float* scratch, void* stream);
@@ -250,14 +244,14 @@ int cffm_layer_forward(const cffm_geom* g, int depth, const cffm_block_params* p
 int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                         const float* dy_tgt_nchw, long dy_bs /* elements between clips: 256*H0*W0 when dy is dense, 4x that
                         when it is the last-frame slice of a [B,4,256,H0,W0] gradient */, float* dx_nchw, const int* key_src, const int* q_dst,
-                        const int* ko_unit, const int* ko_slot, const float* saved, float* scratch, void* stream);
+                        const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream);
 /* The same in pieces: blocks first_block, first_block - 1, ..., last_block (depth - 1 >= first >= last >= 0), issued in order on
  * one stream; the piece with first == depth - 1 starts from dy, the piece with last == 0 writes dx.  Lets a data-parallel
  * trainer start the gradient all-reduce of block i while block i - 1 is still running (mmseg/apis/train.py:57-65). */
 int cffm_layer_backward_range(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                         const float* dy_tgt_nchw, long dy_bs /* elements between clips: 256*H0*W0 when dy is dense, 4x that
                         when it is the last-frame slice of a [B,4,256,H0,W0] gradient */, float* dx_nchw, const int* key_src, const int* q_dst,
-                        const int* ko_unit, const int* ko_slot, const float* saved, float* scratch, int first_block, int last_block, void* stream);
+                        const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, int first_block, int last_block, void* stream);
 /* The same pair on the reference's whole output (BasicLayer3d3.forward returns [B,4,C,H,W] whose frames 0..2 ARE the input frames,
  * cffm_transformer.py:826,917-927): forward writes y_full = [x[:, :3] | new target frame] (the copy runs on the library's side
  * stream under the blocks), backward takes the upstream gradient of that whole tensor and adds its pass-through frames into dx in
@@ -266,8 +260,8 @@ int cffm_layer_forward_full(const cffm_geom* g, int depth, const cffm_block_para
                             float* y_full_nchw, const int* key_src, const int* q_dst, float* saved, float* scratch,
                             void* stream);
 int cffm_layer_backward_full(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
-                             const float* dy_full_nchw, float* dx_nchw, const int* key_src, const int* q_dst, const int* ko_unit,
-                             const int* ko_slot, const float* saved, float* scratch, int first_block, int last_block, void* stream);
+                             const float* dy_full_nchw, float* dx_nchw, const int* key_src, const int* q_dst, const int* inv_ptr,
+                             const int* inv_idx, const float* saved, float* scratch, int first_block, int last_block, void* stream);
 
 /* The layer on token rows (channels-last) on both sides -- what the heads call (their neighbours work on rows too):
  * x_rows [B,4,HW,256] -> y_rows [B,HW,256]; no layout transposes, `x_rows` itself is the stack the blocks read and must be
@@ -276,7 +270,7 @@ int cffm_layer_forward_rows(const cffm_geom* g, int depth, const cffm_block_para
                             const int* key_src, const int* q_dst, float* saved, float* scratch, void* stream);
 int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                              const float* x_rows, const float* dy_rows, float* dx_rows, const int* key_src, const int* q_dst,
-                             const int* ko_unit, const int* ko_slot, const float* saved, float* scratch, void* stream);
+                             const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream);
 
 /* ---- `linear_fuse`'s BatchNorm + ReLU and the 1/4 -> 1/8 resize that builds the clip stack (cffm_head.py:119, :131-135), on token
  * rows [pixels,256].  With even H, W the bilinear 1/2 resize (align_corners=False) is exactly a 2x2 average.

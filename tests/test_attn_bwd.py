@@ -1,6 +1,6 @@
-"""The attention backward on its own (cffm_attn_bwd: prep pass + the two-role kernel of csrc/cfm_attn_bwd_kernels.h) against torch
-autograd of the same windowed cross-attention on the same f16 q|k|v rows: dq of every query, dk / dv of every token and pooled
-row (each written once by its key-owner workgroup), the zeroed q third of the pooled rows and the dense bias gradient.
+"""The attention backward on its own (cffm_attn_bwd: the fused kernel, the bias-gradient tile sum and the dK / dV gather of
+csrc/cfm_attn_kernels.h) against torch autograd of the same windowed cross-attention on the same f16 q|k|v rows: dq of every query,
+dk / dv of every token and pooled row, the zeroed q third of the pooled rows and the dense bias gradient.
 Reference semantics: cffm_transformer.py:364-606; the key assembly comes from geometry.tables, which
 tests/test_geometry.py pins against the oracle's roll / unfold maps."""
 import ctypes as C
@@ -18,20 +18,19 @@ def P(t):
 
 
 def bias_buffer(bias):
-    """[8, 64, 304] fp32 -> the f16 buffer cffm_bias_assemble builds: MFMA fragments, then the key-major table"""
+    """[8, 64, 304] fp32 -> the f16 MFMA fragments cffm_bias_assemble builds"""
     bh = bias.half()
     b320 = torch.zeros(8, 64, 320, dtype=torch.float16)
     b320[:, :, :304] = bh
     # (h, wave, j, pair, g2 (tile of the pair, 8-key half), e) -> (h, wave, pair, g2, j, e): lane 16 g2 + j of pair p
-    frag = b320.view(8, 4, 16, 10, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
-    return torch.cat([frag.reshape(-1), bh.transpose(1, 2).contiguous().reshape(-1)])
+    return b320.view(8, 4, 16, 10, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)
 
 
 def run_attn_bwd_stage(lib, device, b, h0, w0, grad_scale=1e-3, zero_window=False, raw=False):
     torch.manual_seed(b * 1000 + h0 * 31 + w0)
     g = ops.make_geom(lib, b, h0, w0)
     nw, rc, hw = g.nW, g.RC, g.HW
-    ks_t, qd_t, ko_t, kslot_t = ops.device_tables(h0, w0, device)
+    ks_t, qd_t, ip_t, ii_t = ops.device_tables(h0, w0, device)
     ks_c, qd_c = ks_t.cpu(), qd_t.cpu()
     qkv = (torch.randn(b * rc, 768) * 0.7).half()
     bias = torch.randn(8, 64, 304) * 0.5
@@ -67,10 +66,10 @@ def run_attn_bwd_stage(lib, device, b, h0, w0, grad_scale=1e-3, zero_window=Fals
     dev = lambda t: t.contiguous().to(device)
     dqkv = torch.full((b * rc, 768), float('nan'), device=device)
     dbias_t = torch.zeros(8, 304, 64, device=device)
-    ws = torch.zeros(lib.cffm_attn_bwd_ws_floats(C.byref(g)), device=device)
+    ws = torch.zeros(b * nw * (304 * 256 + 8), device=device)      # f16 partial rows + their scales
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
     args = [dev(t) for t in (qkv, bias_buffer(bias), ao.view(b * hw, 256), dao, lse)]
-    _lib.check(lib.cffm_attn_bwd(C.byref(g), P(args[0]), P(ks_t), P(qd_t), P(ko_t), P(kslot_t), P(args[1]), P(args[2]), P(args[3]),
+    _lib.check(lib.cffm_attn_bwd(C.byref(g), P(args[0]), P(ks_t), P(qd_t), P(ip_t), P(ii_t), P(args[1]), P(args[2]), P(args[3]),
                                  P(args[4]), P(dqkv), P(dbias_t), P(ws), stream), lib)
     if raw:
         return dqkv, dbias_t
@@ -91,7 +90,7 @@ def run_attn_bwd_stage(lib, device, b, h0, w0, grad_scale=1e-3, zero_window=Fals
     return errs
 
 
-STAGE_TOL = 6e-4    # f16 operands (q, k, v exact here; dO, P, dS hi+lo rounded), measured 2-4.5e-4
+STAGE_TOL = 8e-4    # f16 operands (q, k, v exact here; dO, P, dS rounded)
 RANGE_TOL = 1.5e-3  # the same per row range, relative to the range's own maximum (a range can hold only small gradients)
 
 
@@ -103,7 +102,7 @@ def check(errs):
 
 # (7, 7): one window that is its own cyclic neighbour eight times over (up to 4 readings of a key by one window); (5, 20): one row of
 # windows; (8, 8): 2 x 2 windows (every neighbour direction wraps); (14, 21): no padding, non-square; (13, 30): ragged
-@pytest.mark.parametrize('shape', [(1, 7, 7), (1, 5, 20), (1, 8, 8), (2, 14, 21), (2, 13, 30), (1, 22, 23)])
+@pytest.mark.parametrize('shape', [(1, 7, 7), (1, 5, 20), (1, 8, 8), (2, 14, 21), (2, 13, 30), (1, 22, 23)])   # noqa: E501
 def test_attn_bwd_stage_emulated(shape):
     errs = run_attn_bwd_stage(emu.lib(), torch.device('cpu'), *shape)
     check(errs)

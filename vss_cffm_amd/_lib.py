@@ -58,7 +58,6 @@ SIGNATURES = {
     'cffm_bias_scatter': (ci, [vp, vp, vp, P4, vp]),
     'cffm_linear_qkv_fwd': (ci, [vp, vp, vp, vp, cl, vp]),
     'cffm_attn_fwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp]),
-    'cffm_attn_bwd_ws_floats': (cl, [GP]),
     'cffm_attn_bwd': (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'cffm_linear_fwd': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bias_fwd': (ci, [vp, vp, vp, vp, cl, ci, ci, vp]),

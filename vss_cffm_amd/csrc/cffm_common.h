@@ -14,7 +14,7 @@
 // "off" here, so libcffm_hip.so contains exactly the kernels bench.py runs.
 #ifndef CFFM_EXPERIMENTS
 #if defined(GEMM_ABLATE) || defined(FWD_ABLATE) || defined(BWD_ABLATE) || defined(LNPB_ABLATE) || defined(PNL_ABLATE) || defined(FWD_DMA) || \
-    defined(VFLAG_RD) || defined(FWD_TIMING) || defined(BWD_TIMING) || defined(UPCE_ABLATE) || defined(BWD_K_ABLATE) || defined(BWD_Q_ABLATE)
+    defined(VFLAG_RD) || defined(FWD_TIMING) || defined(BWD_TIMING) || defined(UPCE_ABLATE)
 #error "profiling switches need -DCFFM_EXPERIMENTS"
 #endif
 #endif
@@ -30,10 +30,9 @@
 #define CFFM_NQ_PAD 64
 #define CFFM_NCELL 15      // pooled cells per window: 1 (target) + 1 + 4 + 9
 #define CFFM_HID 1024
-// the dense position bias of a block in its two f16 layouts, one after the other (rowops_kernels.h bias_assemble_body):
-// biasH = MFMA B-operand fragments [8][4][10 tile pairs][64][8] (forward, query-owner backward), biasKT = key-major [8][304][64] (key-owner backward)
+// the dense position bias of a block as f16 MFMA B-operand fragments [8 heads][4 waves][10 key-tile pairs][64 lanes][8] (rowops_kernels.h
+// bias_assemble_body, cfm_attn_kernels.h bias_sel_frag)
 #define BIASH_HALFS (CFFM_HEADS * 4 * 10 * 512)
-#define BIASKT_HALFS (CFFM_HEADS * CFFM_NKEY_PAD * CFFM_NQ_PAD)
 #define CFFM_LN_EPS 1e-5f
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

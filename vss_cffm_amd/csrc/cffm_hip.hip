@@ -1,6 +1,6 @@
 // cffm_hip.hip -- C-ABI entry points of libcffm_hip.so (see include/cffm_hip.h) and the host-side
 // orchestration of one CFFM block / layer on a HIP stream.  gfx950 only.
-#include "cfm_attn_bwd_kernels.h"
+#include "cfm_attn_kernels.h"
 #include "clip_kernels.h"
 #include "rowops_kernels.h"
 #include "gtc_kernels.h"
@@ -48,12 +48,12 @@ enum { ST_TRANSPOSE, ST_POOLMAT, ST_LN_POOL_FWD, ST_LN_POOL_BWD, ST_BIAS_ASM, ST
        ST_GEMM, ST_COLSUM, ST_RES_LN, ST_LN_BWD, ST_GELU, ST_GELU_BWD, ST_RES_OUT, ST_GTC_FWD, ST_GTC_BWD, ST_LN, ST_ADAMW, ST_NULL_PAIR,
        // per-kernel-family stages of the block (bench.py's `roofline_kernels`); the ST_GEMM / ST_ATTN_BWD totals above stay
        ST_G_QKV_FWD, ST_G_PROJ_FWD, ST_G_FC1_FWD, ST_G_FC2_FWD, ST_G_FC2_DX, ST_G_FC1_DX, ST_G_PROJ_DX, ST_G_QKV_DX, ST_G_DW,
-       ST_ATTN_BWD_Q, ST_ATTN_BWD_KV, ST_ATTN_BWD_PREP, ST_ATTN_BWD_K, ST_MLP_FWD, ST_MLP_BWD, ST_COUNT };
+       ST_ATTN_BWD_Q, ST_ATTN_BWD_KV, ST_DKV_GATHER, ST_MLP_FWD, ST_MLP_BWD, ST_COUNT };
 static const char* const k_stage_names[ST_COUNT] = {"transpose", "pool_matrix", "ln_pool_fwd", "ln_pool_bwd", "bias_assemble",
     "bias_scatter", "cfm_attn_fwd", "cfm_attn_bwd", "linear_gemm", "colsum", "residual_ln", "ln_bwd", "bias_gelu", "gelu_bwd",
     "residual_out", "gtc_attn_fwd", "gtc_attn_bwd", "layernorm", "adamw", "event_pair_null",
     "gemm_qkv_fwd", "gemm_proj_fwd", "gemm_fc1_fwd", "gemm_fc2_fwd", "gemm_fc2_dx_gelu", "gemm_fc1_dx", "gemm_proj_dx", "gemm_qkv_dx",
-    "gemm_dw_group", "attn_bwd_q", "attn_bwd_bias_sum", "attn_bwd_prep", "attn_bwd_k", "mlp_fwd_fused", "mlp_bwd_fused"};
+    "gemm_dw_group", "attn_bwd_fused", "attn_bwd_bias_sum", "attn_dkv_gather", "mlp_fwd_fused", "mlp_bwd_fused"};
 #ifndef CFFM_EMU
 #include <vector>
 struct ProfRec { int stage; hipEvent_t e0, e1; };
@@ -226,8 +226,8 @@ int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* o) {
     o->M = p; p += up(CFFM_NCELL * CFFM_WA);
     o->zall = p; p += up(B * RC * CFFM_C);
     o->qkv = p; p += up(B * RC * 768 / 2);   // f16 q|k|v
-    o->bias = p; p += up((long)BIASH_HALFS / 2);                  // biasH: f16 B-operand fragments of the position bias
-    o->biasT = p; p += up((long)BIASKT_HALFS / 2);                // biasKT: the same values key-major (key-owner role of the attention backward); = bias + BIASH_HALFS / 2
+    o->bias = p; p += up((long)BIASH_HALFS / 2);                  // biasH: f16 B-operand fragments of the position bias (tile pairs)
+    o->biasT = o->bias;                                           // (kept in the struct for ABI stability: no key-major table any more)
     o->lse = p; p += up(B * nW * CFFM_HEADS * CFFM_NQ_PAD);
     o->ao = p; p += up(B * HW * CFFM_C);
     o->x1 = p; p += up(B * HW * CFFM_C);
@@ -249,7 +249,6 @@ long cffm_layer_saved_floats(const cffm_geom* g, int depth) {
     return up((long)g->B * 4 * g->HW * CFFM_C) + depth * w.total;
 }
 
-static long attn_bwd_ws_floats(const cffm_geom* g);
 // scratch carve (floats): fwd uses [0, BHW*C); bwd uses all of it
 struct Scratch { long a, a2, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, dkvp, alt, total; };
 static Scratch scratch_layout(const cffm_geom* g) {
@@ -267,7 +266,7 @@ static Scratch scratch_layout(const cffm_geom* g) {
     s.dM = p; p += up(CFFM_NCELL * CFFM_WA);
     s.dbiasT = p; p += up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     s.dxs = p; p += up(B * 4 * HW * CFFM_C);
-    s.dkvp = p; p += attn_bwd_ws_floats(g);   // the attention backward's prep outputs: f16 dO rows per (window, head), D, scales
+    s.dkvp = p; p += up(B * g->nW * ((long)CFFM_NKEY_PAD * 256 + CFFM_HEADS));   // f16 partial rows + their (window, head) scales
     // second copies of what a block's side work (weight-gradient GEMMs, column sums, bias-tile sum) still reads after the chain has
     // moved on to the next block: blocks alternate between the two sets (block_backward_impl `par`), so the next block's chain never
     // waits for the side streams.  Offsets relative to `alt`: b | dact | dqkv | dbiasT | dM
@@ -708,71 +707,37 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     return 0;
 }
 
-// Workgroups of the attention backward: two kernels, every workgroup persistent: the query-owner kernel (12 waves, one workgroup per
-// CU = 32 groups per head, per_group windows each), then the key-owner kernel (4 waves, four per CU = 128 per head sharing the units
-// round-robin).
-static void attn_bwd_split(const cffm_geom* g, int* nq, int* per_group, int* nk) {
-    // units of the geometry (geometry.ko_unit_count): one per window, 16-cell tiles of the two stride-1 pooled grids, 4 x 4 blocks of the stride-2 grid
-    const int total = g->B * g->nW, units = (g->nW + 2 * ((g->nW + 15) / 16) + ((2 * g->gy + 3) / 4) * ((2 * g->gx + 3) / 4)) * g->B;
-    int q = total < 32 ? total : 32;
-    *per_group = (total + q - 1) / q;
-    *nq = (total + *per_group - 1) / *per_group;
-    *nk = units < 128 ? units : 128;       // key-owner workgroups per head: 4 waves each, four per CU
-#ifdef CFFM_EXPERIMENTS   // timing of one kernel alone (results incomplete): CFFM_BWD_ONLY=q | k
-    { const char* e = getenv("CFFM_BWD_ONLY"); if (e && e[0] == 'q') *nk = 0; if (e && e[0] == 'k') *nq = 0;
-      const char* s = getenv("CFFM_BWD_NK"); if (s && atoi(s) > 0 && *nk) *nk = atoi(s); }
-#endif
+// window groups of the fused backward: 8 heads x groups <= 2 workgroups per CU on 256 CUs, every group the same length
+static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
+    const int total = g->B * g->nW;
+    static int want = -1;   // tuning aid: CFFM_BWD_GROUPS
+    if (want < 0) { const char* e = getenv("CFFM_BWD_GROUPS"); want = e ? atoi(e) : 64; if (want < 1) want = 64; }
+    int ng = total < want ? total : want;
+    *per_group = (total + ng - 1) / ng;
+    return (total + *per_group - 1) / *per_group;
 }
 
-// scratch of the attention backward (floats): dO as f16 rows per (window, head) | D | scales (k_attn_bwd_prep)
-static long attn_bwd_ws_floats(const cffm_geom* g) {
-    const long n = (long)g->B * g->nW * CFFM_HEADS;
-    return up(n * 64 * CFFM_HD / 2) + up(n * 64) + up(n);
-}
-long cffm_attn_bwd_ws_floats(const cffm_geom* g) { return g ? attn_bwd_ws_floats(g) : -1; }
-
-// the pieces of the attention backward (the block backward puts the bias-gradient sum on its side stream): the prep pass and the
-// two-role kernel on the chain
+// the three pieces of the attention backward (the block backward puts the bias-gradient sum on its side stream)
 static int attn_bwd_fused(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst, const h16* bias, const float* ao,
-                          const float* dao, const float* lse, const int* ko_unit, const int* ko_slot, float* dqkv, float* bws,
-                          float** dbp_out, int* ng_out, int par, void* stream) {
-    int per, ng, nk;
-    attn_bwd_split(g, &ng, &per, &nk);
-    REQUIRE(g->B <= KO_MAX_CLIPS, "attn_bwd: more than 64 clips per call");
+                          const float* dao, const float* lse, float* dqkv, float* dkv_part, float** dbp_out, int* ng_out, int par, void* stream) {
+    PROF2(ST_ATTN_BWD_Q);
+    int per;
+    const int ng = attn_bwd_groups(g, &per);
     const long nb = (long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD;   // one bias-gradient tile set per window group
-    float* dbp = lib_scratch3((size_t)2 * (ng > 0 ? ng : 1) * nb);      // two sets: see scratch_layout (alt)
+    float* dbp = lib_scratch3((size_t)2 * ng * nb);      // two sets: see scratch_layout (alt)
     REQUIRE(dbp, "attn_bwd: scratch allocation failed");
     dbp += (size_t)(par ? 1 : 0) * ng * nb;
-    const long n = (long)g->B * g->nW * CFFM_HEADS;
-    h16* doh = (h16*)bws;
-    float* dsc = bws + up(n * 64 * CFFM_HD / 2);
-    float* scl = dsc + up(n * 64);
-    {
-        PROF2(ST_ATTN_BWD_PREP);
-        CFFM_LAUNCH(k_attn_bwd_prep, (g->B * g->nW * 4), (256), 0, (hipStream_t)stream, to_geo(g), q_dst, ao, dao, doh, dsc, scl);
-        CHECK_LAUNCH("attn_bwd prep");
-    }
 #ifndef CFFM_EMU
     static bool granted = false;
     if (!granted) {
-        REQUIRE(hipFuncSetAttribute((const void*)k_cfm_attn_bwd_q, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_BWD_Q_LDS) == hipSuccess &&
-                hipFuncSetAttribute((const void*)k_cfm_attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_BWD_K_LDS) == hipSuccess,
+        REQUIRE(hipFuncSetAttribute((const void*)k_cfm_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_BWD_LDS) == hipSuccess,
                 "attn_bwd: LDS grant failed");
         granted = true;
     }
 #endif
-    if (ng > 0) {
-        PROF2(ST_ATTN_BWD_Q);
-        CFFM_LAUNCH(k_cfm_attn_bwd_q, (CFFM_HEADS * ng), (ATT_BWD_Q_THREADS), ATT_BWD_Q_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16, key_src,
-                    bias, (const h16*)doh, (const float*)dsc, (const float*)scl, lse, dqkv, dbp, per);
-        CHECK_LAUNCH("attn_bwd q");
-    }
-    if (nk > 0) {
-        PROF2(ST_ATTN_BWD_K);
-        CFFM_LAUNCH(k_cfm_attn_bwd_k, (CFFM_HEADS * nk), (ATT_BWD_K_THREADS), ATT_BWD_K_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16,
-                    bias + BIASH_HALFS, (const h16*)doh, (const float*)dsc, (const float*)scl, lse, ko_unit, (const int16_t*)ko_slot, dqkv, nk);
-        CHECK_LAUNCH("attn_bwd k");
-    }
+    CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (256), ATT_BWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias,
+                ao, dao, lse, dqkv, dbp, dkv_part, per);
+    CHECK_LAUNCH("attn_bwd");
     *dbp_out = dbp; *ng_out = ng;
     return 0;
 }
@@ -783,16 +748,23 @@ static int attn_bwd_bias_sum(const float* dbp, int ng, float* dbiasT, void* stre
     CHECK_LAUNCH("attn_bwd bias sum");
     return 0;
 }
+static int attn_bwd_gather(const cffm_geom* g, const int* inv_ptr, const int* inv_idx, const float* dkv_part, float* dqkv, void* stream) {
+    PROF2(ST_DKV_GATHER);
+    CFFM_LAUNCH(k_dkv_gather, ((g->RC + 3) / 4, g->B), (256), 0, (hipStream_t)stream, to_geo(g), inv_ptr, inv_idx, dkv_part, dqkv);
+    CHECK_LAUNCH("attn_bwd gather");
+    return 0;
+}
 int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst,
-                  const int* ko_unit, const int* ko_slot, const void* biasH, const float* ao,
-                  const float* dao, const float* lse, float* dqkv, float* dbiasT, float* bwd_ws, void* stream) {
+                  const int* inv_ptr, const int* inv_idx, const void* biasH, const float* ao,
+                  const float* dao, const float* lse, float* dqkv, float* dbiasT, float* dkv_part, void* stream) {
     PROF(ST_ATTN_BWD);
     const h16* bias = (const h16*)biasH;
-    REQUIRE(g && qkv16 && bias && dao && dqkv && dbiasT && bwd_ws && ko_unit && ko_slot, "attn_bwd: null");
+    REQUIRE(g && qkv16 && bias && dao && dqkv && dbiasT && dkv_part && inv_ptr && inv_idx, "attn_bwd: null");
     float* dbp;
     int ng;
-    TRY(attn_bwd_fused(g, qkv16, key_src, q_dst, bias, ao, dao, lse, ko_unit, ko_slot, dqkv, bwd_ws, &dbp, &ng, 0, stream));
+    TRY(attn_bwd_fused(g, qkv16, key_src, q_dst, bias, ao, dao, lse, dqkv, dkv_part, &dbp, &ng, 0, stream));
     TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, stream));
+    TRY(attn_bwd_gather(g, inv_ptr, inv_idx, dkv_part, dqkv, stream));
     return 0;
 }
 
@@ -1297,7 +1269,7 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
 
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                                const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
-                               const int* q_dst, const int* ko_unit, const int* ko_slot, const float* ws, const float* dout,
+                               const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
                                float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, void* stream);
 // The parameter-gradient tail of a block backward (record reductions, pooling-matrix backward), LAUNCHED LATE: its fork point is the end
 // of ln_pool_bwd (event fork[3]), but the launches happen only after the chain's next kernel has been launched (tail_flush), so that
@@ -1353,9 +1325,9 @@ static void tail_reset() {      // entry of a layer backward: nothing of a previ
 }
 int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                         const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
-                        const int* q_dst, const int* ko_unit, const int* ko_slot, const float* ws, const float* dout,
+                        const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
                         float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, void* stream) {
-    return block_backward_impl(g, p, gr, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, ko_unit, ko_slot, ws, dout, dx_ref, dref_bs, accum_ref,
+    return block_backward_impl(g, p, gr, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_ref, dref_bs, accum_ref,
                                dx_tgt, dtgt_bs, scratch, 0, 0, stream);
 }
 // `defer` (layer backward, round 3): the call returns with this block's parameter-gradient tail (partial-slab sums, record reductions,
@@ -1365,7 +1337,7 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
 // block between ln_pool_bwd and the next block's first kernel, behind four small side kernels.)
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                                const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
-                               const int* q_dst, const int* ko_unit, const int* ko_slot, const float* ws, const float* dout,
+                               const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
                                float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, void* stream) {
     REQUIRE(g && p && gr && ws && dout && scratch, "block_backward: null");
     {
@@ -1504,16 +1476,18 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             g_side.bias_pending[par] = false;
         }
 #endif
-        TRY(attn_bwd_fused(g, ws + L.qkv, key_src, q_dst, (const h16*)(ws + L.bias), ws + L.ao, dao, ws + L.lse, ko_unit, ko_slot, dqkv, scratch + S.dkvp, &dbp, &ng, par, stream));
+        TRY(attn_bwd_fused(g, ws + L.qkv, key_src, q_dst, (const h16*)(ws + L.bias), ws + L.ao, dao, ws + L.lse, dqkv, scratch + S.dkvp, &dbp, &ng, par, stream));
         // (side work first here, although that makes the chain change hardware queues under graph replay -- see side_fork_mark: with the
         //  chain launched first the executor parked these side kernels behind the NEXT block's chain and the step's tail grew:
         //  0.864 vs 0.849 ms per step, means of three alternating runs)
         if (sp && (fork_order() & 4)) {
             // no branch of its own: the bias-gradient tile sum and scatter follow the weight-gradient group on ITS stream (below), so
             // the attention backward has ONE dependant and the chain stays on its hardware queue
+            TRY(attn_bwd_gather(g, inv_ptr, inv_idx, scratch + S.dkvp, dqkv, stream));
             bias_late = 1; late_dbp = dbp; late_ng = ng;
         } else if (sp && (fork_order() & 1)) {
             side_fork_mark(st, 1);
+            TRY(attn_bwd_gather(g, inv_ptr, inv_idx, scratch + S.dkvp, dqkv, stream));
             s1 = side_fork_take(st, 1);
             TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, (void*)s1));
             TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
@@ -1521,6 +1495,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         s1 = sp ? side_fork(st, 1) : st;
         TRY(attn_bwd_bias_sum(dbp, ng, dbiasT, (void*)s1));
         TRY(cffm_bias_scatter(dbiasT, gr->rpb_own, gr->rpb_ring, gr->rpb_pool, (void*)s1));
+        TRY(attn_bwd_gather(g, inv_ptr, inv_idx, scratch + S.dkvp, dqkv, stream));
         }
     }
     // q|k|v = zall Wqkv^T + b (bias folded into the f16 epilogue; its gradient is the column sum of dqkv)
@@ -2060,7 +2035,7 @@ int cffm_layer_forward_rows(const cffm_geom* g, int depth, const cffm_block_para
 // dy_rows [B,HW,256] -> dx_rows [B,4,HW,256] and every parameter gradient; x_rows as given to cffm_layer_forward_rows
 int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                              const float* x_rows, const float* dy_rows, float* dx_rows, const int* key_src, const int* q_dst,
-                             const int* ko_unit, const int* ko_slot, const float* saved, float* scratch, void* stream) {
+                             const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream) {
     REQUIRE(g && params && grads && x_rows && dy_rows && dx_rows && saved && scratch && depth >= 1, "layer_backward_rows: bad arguments");
     cffm_block_ws L;
     cffm_block_ws_layout(g, &L);
@@ -2078,7 +2053,7 @@ int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_par
         const long dtgt_bs = (i == 0) ? 4 * img : img;
         // the last block reads the caller's gradient directly
         const float* dout = (i == depth - 1) ? dy_rows : scratch + (((depth - 1 - i) & 1) ? S.a2 : S.a);
-        TRY(block_backward_impl(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, ko_unit, ko_slot, ws, dout, dx_rows,
+        TRY(block_backward_impl(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_rows,
                                 4 * img, i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
     }
     TRY(tail_flush((hipStream_t)stream, tail_on_main()));
@@ -2161,7 +2136,7 @@ int cffm_layer_forward_full(const cffm_geom* g, int depth, const cffm_block_para
 // (vss_cffm_amd/distributed.py; the reference's DDP does the same with its buckets: mmseg/apis/train.py:57-65).
 static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                                const float* dy_tgt_nchw, long dy_bs, const float* dy_full, float* dx_nchw, const int* key_src,
-                               const int* q_dst, const int* ko_unit, const int* ko_slot, const float* saved, float* scratch,
+                               const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch,
                                int first_block, int last_block, void* stream) {
     REQUIRE(g && params && grads && dy_tgt_nchw && dx_nchw && saved && scratch && depth >= 1, "layer_backward: bad arguments");
     REQUIRE(first_block < depth && last_block >= 0 && first_block >= last_block, "layer_backward: bad block range %d..%d of %d", first_block,
@@ -2186,7 +2161,7 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
         float* dcur = scratch + (((depth - 1 - i) & 1) ? S.a2 : S.a);
         float* dtgt = (i == 0) ? dxs + 3 * img : scratch + (((depth - i) & 1) ? S.a2 : S.a);
         const long dtgt_bs = (i == 0) ? 4 * img : img;
-        TRY(block_backward_impl(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, ko_unit, ko_slot, ws, dcur, dxs, 4 * img,
+        TRY(block_backward_impl(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dcur, dxs, 4 * img,
                                 i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
     }
     // (dy_full: the upstream gradient of the whole [B,4,C,H,W] output -- its pass-through frames 0..2 join dx in the same pass)
@@ -2204,23 +2179,23 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
 }
 int cffm_layer_backward_range(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                               const float* dy_tgt_nchw, long dy_bs, float* dx_nchw, const int* key_src, const int* q_dst,
-                              const int* ko_unit, const int* ko_slot, const float* saved, float* scratch, int first_block,
+                              const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, int first_block,
                               int last_block, void* stream) {
-    return layer_backward_impl(g, depth, params, grads, dy_tgt_nchw, dy_bs, nullptr, dx_nchw, key_src, q_dst, ko_unit, ko_slot, saved,
+    return layer_backward_impl(g, depth, params, grads, dy_tgt_nchw, dy_bs, nullptr, dx_nchw, key_src, q_dst, inv_ptr, inv_idx, saved,
                                scratch, first_block, last_block, stream);
 }
 int cffm_layer_backward_full(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
-                             const float* dy_full_nchw, float* dx_nchw, const int* key_src, const int* q_dst, const int* ko_unit,
-                             const int* ko_slot, const float* saved, float* scratch, int first_block, int last_block, void* stream) {
+                             const float* dy_full_nchw, float* dx_nchw, const int* key_src, const int* q_dst, const int* inv_ptr,
+                             const int* inv_idx, const float* saved, float* scratch, int first_block, int last_block, void* stream) {
     REQUIRE(g && dy_full_nchw && dy_full_nchw != dx_nchw, "layer_backward_full: bad arguments");
     const long img = g->HW * CFFM_C;
-    return layer_backward_impl(g, depth, params, grads, dy_full_nchw + 3 * img, 4 * img, dy_full_nchw, dx_nchw, key_src, q_dst, ko_unit,
-                               ko_slot, saved, scratch, first_block, last_block, stream);
+    return layer_backward_impl(g, depth, params, grads, dy_full_nchw + 3 * img, 4 * img, dy_full_nchw, dx_nchw, key_src, q_dst, inv_ptr,
+                               inv_idx, saved, scratch, first_block, last_block, stream);
 }
 int cffm_layer_backward(const cffm_geom* g, int depth, const cffm_block_params* params, const cffm_block_grads* grads,
                         const float* dy_tgt_nchw, long dy_bs, float* dx_nchw, const int* key_src, const int* q_dst,
-                        const int* ko_unit, const int* ko_slot, const float* saved, float* scratch, void* stream) {
-    return cffm_layer_backward_range(g, depth, params, grads, dy_tgt_nchw, dy_bs, dx_nchw, key_src, q_dst, ko_unit, ko_slot, saved, scratch,
+                        const int* inv_ptr, const int* inv_idx, const float* saved, float* scratch, void* stream) {
+    return cffm_layer_backward_range(g, depth, params, grads, dy_tgt_nchw, dy_bs, dx_nchw, key_src, q_dst, inv_ptr, inv_idx, saved, scratch,
                                      depth - 1, 0, stream);
 }
 

@@ -50,10 +50,8 @@ __device__ __forceinline__ int bias_locate(int h, int q, int n, int& off) {
 //         (h, wave, p, lane = 16 g + j, e) = bias(h, query 16 wave + j, key 16 (2 p + (g >> 1)) + 8 (g & 1) + e).  One contiguous
 //         1 KiB load per (wave, tile pair); the kernels add it to S^T on the matrix pipe (S^T tile t = K Q^T + Sel_(t & 1) B,
 //         Sel_o = the 16 x 32 selection matrix that routes k-slot 16 o + i to key row i), so the position bias costs neither
-//         fp32 bytes nor VALU instructions.  f16 rounding of the bias moves the layer output by 3e-5 of its maximum (the oracle
+//         fp32 bytes nor VALU instructions (round 4: tile pairs; rounds 2-3 kept one tile per fragment, upper 32 lanes zero).  f16 rounding of the bias moves the layer output by 3e-5 of its maximum (the oracle
 //         with the tables rounded to f16), a fifth of what the f16 Q / K / P / V operands already contribute;
-//   biasKT [8][304 keys][64 queries] f16, behind biasH in the same buffer: the same f16 values key-major, for the key-owner role of the
-//         attention backward (cfm_attn_bwd_kernels.h), whose lanes each need 4 consecutive queries of one key slot (one 8-byte load);
 //   bias  [8][64][304] fp32, query-major (stage-level checks only; NULL inside the block).
 __device__ __forceinline__ long biash_index(int h, int q, int n) {      // n < 320: key tile 19 (keys 304..319) is the zero half of pair 9
     const int t = n >> 4;
@@ -73,7 +71,6 @@ __device__ __forceinline__ void bias_assemble_body(const BiasTables& t, float* _
     if (biasH) {
         biasH[biash_index(h, q, n)] = (h16)v;
         if (n >= CFFM_NKEY_PAD - 16) biasH[biash_index(h, q, n + 16)] = (h16)0.f;    // the unused second half of the last tile pair
-        biasH[BIASH_HALFS + ((long)h * CFFM_NKEY_PAD + n) * CFFM_NQ_PAD + q] = (h16)v;   // biasKT (key-owner role of the attention backward)
     }
 }
 __global__ void __launch_bounds__(256) k_bias_assemble(BiasTables t, float* __restrict__ bias, h16* __restrict__ biasH) {

@@ -81,7 +81,7 @@ def device_tables(h0, w0, device):
     key = (h0, w0, str(device))
     if key not in _table_cache:
         ks, qd = geometry.tables(h0, w0)
-        ip, ii = geometry.ko_tables(h0, w0)
+        ip, ii = geometry.inverse_tables(h0, w0)
         _table_cache[key] = tuple(torch.from_numpy(np.array(a)).to(device) for a in (ks, qd, ip, ii))
     return _table_cache[key]
 
@@ -159,7 +159,7 @@ class _LayerFn(torch.autograd.Function):
             if not p.is_contiguous() or p.dtype != torch.float32:
                 raise _lib.CffmError('cffm layer parameters must be contiguous float32')
         g = make_geom(lib, b, h0, w0)
-        key_src, q_dst, ko_unit, ko_slot = device_tables(h0, w0, x.device)
+        key_src, q_dst, inv_ptr, inv_idx = device_tables(h0, w0, x.device)
         saved = torch.empty(lib.cffm_layer_saved_floats(C.byref(g), depth), dtype=torch.float32, device=x.device)
         scratch = torch.empty(lib.cffm_layer_scratch_floats(C.byref(g)), dtype=torch.float32, device=x.device)
         y = torch.empty(b, 256, h0, w0, dtype=torch.float32, device=x.device)
@@ -167,14 +167,14 @@ class _LayerFn(torch.autograd.Function):
         _lib.check(lib.cffm_layer_forward(C.byref(g), depth, pstructs, _ptr(x), _ptr(y), _ptr(key_src), _ptr(q_dst),
                                           _ptr(saved), _ptr(scratch), _stream(x)), lib)
         ctx.depth, ctx.geom_args = depth, (b, h0, w0)
-        ctx.save_for_backward(saved, key_src, q_dst, ko_unit, ko_slot, *params)
+        ctx.save_for_backward(saved, key_src, q_dst, inv_ptr, inv_idx, *params)
         ctx.scratch = scratch
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.get()
-        saved, key_src, q_dst, ko_unit, ko_slot, *params = ctx.saved_tensors
+        saved, key_src, q_dst, inv_ptr, inv_idx, *params = ctx.saved_tensors
         depth = ctx.depth
         b, h0, w0 = ctx.geom_args
         g = make_geom(lib, b, h0, w0)
@@ -202,7 +202,7 @@ class _LayerFn(torch.autograd.Function):
         hook = block_grad_hook
         if hook is None:
             _lib.check(lib.cffm_layer_backward(C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx), _ptr(key_src),
-                                               _ptr(q_dst), _ptr(ko_unit), _ptr(ko_slot), _ptr(saved), _ptr(ctx.scratch),
+                                               _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch),
                                                _stream(dy)), lib)
         else:
             # block by block (last block first, as the chain runs): once a block's kernels are enqueued its slice of the
@@ -211,7 +211,7 @@ class _LayerFn(torch.autograd.Function):
             per = sum(sizes[:NPB])
             for i in range(depth - 1, -1, -1):
                 _lib.check(lib.cffm_layer_backward_range(C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx),
-                                                         _ptr(key_src), _ptr(q_dst), _ptr(ko_unit), _ptr(ko_slot), _ptr(saved),
+                                                         _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved),
                                                          _ptr(ctx.scratch), i, i, _stream(dy)), lib)
                 hook(i, flat[i * per:(i + 1) * per], depth)
         return (dx, None) + tuple(grads)
@@ -257,14 +257,14 @@ class LayerPieces:
     def backward(self, dy, first_block, last_block):
         """blocks first_block .. last_block (descending) of the backward from dy [B,256,H,W] (a dense tensor or the last-frame
         slice of a [B,4,256,H,W] gradient)."""
-        key_src, q_dst, ko_unit, ko_slot = self.tables
+        key_src, q_dst, inv_ptr, inv_idx = self.tables
         b, h0, w0 = self.x.shape[0], self.x.shape[3], self.x.shape[4]
         img = 256 * h0 * w0
         if not (dy.dim() == 4 and dy.stride()[1:] == (h0 * w0, w0, 1) and (b == 1 or dy.stride(0) >= img)):
             raise _lib.CffmError('LayerPieces.backward: dy must be dense inside a clip')
         dy_bs = dy.stride(0) if b > 1 else img
         _lib.check(self.lib.cffm_layer_backward_range(C.byref(self.g), self.depth, self.pstructs, self.gstructs, _ptr(dy), dy_bs,
-                                                      _ptr(self.dx), _ptr(key_src), _ptr(q_dst), _ptr(ko_unit), _ptr(ko_slot),
+                                                      _ptr(self.dx), _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx),
                                                       _ptr(self.saved), _ptr(self.scratch), first_block, last_block,
                                                       _stream(self.x)), self.lib)
 
@@ -290,21 +290,21 @@ class _LayerFullFn(torch.autograd.Function):
             if not p.is_contiguous() or p.dtype != torch.float32:
                 raise _lib.CffmError('cffm layer parameters must be contiguous float32')
         g = make_geom(lib, b, h0, w0)
-        key_src, q_dst, ko_unit, ko_slot = device_tables(h0, w0, x.device)
+        key_src, q_dst, inv_ptr, inv_idx = device_tables(h0, w0, x.device)
         saved = torch.empty(lib.cffm_layer_saved_floats(C.byref(g), depth), dtype=torch.float32, device=x.device)
         scratch = torch.empty(lib.cffm_layer_scratch_floats(C.byref(g)), dtype=torch.float32, device=x.device)
         y = torch.empty(b, 4, 256, h0, w0, dtype=torch.float32, device=x.device)
         _lib.check(lib.cffm_layer_forward_full(C.byref(g), depth, block_structs(params, depth), _ptr(x), _ptr(y), _ptr(key_src), _ptr(q_dst),
                                                _ptr(saved), _ptr(scratch), _stream(x)), lib)
         ctx.depth, ctx.geom_args = depth, (b, h0, w0)
-        ctx.save_for_backward(saved, key_src, q_dst, ko_unit, ko_slot, *params)
+        ctx.save_for_backward(saved, key_src, q_dst, inv_ptr, inv_idx, *params)
         ctx.scratch = scratch
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.get()
-        saved, key_src, q_dst, ko_unit, ko_slot, *params = ctx.saved_tensors
+        saved, key_src, q_dst, inv_ptr, inv_idx, *params = ctx.saved_tensors
         depth = ctx.depth
         b, h0, w0 = ctx.geom_args
         g = make_geom(lib, b, h0, w0)
@@ -322,7 +322,7 @@ class _LayerFullFn(torch.autograd.Function):
         per = sum(sizes[:NPB])
         for first, last in ([(depth - 1, 0)] if hook is None else [(i, i) for i in range(depth - 1, -1, -1)]):
             _lib.check(lib.cffm_layer_backward_full(C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst),
-                                                    _ptr(ko_unit), _ptr(ko_slot), _ptr(saved), _ptr(ctx.scratch), first, last,
+                                                    _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch), first, last,
                                                     _stream(dy)), lib)
             if hook is not None:
                 hook(first, flat[first * per:(first + 1) * per], depth)
@@ -605,21 +605,21 @@ class _LayerRowsFn(torch.autograd.Function):
         x_rows = x_rows.contiguous()
         b = x_rows.shape[0]
         g = make_geom(lib, b, h0, w0)
-        key_src, q_dst, ko_unit, ko_slot = device_tables(h0, w0, x_rows.device)
+        key_src, q_dst, inv_ptr, inv_idx = device_tables(h0, w0, x_rows.device)
         saved = torch.empty(lib.cffm_layer_saved_floats(C.byref(g), depth), dtype=torch.float32, device=x_rows.device)
         scratch = torch.empty(lib.cffm_layer_scratch_floats(C.byref(g)), dtype=torch.float32, device=x_rows.device)
         y = torch.empty(b, h0 * w0, 256, dtype=torch.float32, device=x_rows.device)
         _lib.check(lib.cffm_layer_forward_rows(C.byref(g), depth, block_structs(params, depth), _ptr(x_rows), _ptr(y), _ptr(key_src),
                                                _ptr(q_dst), _ptr(saved), _ptr(scratch), _stream(x_rows)), lib)
         ctx.depth, ctx.geom_args = depth, (b, h0, w0)
-        ctx.save_for_backward(x_rows, saved, key_src, q_dst, ko_unit, ko_slot, *params)
+        ctx.save_for_backward(x_rows, saved, key_src, q_dst, inv_ptr, inv_idx, *params)
         ctx.scratch = scratch
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.get()
-        x_rows, saved, key_src, q_dst, ko_unit, ko_slot, *params = ctx.saved_tensors
+        x_rows, saved, key_src, q_dst, inv_ptr, inv_idx, *params = ctx.saved_tensors
         depth = ctx.depth
         b, h0, w0 = ctx.geom_args
         g = make_geom(lib, b, h0, w0)
@@ -632,7 +632,7 @@ class _LayerRowsFn(torch.autograd.Function):
         grads = [c[:p.numel()].view(p.shape) for c, p in zip(flat.split(sizes), params)]
         dx = torch.empty(b, 4, h0 * w0, 256, dtype=torch.float32, device=dy.device)
         _lib.check(lib.cffm_layer_backward_rows(C.byref(g), depth, block_structs(params, depth), block_structs(grads, depth), _ptr(x_rows),
-                                                _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst), _ptr(ko_unit), _ptr(ko_slot), _ptr(saved),
+                                                _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved),
                                                 _ptr(ctx.scratch), _stream(dy)), lib)
         return (dx, None, None, None) + tuple(grads)
 
