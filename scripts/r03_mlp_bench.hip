@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/r03_mlp_bench.hip -o build/r03_mlp_bench
 #define CFFM_EXPERIMENTS 1
 #include "../vss_cffm_amd/csrc/panel_kernels.h"
+#include "r03_panel_experiments.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>

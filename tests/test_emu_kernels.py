@@ -54,6 +54,45 @@ def test_layer_golden_with_the_eager_form_of_the_weight_gradient_groups():
     assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def run_nan_poisoned_backward(device):
+    """Every buffer the backward allocates starts as NaN: every element of dx and of every parameter gradient must still come out
+    finite (the library overwrites, never accumulates into, what it is handed), and the padding behind the odd-sized tensors of the
+    flat gradient buffer -- which travels through the data-parallel all-reduce -- must be zero (cffm_grad_slices_padded)."""
+    g = H.load_golden('layer_b2_8x8_d2')
+    b, h, w, depth, st, x, gy = H.layer_case_inputs(g)
+    params = [p.detach().to(device).requires_grad_(True) for p in flat_params(st, depth)]
+    xd = x.to(device).requires_grad_(True)
+    real_empty = torch.empty
+
+    def nan_empty(*size, **kw):
+        t = real_empty(*size, **kw)
+        return t.fill_(float('nan')) if t.is_floating_point() else t
+
+    y = ops.cffm_layer(xd, depth, params)
+    ops.torch.empty = nan_empty
+    try:
+        (y[:, -1] * gy.to(device)).sum().backward()
+    finally:
+        ops.torch.empty = real_empty
+    assert torch.isfinite(xd.grad).all()
+    flat = torch.empty(0, dtype=torch.float32, device=device).set_(params[0].grad.untyped_storage())   # the flat buffer behind the views
+    assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in params)
+    assert flat.numel() == sum((p.numel() + 3) // 4 * 4 for p in params) and torch.isfinite(flat).all()
+    off = 0
+    for p in params:
+        assert torch.isfinite(p.grad).all()
+        pad = flat[off + p.numel(): off + (p.numel() + 3) // 4 * 4]
+        assert float(pad.abs().sum()) == 0 if pad.numel() else True
+        off += (p.numel() + 3) // 4 * 4
+    H.check_layer_backward(g, xd.grad.cpu(), {'blocks.%d.%s' % (i, k): params[i * ops.NPB + j].grad.cpu() for i in range(depth)
+                                              for j, (k, _, _) in enumerate(ops.BLOCK_PARAM_KEYS)}, BWD_TOL)
+
+
+def test_every_gradient_element_is_written_and_the_padding_is_zeroed():
+    with emu.active():
+        run_nan_poisoned_backward(torch.device('cpu'))
+
+
 def run_depth3_against_oracle(device, b, h, w):
     """Three blocks (the goldens stop at depth 2): every block ADDS its reference-frame gradients to what the later blocks wrote,
     the target-frame gradient ping-pongs between two buffers an odd number of times, and the pass-through frames' upstream

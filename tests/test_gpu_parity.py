@@ -274,3 +274,25 @@ def test_stage_level_on_device():
 def test_gtc_against_reference_golden(case):
     from tests.test_emu_kernels import run_gtc_case
     run_gtc_case(case, dev())
+
+
+def test_every_gradient_element_is_written_and_the_padding_is_zeroed_gpu():
+    """NaN-poisoned allocations: dx and every parameter gradient finite, the padding of the flat gradient buffer zeroed by the library
+    (include/cffm_hip.h cffm_grad_slices_padded), goldens still met."""
+    from tests.test_emu_kernels import run_nan_poisoned_backward
+    run_nan_poisoned_backward(torch.device('cuda'))
+
+
+@pytest.mark.parametrize('form', ['split', 'group'])
+def test_layer_goldens_with_either_form_of_the_weight_gradient_groups_gpu(form):
+    """CFFM_DW_GROUP is the one environment switch the product library reads: the block backward issues its four weight-gradient
+    GEMMs as two early groups of two when launched eagerly ('split') and as one late group under stream capture ('group'); the choice
+    is cached per process, hence the subprocess.  Both forms forced, against the reference goldens (eager launches)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CFFM_DW_GROUP=form)
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider', '-m', 'gpu', os.path.abspath(__file__), '-k',
+                        'test_layer_against_reference_golden'], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and '5 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -52,6 +52,7 @@ SIGNATURES = {
     'cffm_transpose': (ci, [vp, vp, ci, ci, ci, cl, cl, vp]),
     'cffm_pool_matrix': (ci, [P4, vp, vp]),
     'cffm_pool_matrix_bwd': (ci, [vp, P4, vp]),
+    'cffm_grad_slices_padded': (None, [ci]),
     'cffm_ln_pool_fwd': (ci, [GP, vp, cl, vp, cl, vp, vp, vp, P4, vp, vp, vp, vp]),
     'cffm_ln_pool_bwd': (ci, [GP, vp, cl, vp, cl, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp, cl, vp, vp, vp, P4, vp]),
     'cffm_bias_assemble': (ci, [vp, vp, P4, vp, vp, vp]),
@@ -130,6 +131,8 @@ def bind(path):
         fn.restype, fn.argtypes = res, args
     if lib.cffm_abi_version() != ABI_VERSION:
         raise CffmError('%s: ABI version %d, expected %d' % (path, lib.cffm_abi_version(), ABI_VERSION))
+    # vss_cffm_amd.ops keeps every gradient in a 16-byte-aligned slice of one flat buffer: the library zeroes the padding (include/cffm_hip.h)
+    lib.cffm_grad_slices_padded(1)
     return lib
 
 

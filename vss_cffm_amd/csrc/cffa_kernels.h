@@ -101,7 +101,7 @@ __device__ __forceinline__ void cell_geom(int g, int& grp, int& u, int& v, int& 
 }
 
 struct PoolW { const float* w[4]; };  // pool_layers.0, pool_layers_clips.{0,1,2} weights
-struct PoolWG { float* w[4]; };
+struct PoolWG { float* w[4]; float* b[4]; };   // b: the four pool-bias gradients, or NULL (see k_pool_matrix_bwd: padding of flat gradient buffers)
 
 // entry (cell g, window pixel i) of the pooling matrix
 __device__ __forceinline__ float pool_matrix_entry(const PoolW& pw, int g, int i) {
@@ -142,6 +142,16 @@ __global__ void __launch_bounds__(64) k_pool_matrix_bwd(const float* __restrict_
     }
     acc = wave_sum(acc);
     if (i == 0) gw.w[grp][k] = acc;
+    // The seven gradient tensors of a block whose length is not a multiple of 4 floats -- the pooling weights of 49 / 49 / 9 elements
+    // and the four scalar pooling biases -- all belong to the pooling Linears.  When the caller keeps every gradient in a slice padded
+    // to 16 bytes of one flat buffer (cffm_grad_slices_padded: vss_cffm_amd.ops does, the data-parallel exchange all-reduces that
+    // buffer whole), this launch also zeroes the 3 floats behind each of them, so recycled memory never travels through a collective
+    // as NaN / Inf bit patterns and no separate fill kernel sits in front of the backward.
+    if (t == 0 && i < 3 && gw.b[0]) {
+        gw.w[0][49 + i] = 0.f; gw.w[1][49 + i] = 0.f; gw.w[2][9 + i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gw.b[q][1 + i] = 0.f;
+    }
 }
 
 // --------------------------------------------------------------------------- geometry helpers

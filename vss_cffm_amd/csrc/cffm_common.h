@@ -19,6 +19,17 @@
 #endif
 #endif
 
+// Tuning switches (launch shapes, stream forks, rejected forms kept for A/B runs) are read from the environment only in
+// -DCFFM_EXPERIMENTS builds (scripts/): the product library is built without it, and there every switch IS its default -- what
+// bench.py and the -m gpu tests run is the only configuration libcffm_hip.so has.  (The one exception is documented where it is read:
+// CFFM_DW_GROUP, the two legitimate forms of the weight-gradient groups, both covered by tests.)
+#include <stdlib.h>
+#ifdef CFFM_EXPERIMENTS
+static inline const char* cffm_tune(const char* name) { return getenv(name); }
+#else
+static inline const char* cffm_tune(const char*) { return nullptr; }
+#endif
+
 // ---- fixed problem constants of the reference head (cffm_head.py:74-95) ------------------------
 #define CFFM_C 256         // embed_dim of every CFFM config
 #define CFFM_HEADS 8

@@ -14,6 +14,16 @@
 
 #include "../../include/cffm_hip.h"
 
+// A boolean / integer tuning switch: a constant in the product build, an environment variable in -DCFFM_EXPERIMENTS builds (see
+// cffm_tune in cffm_common.h).  The alternative legs these switches select are dead code the compiler removes from libcffm_hip.so.
+#ifdef CFFM_EXPERIMENTS
+#define CFFM_SWITCH(fn, env, dflt) static int fn() { static int v = -(1 << 30); if (v == -(1 << 30)) { const char* e = getenv(env); v = e ? atoi(e) : (dflt); } return v; }
+#define constexpr_or_not
+#else
+#define CFFM_SWITCH(fn, env, dflt) static constexpr int fn() { return (dflt); }
+#define constexpr_or_not constexpr
+#endif
+
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char* fmt, ...) {
@@ -369,13 +379,13 @@ static bool side_init(hipStream_t main) {
     if (state < 0) {
         state = 0;
 #ifndef CFFM_EMU
-        const char* e = getenv("CFFM_SIDE_STREAM");
-        const char* n = getenv("CFFM_SIDE_STREAMS");
+        const char* e = cffm_tune("CFFM_SIDE_STREAM");
+        const char* n = cffm_tune("CFFM_SIDE_STREAMS");
         forced_ns = !n ? 0 : (n[0] == '1' ? 1 : (n[0] == '4' ? 4 : 2));
         // CFFM_SIDE_PRIO=low: the side streams get the lowest stream priority (parameter-gradient work yields to the chain's kernels
         // when both have workgroups ready)
         int lo = 0, hi = 0;
-        const char* pr = getenv("CFFM_SIDE_PRIO");
+        const char* pr = cffm_tune("CFFM_SIDE_PRIO");
         const bool low = pr && pr[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         auto mk = [&](hipStream_t* st_) { return (low ? hipStreamCreateWithPriority(st_, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(st_, hipStreamNonBlocking)) == hipSuccess; };
         if (!(e && e[0] == '0') && mk(&g_side.st[0]) && mk(&g_side.st[1]) && mk(&g_side.st[2]) && mk(&g_side.st[3])) {
@@ -418,11 +428,7 @@ static bool side_init(hipStream_t main) {
 // stretch beside the gather instead of behind the weight gradients on the step's tail) -> 0.773-0.785 against 0.783-0.786 for 38; with
 // the last block's tail on the caller's stream and the L2 warm-up of the fused kernels 38 is ahead again (one fork less on the chain:
 // a node with a dependant on another stream costs its same-stream successor ~5 us): 0.724-0.728 against 0.732-0.737 for 35.
-static int fork_order() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_FORK_ORDER"); v = e ? atoi(e) : 38; }
-    return v;
-}
+CFFM_SWITCH(fork_order, "CFFM_FORK_ORDER", 38)
 static int dw_one_group(hipStream_t st) {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("CFFM_DW_GROUP"); forced = !e ? -1 : (e[0] == 's' ? 0 : 1); }
@@ -619,14 +625,17 @@ int cffm_pool_matrix(const float* const pool_w[4], float* M, void* stream) {
     return 0;
 }
 
-int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream) {
+static int g_grad_pads = 0;
+void cffm_grad_slices_padded(int yes) { g_grad_pads = yes ? 1 : 0; }
+static int pool_matrix_bwd_impl(const float* dM, float* const dpool_w[4], float* const dpool_b[4], void* stream) {
     PROF(ST_POOLMAT);
     PoolWG gw;
-    for (int i = 0; i < 4; ++i) gw.w[i] = dpool_w[i];
+    for (int i = 0; i < 4; ++i) { gw.w[i] = dpool_w[i]; gw.b[i] = dpool_b ? dpool_b[i] : nullptr; }
     CFFM_LAUNCH(k_pool_matrix_bwd, (111), (64), 0, (hipStream_t)stream, dM, gw);
     CHECK_LAUNCH("pool_matrix_bwd");
     return 0;
 }
+int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream) { return pool_matrix_bwd_impl(dM, dpool_w, nullptr, stream); }
 
 // `split`: the rows a GEMM is the only reader of are written in split-4 storage (cffm_common.h); the public stage
 // functions always write plain fp32, the block orchestration asks for split-4 when the hand-written GEMMs are in use
@@ -711,7 +720,7 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
 static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
     const int total = g->B * g->nW;
     static int want = -1;   // tuning aid: CFFM_BWD_GROUPS
-    if (want < 0) { const char* e = getenv("CFFM_BWD_GROUPS"); want = e ? atoi(e) : 64; if (want < 1) want = 64; }
+    if (want < 0) { const char* e = cffm_tune("CFFM_BWD_GROUPS"); want = e ? atoi(e) : 64; if (want < 1) want = 64; }
     int ng = total < want ? total : want;
     *per_group = (total + ng - 1) / ng;
     return (total + *per_group - 1) / *per_group;
@@ -783,11 +792,6 @@ int cffm_linear_bias_fwd(const float* x, const float* w, const float* b, float* 
     if (!M) return 0;
     REQUIRE(x && w && b && y, "linear_bias_fwd: null");
     PROF(ST_GEMM);
-    if (gemm_use_lib()) {
-        if (gemm_nt_lib(x, w, y, M, N, K, (hipStream_t)stream)) return fail(-3, "linear_bias_fwd: gemm failed");
-        CFFM_LAUNCH(k_add_bias_rows, ((unsigned)((M * N + 255) / 256)), (256), 0, (hipStream_t)stream, y, b, M, N);
-        return 0;
-    }
     return gemm_split_launch<false, false>(x, w, y, (int)M, N, K, K, K, N, 1, (hipStream_t)stream, b) ? fail(-3, "linear_bias_fwd: gemm failed") : 0;
 }
 int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, int N, int K, void* stream) {
@@ -812,37 +816,18 @@ int cffm_linear_bwd_weight_group(const cffm_wgrad* problems, int n, void* stream
 // q|k|v Linear feeding the CFM kernels: qkv16[M,768] (f16) = x w^T + b, q third times 32^-0.5 (cffm_transformer.py:374, :528)
 int cffm_linear_qkv_fwd(const float* x, const float* w, const float* b, void* qkv16, long M, void* stream) {
     REQUIRE(x && w && b && qkv16, "linear_qkv_fwd: null");
-    if (gemm_use_lib()) {
-        float* tmp = lib_scratch((size_t)M * 768);
-        REQUIRE(tmp, "linear_qkv_fwd: scratch allocation failed");
-        TRY(cffm_linear_fwd(x, w, tmp, M, 768, CFFM_C, stream));
-        const long n4 = M * 768 / 4;
-        CFFM_LAUNCH(k_qkv_to_f16, (ew_grid(n4)), (256), 0, (hipStream_t)stream, (const float*)tmp, b, (h16*)qkv16, n4);
-        CHECK_LAUNCH("qkv_to_f16");
-        return 0;
-    }
     PROF(ST_GEMM);
     return gemm_nt_qkv16_split(x, w, b, (h16*)qkv16, M, 768, CFFM_C, (hipStream_t)stream) ? fail(-3, "linear_qkv_fwd: gemm failed") : 0;
 }
 
-// fused Mlp halves (one launch each on the hand-written GEMM; the exact-fp32 library path sequences the unfused stages)
+// fused Mlp halves (one launch each)
 int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K, void* stream) {
-    if (gemm_use_lib()) {
-        TRY(cffm_linear_fwd(x, w, hraw, M, N, K, stream));
-        return cffm_bias_gelu(hraw, b, act, M, N, stream);
-    }
     PROF(ST_GEMM);
     REQUIRE(N % 4 == 0, "linear_gelu_fwd: N %% 4");
     return gemm_nt_gelu_split(x, w, b, hraw, act, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_gelu_fwd: gemm failed") : 0;
 }
 int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, const float* res, float* out, long M, int N, int K,
                              void* stream) {
-    if (gemm_use_lib()) {
-        float* tmp = lib_scratch((size_t)M * N);
-        REQUIRE(tmp && N == CFFM_C, "linear_residual_fwd: library path needs N == 256");
-        TRY(cffm_linear_fwd(x, w, tmp, M, N, K, stream));
-        return cffm_residual_out(res, tmp, b, out, M, stream);
-    }
     PROF(ST_GEMM);
     REQUIRE(N % 4 == 0, "linear_residual_fwd: N %% 4");
     return gemm_nt_residual_split(x, w, b, res, out, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_residual_fwd: gemm failed") : 0;
@@ -1022,16 +1007,8 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
 // CFFM_STORE_ACT=0: the fused forward does NOT store gelu(hraw + b1); the fc2 weight gradient re-applies bias + GELU to hraw while it
 // stages its tiles (29.5 MB less written per block, but the GELU then sits in the weight-gradient GEMM's staging path: measured
 // 0.8914 vs 0.8843 ms per step without / with the stored activation, means of three alternating runs -- storing is the default)
-static int store_act() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_STORE_ACT"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v;
-}
-static int panel_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_PANEL"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v;
-}
+CFFM_SWITCH(store_act, "CFFM_STORE_ACT", 1)
+CFFM_SWITCH(panel_on, "CFFM_PANEL", 1)
 #define MLP_MT 2
 #define MLP_D 4
 static int mlp_lds_grant() {
@@ -1082,16 +1059,9 @@ static int panel_qkv_dx(const float* dqkv, const float* wfn, float* dx, long M, 
 }
 // CFFM_PANEL_QKV=0: the q|k|v Linear keeps the tiled GEMMs (A/B: 0.8843 tiled vs 0.8729 ms per step as row panels, means of three
 // alternating runs with the activation stored)
-static int qkv_colrec_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_QKV_COLREC"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v;
-}
-static int panel_qkv_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_PANEL_QKV"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v && panel_on();
-}
+CFFM_SWITCH(qkv_colrec_on, "CFFM_QKV_COLREC", 1)
+CFFM_SWITCH(panel_qkv_sw, "CFFM_PANEL_QKV", 1)
+static constexpr_or_not int panel_qkv_on() { return panel_qkv_sw() && panel_on(); }
 
 long cffm_mlp_records(long NP) { return (NP + 16 * MLP_MT - 1) / (16 * MLP_MT); }
 
@@ -1168,7 +1138,7 @@ static int prep_args(PrepArgs& a, const cffm_block_params* params, int d0, int n
     a.nbias = nb;
     // pack: 0 nothing (library GEMMs) | 1 split-4 copy + fragment-ordered copies | 2 fragment-ordered copies only -- every Linear of the
     // block runs as a row-panel kernel then and nobody reads the split-4 copy (3 MB read + 3 MB written per block saved)
-    a.pack = gemm_use_lib() ? 0 : ((panel_on() && panel_qkv_on()) ? 2 : 1);
+    a.pack = (panel_on() && panel_qkv_on()) ? 2 : 1;
     return nb + 1 + (a.pack ? PREP_WBLOCKS + PREP_FBLOCKS : 0);      // workgroups per block
 }
 static int param_prep(const cffm_block_params* params, int n, float* ws0, long ws_stride, const cffm_block_ws& L, void* stream) {
@@ -1208,7 +1178,7 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     // Hand-written GEMMs: the tensors only they read (zall, z2, act) are produced in split-4 storage and the weights come
     // from the split-4 copy k_param_prep made (ws.w_split), so no operand tile is split while it is staged -- except ao,
     // which the attention backward also reads.  CFFM_GEMM=lib (rocBLAS cross-check) keeps everything plain fp32.
-    const int sp = gemm_use_lib() ? 0 : 1;
+    constexpr int sp = 1;   // split-4 storage of what only the GEMMs read (zall, z2, act, dh) and of the weights: always (the library-GEMM form that kept plain fp32 left in round 4)
     const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
     // (a pending join with the side-stream parameter prep -- layer_forward_impl -- is taken AFTER this launch: the kernel builds its
     //  pooling-matrix rows from the raw weights then, and the chain's first kernel does not wait for another stream)
@@ -1222,12 +1192,13 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     if (sp && panel_qkv_on()) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
         REQUIRE(!panel_qkv_fwd(ws + L.zall, ws + L.w_frag, p->qkv_b, (h16*)(ws + L.qkv), NR, st), "block_forward: qkv gemm failed");
-    } else if (sp) {
+    }
+#ifdef CFFM_EXPERIMENTS   // the tiled q|k|v GEMM (rounds 1-2), CFFM_PANEL_QKV=0
+    else {
         PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
         REQUIRE(!gemm_nt_qkv16_split_pre(ws + L.zall, wq_s, p->qkv_b, (h16*)(ws + L.qkv), NR, 768, CFFM_C, st), "block_forward: qkv gemm failed");
-    } else {
-        TRY(cffm_linear_qkv_fwd(ws + L.zall, p->qkv_w, p->qkv_b, ws + L.qkv, NR, stream));
     }
+#endif
     TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, (const void*)(ws + L.bias), ws + L.ao, ws + L.lse, stream));
     if (sp && panel_on()) {
         // proj + residual + norm2 + Mlp in one row-panel launch (panel_kernels.h); weights in fragment order from k_param_prep
@@ -1240,31 +1211,29 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
         CHECK_LAUNCH("block_forward");
         return 0;
     }
-    if (sp) {
+#ifdef CFFM_EXPERIMENTS   // the block as separate tiled GEMMs + row kernels (rounds 1-2), CFFM_PANEL=0
+    {
         PROF(ST_GEMM); PROF2(ST_G_PROJ_FWD);
         REQUIRE(!gemm_nt_split_pre<false>(ws + L.ao, wp_s, yraw, NP, CFFM_C, CFFM_C, st), "block_forward: proj gemm failed");
-    } else {
-        TRY(cffm_linear_fwd(ws + L.ao, p->proj_w, yraw, NP, CFFM_C, CFFM_C, stream));
     }
     TRY(residual_ln_impl(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
                          ws + L.mean2, ws + L.rstd2, NP, sp, stream));
-    if (sp) {
-        {
-            PROF(ST_GEMM); PROF2(ST_G_FC1_FWD);
-            REQUIRE(!gemm_nt_gelu_split_pre(ws + L.z2, w1_s, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, st),
-                    "block_forward: fc1 gemm failed");
-        }
-        {
-            PROF(ST_GEMM); PROF2(ST_G_FC2_FWD);
-            REQUIRE(!gemm_nt_residual_split_pre(ws + L.act, w2_s, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, st),
-                    "block_forward: fc2 gemm failed");
-        }
-    } else {
-        TRY(cffm_linear_gelu_fwd(ws + L.z2, p->fc1_w, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, stream));
-        TRY(cffm_linear_residual_fwd(ws + L.act, p->fc2_w, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, stream));
+    {
+        PROF(ST_GEMM); PROF2(ST_G_FC1_FWD);
+        REQUIRE(!gemm_nt_gelu_split_pre(ws + L.z2, w1_s, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, st),
+                "block_forward: fc1 gemm failed");
+    }
+    {
+        PROF(ST_GEMM); PROF2(ST_G_FC2_FWD);
+        REQUIRE(!gemm_nt_residual_split_pre(ws + L.act, w2_s, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, st),
+                "block_forward: fc2 gemm failed");
     }
     CHECK_LAUNCH("block_forward");
     return 0;
+#else
+    (void)yraw; (void)wq_s; (void)wp_s; (void)w1_s; (void)w2_s;
+    return fail(-3, "block_forward: unreachable");
+#endif
 }
 
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
@@ -1289,7 +1258,7 @@ static int tail_flush(hipStream_t st, bool on_main = false, hipStream_t on = nul
         g_tail.cs = false;
         redq_launch(g_tail.jobs, s3);
         CHECK_LAUNCH("block_backward reductions");
-        TRY(cffm_pool_matrix_bwd(g_tail.dM, g_tail.gr->pool_w, (void*)s3));
+        TRY(pool_matrix_bwd_impl(g_tail.dM, g_tail.gr->pool_w, g_grad_pads ? g_tail.gr->pool_b : nullptr, (void*)s3));
         side_record(s3, st, g_side.tail_done[g_tail.parity]);
         g_side.tail_pending[g_tail.parity] = true;
         return 0;
@@ -1302,7 +1271,7 @@ static int tail_flush(hipStream_t st, bool on_main = false, hipStream_t on = nul
     g_tail.cs = false;
     redq_launch(g_tail.jobs, s3);
     CHECK_LAUNCH("block_backward reductions");
-    TRY(cffm_pool_matrix_bwd(g_tail.dM, g_tail.gr->pool_w, (void*)s3));
+    TRY(pool_matrix_bwd_impl(g_tail.dM, g_tail.gr->pool_w, g_grad_pads ? g_tail.gr->pool_b : nullptr, (void*)s3));
     if (s3 != st) {
         side_record(s3, st, g_side.tail_done[g_tail.parity]);
         g_side.tail_pending[g_tail.parity] = true;
@@ -1314,7 +1283,7 @@ static int tail_flush(hipStream_t, bool = false, hipStream_t = nullptr) { return
 #endif
 static bool tail_on_main() {     // CFFM_TAIL_MAIN=0: the last block's tail on the side stream like every other block's (A/B)
     static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_TAIL_MAIN"); v = (e && e[0] == '0') ? 0 : 1; }
+    if (v < 0) { const char* e = cffm_tune("CFFM_TAIL_MAIN"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
 static void tail_reset() {      // entry of a layer backward: nothing of a previous (failed) call is left to launch or to wait for
@@ -1342,7 +1311,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     REQUIRE(g && p && gr && ws && dout && scratch, "block_backward: null");
     {
         static int defer_env = -1;   // CFFM_DEFER_JOIN=0: every block ends fully joined (round-2 behaviour; A/B measurements)
-        if (defer_env < 0) { const char* e = getenv("CFFM_DEFER_JOIN"); defer_env = (e && e[0] == '0') ? 0 : 1; }
+        if (defer_env < 0) { const char* e = cffm_tune("CFFM_DEFER_JOIN"); defer_env = (e && e[0] == '0') ? 0 : 1; }
         defer = defer && defer_env;
     }
     cffm_block_ws L;
@@ -1377,7 +1346,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         g_side.dw_pending[par] = false;
     }
 #endif
-    const int sp = gemm_use_lib() ? 0 : 1;   // see block_forward_impl: zall / z2 / act / weights (and dh below) in split-4 storage
+    constexpr int sp = 1;   // see block_forward_impl: zall / z2 / act / weights (and dh below) in split-4 storage
     const int one_group = sp ? dw_one_group(st) : 0;
     if (sp && !one_group) {
         // the grouped form (chosen under stream capture) needs larger partial slabs than the split form: size the side scratch for it
@@ -1390,12 +1359,8 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
 #define DX_GEMM(FAM, PRE_DY, dy_, w_plain, w_s_, dx_, M_, N_, K_)                                                         \
     do {                                                                                                                  \
-        if (sp) {                                                                                                         \
-            PROF(ST_GEMM); PROF2(FAM);                                                                                    \
-            REQUIRE(!gemm_nn_split_pre<PRE_DY>(dy_, w_s_, dx_, M_, N_, K_, st), "block_backward: input-gradient gemm failed"); \
-        } else {                                                                                                          \
-            TRY(cffm_linear_bwd_input(dy_, w_plain, dx_, M_, N_, K_, stream));                                            \
-        }                                                                                                                 \
+        PROF(ST_GEMM); PROF2(FAM);                                                                                        \
+        REQUIRE(!gemm_nn_split_pre<PRE_DY>(dy_, w_s_, dx_, M_, N_, K_, st), "block_backward: input-gradient gemm failed"); \
     } while (0)
     // x2 = x1 + act W2^T + b2
     // act = gelu(hraw + b1); hraw = z2 W1^T: the GELU backward runs in the epilogue of the fc2 input-gradient GEMM (dact is
@@ -1422,7 +1387,9 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             }
             side_mark(sa, st, 0);
         }
-    } else if (sp) {
+    }
+#ifdef CFFM_EXPERIMENTS   // the block backward as separate tiled GEMMs + row kernels (rounds 1-2), CFFM_PANEL=0
+    else {
         PROF(ST_GEMM); PROF2(ST_G_FC2_DX);
         const int nrec = GEMM_GELUBWD_RECORDS(NP);
         float* part = red_scratch((size_t)nrec * CFFM_HID, st);
@@ -1447,10 +1414,9 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         }
         side_mark(sa, st, 0);
         }
-    } else {
-        TRY(cffm_linear_bwd_input(dout, p->fc2_w, dact, NP, CFFM_C, CFFM_HID, stream));
-        TRY(gelu_bwd_impl(ws + L.hraw, p->fc1_b, dact, NP, CFFM_HID, gr->fc1_b, 0, stream));
     }
+#endif
+#ifdef CFFM_EXPERIMENTS
     if (!panel) {
     DX_GEMM(ST_G_FC1_DX, true, dact, p->fc1_w, w1_s, dz2, NP, CFFM_HID, CFFM_C);
     // z2 = LN2(x1); x1 also feeds the residual
@@ -1459,6 +1425,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     // x1 = xt + ao Wp^T + bp
     DX_GEMM(ST_G_PROJ_DX, false, dx1, p->proj_w, wp_s, dao, NP, CFFM_C, CFFM_C);
     }
+#endif
     // attention: the fused kernel and the dK/dV gather stay on the chain; the bias-gradient tile sum and its scatter into the six
     // tables go to the side stream (branch 1), the q|k|v bias column sum and the weight gradients of q|k|v / proj after the gather
     // (branch 2)
@@ -1563,24 +1530,18 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             bias_late = 0;
         }
         }
-    } else {
-        TRY(cffm_colsum(dqkv, NR, 768, gr->qkv_b, stream));
     }
     if (dx_done) {
     } else if (sp && panel_qkv_on()) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
         REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st, qkv_rec), "block_backward: q|k|v input-gradient gemm failed");
-    } else {
+    }
+#ifdef CFFM_EXPERIMENTS
+    else {
         DX_GEMM(ST_G_QKV_DX, false, dqkv, p->qkv_w, wq_s, dzall, NR, 768, CFFM_C);
     }
+#endif
 #undef DX_GEMM
-    if (!sp) {
-        const cffm_wgrad wg[4] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C},
-                                  {dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C},
-                                  {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID},
-                                  {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
-        TRY(cffm_linear_bwd_weight_group(wg, 4, stream));
-    }
     if (!one_group || dx_tgt == dout) side_join(sa, st, 0);    // fc2's weight gradient has read dout before an in-place ln_pool_bwd overwrites it
 #ifndef CFFM_EMU
     if (g_side.dw_pending[par ^ 1] && g_side.dw_dout[par ^ 1] == dx_tgt) {   // (depth >= 3: the block before still reads its dout = our dx_tgt)
@@ -1613,7 +1574,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     if (sp && s1 != st && s3 != st && s1 != s3) side_order(s1, s3);   // (four side streams: branch 1 joins through branch 3)
     reductions.finish_on(s3);
     CHECK_LAUNCH("block_backward reductions");
-    TRY(cffm_pool_matrix_bwd(dM, gr->pool_w, (void*)s3));
+    TRY(pool_matrix_bwd_impl(dM, gr->pool_w, g_grad_pads ? gr->pool_b : nullptr, (void*)s3));
 #ifndef CFFM_EMU
     if (defer && sp && sb != st && s3 != st) {
         // (no wait for the weight-gradient GEMMs: the next block works in the other scratch set; whoever reuses THIS set, or writes
@@ -1813,8 +1774,8 @@ int cffm_upce_maps_bwd(const float* logits, const long long* labels, const int* 
     // fallback for down-sampling geometries, where blocks are not contiguous runs)
     static int form = -1, ty_env = 0, slots = 0;
     if (form < 0) {
-        const char* e = getenv("CFFM_UPCE_BWD");
-        const char* t = getenv("CFFM_UPCE_TY");
+        const char* e = cffm_tune("CFFM_UPCE_BWD");
+        const char* t = cffm_tune("CFFM_UPCE_TY");
         ty_env = t ? atoi(t) : 0;
         slots = 1024;                                   // resident workgroups of the block kernel on the whole device
 #ifndef CFFM_EMU
@@ -2076,7 +2037,7 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
     hipStream_t st = (hipStream_t)stream;
     side_init(st);
     static int fused_prep = -1;      // CFFM_PREP_FUSED=0: the prep on the side stream beside the transpose (A/B)
-    if (fused_prep < 0) { const char* e = getenv("CFFM_PREP_FUSED"); fused_prep = (e && e[0] == '0') ? 0 : 1; }
+    if (fused_prep < 0) { const char* e = cffm_tune("CFFM_PREP_FUSED"); fused_prep = (e && e[0] == '0') ? 0 : 1; }
     if (fused_prep && depth <= PREP_MAXD) {
         // ONE launch: the input transpose (frames 0..2 also copied to y_full) + the parameter prep of every block (k_transpose_prep)
         PROF(ST_TRANSPOSE);
@@ -2097,7 +2058,7 @@ static int layer_forward_impl(const cffm_geom* g, int depth, const cffm_block_pa
     side_mark(sd, st, 0);
     {
         static int early = -1;           // CFFM_PREP_JOIN=early: join in front of the first block (A/B)
-        if (early < 0) { const char* e = getenv("CFFM_PREP_JOIN"); early = (e && e[0] == 'e') ? 1 : 0; }
+        if (early < 0) { const char* e = cffm_tune("CFFM_PREP_JOIN"); early = (e && e[0] == 'e') ? 1 : 0; }
         g_prep_join.pending = sd != st && !early;      // joined behind the first block's ln_pool_fwd (block_forward_impl)
         g_prep_join.side = sd;
         if (!g_prep_join.pending) side_join(sd, st, 0);

@@ -1,7 +1,7 @@
-// gemm.h -- the plain dense Linear GEMMs of the block (qkv, proj, fc1, fc2 and their gradients), fp32.
-// These are library GEMMs (rocBLAS SGEMM on the caller's stream); the hand-written kernels of this
-// library are the CFFA / CFM path around them.  Row-major operands are mapped onto rocBLAS'
-// column-major interface by swapping operand roles (C^T = B^T A^T), never by copying.
+// gemm.h -- host side of the dense Linear GEMMs (qkv, proj, fc1, fc2 and their gradients; the head's classifiers and embedding):
+// launchers of the hand-written split-bf16 MFMA kernels of gemm_kernels.h (fp32 operands split into bf16 hi + lo, three MFMA
+// products per fp32 product, fp32 accumulate).  There is no library GEMM behind this file: rounds 1-3 carried a dlopen-ed
+// rocBLAS SGEMM as a cross-check (CFFM_GEMM=lib); it left with the rest of the alternative code paths in round 4.
 #pragma once
 #include <stdlib.h>
 #include "gemm_kernels.h"
@@ -45,7 +45,7 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
     // measured on MI355X (scripts/gemm_bench.py, CFFM-B1 shapes): 128x128 wins when it already gives >= 384 workgroups
     // (qkv / fc1 forward, the 1024-wide input gradient), 64x64 otherwise; prefetch depth beyond the listed one is neutral.
     static int sel = -1;   // tuning aid: CFFM_GEMM_SEL = 1 -> 128x64 tiles, 2 -> 64x128, 3 -> 128x128 for the small cases
-    if (sel < 0) { const char* e = getenv("CFFM_GEMM_SEL"); sel = e ? atoi(e) : 0; }
+    if (sel < 0) { const char* e = cffm_tune("CFFM_GEMM_SEL"); sel = e ? atoi(e) : 0; }
     if (b128 >= 384 || prefer_big) {
         GEMM_GO(128, 128, 32, 1);   // a second K-tile in flight in registers: neutral (k-contiguous forms) or one workgroup per CU (others)
     } else if (sel == 1) GEMM_GO(128, 64, 32, 2);
@@ -136,7 +136,7 @@ static size_t gemm_tn_group_partial_floats(const GemmTN* pr, int n, int target_w
         if (pr[p].N % 128 || pr[p].K % 128 || pr[p].M < 32) return 0;
         units += (long)(pr[p].N / 128) * (pr[p].K / 128) * ((pr[p].M + 31) / 32);
     }
-    const char* e = getenv("CFFM_GROUP_WGS");
+    const char* e = cffm_tune("CFFM_GROUP_WGS");
     const int env = e ? atoi(e) : 0, target = env > 0 ? env : (target_wgs > 0 ? target_wgs : 480);
     long ksteps = (units + target - 1) / target;
     if (ksteps < 4) ksteps = 4;
@@ -173,7 +173,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
     long units = 0;
     for (int p = 0; p < n; ++p) units += (long)(pr[p].N / 128) * (pr[p].K / 128) * ((pr[p].M + 31) / 32);
     static int target_env = -1;   // tuning aid: CFFM_GROUP_WGS
-    if (target_env < 0) { const char* e = getenv("CFFM_GROUP_WGS"); target_env = e ? atoi(e) : 0; if (target_env < 0) target_env = 0; }
+    if (target_env < 0) { const char* e = cffm_tune("CFFM_GROUP_WGS"); target_env = e ? atoi(e) : 0; if (target_env < 0) target_env = 0; }
     const int target = target_env ? target_env : (target_wgs > 0 ? target_wgs : 480);
     long ksteps = (units + target - 1) / target;
     if (ksteps < 4) ksteps = 4;
@@ -220,7 +220,7 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
     // finish; with one per CU the two kernels really share the CUs: the group 62 -> 70 us, k_ln_pool_bwd 85 -> 77, step 0.717-0.730 ->
     // 0.713-0.722 ms (same box, three alternating runs; 256 / 384 / 512 workgroups instead of 480: slower).  CFFM_DW_LDS_PAD=0: two per CU.
     static int lds_pad = -1;
-    if (lds_pad < 0) { const char* e = getenv("CFFM_DW_LDS_PAD"); lds_pad = e ? atoi(e) : 8192; if (lds_pad < 0 || lds_pad > 16384) lds_pad = 8192; }
+    if (lds_pad < 0) { const char* e = cffm_tune("CFFM_DW_LDS_PAD"); lds_pad = e ? atoi(e) : 8192; if (lds_pad < 0 || lds_pad > 16384) lds_pad = 8192; }
     CFFM_LAUNCH(k_gemm_group_tt, ((unsigned)wg), (256), GEMM_LDS(128, 128, 32) + lds_pad, st, G);
     if (after_gemm) after_gemm(st);
     if (nsum) {
@@ -231,111 +231,17 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
     return 0;
 }
 
-#ifdef CFFM_EMU
-// TEST INFRASTRUCTURE (emulator build only): naive host loops standing in for rocBLAS.
-static int gemm_nt_lib(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t) {
-    for (long m = 0; m < M; ++m)
-        for (int n = 0; n < N; ++n) {
-            double acc = 0;
-            for (int k = 0; k < K; ++k) acc += (double)x[m * K + k] * w[(long)n * K + k];
-            y[m * N + n] = (float)acc;
-        }
-    return 0;
-}
-static int gemm_nn_lib(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t) {
-    for (long m = 0; m < M; ++m)
-        for (int k = 0; k < K; ++k) {
-            double acc = 0;
-            for (int n = 0; n < N; ++n) acc += (double)dy[m * N + n] * w[(long)n * K + k];
-            dx[m * K + k] = (float)acc;
-        }
-    return 0;
-}
-static int gemm_tn_lib(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t) {
-    for (int n = 0; n < N; ++n)
-        for (int k = 0; k < K; ++k) {
-            double acc = 0;
-            for (long m = 0; m < M; ++m) acc += (double)dy[m * N + n] * x[m * K + k];
-            dw[(long)n * K + k] = (float)acc;
-        }
-    return 0;
-}
-#else
-// rocBLAS is a debugging cross-check (CFFM_GEMM=lib: exact-fp32 SGEMM), not a dependency of the product: it is dlopen-ed the
-// first time that path is asked for, so libcffm_hip.so loads (and the default split-bf16 MFMA path runs) on a box without it.
-#include <dlfcn.h>
-namespace rb {
-typedef void* handle_t;
-enum { op_none = 111, op_transpose = 112 };          // rocblas_operation_none / _transpose
-enum { pointer_mode_host = 0 };
-typedef int (*create_t)(handle_t*);
-typedef int (*set_stream_t)(handle_t, hipStream_t);
-typedef int (*set_pm_t)(handle_t, int);
-typedef int (*sgemm_t)(handle_t, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
-static handle_t h = nullptr;
-static set_stream_t set_stream = nullptr;
-static sgemm_t sgemm = nullptr;
-static int state = 0;   // 0 untried, 1 ready, -1 unavailable
-static int load() {
-    if (state) return state;
-    state = -1;
-    void* so = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!so) so = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
-    if (!so) so = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!so) return state;
-    create_t create = (create_t)dlsym(so, "rocblas_create_handle");
-    set_pm_t set_pm = (set_pm_t)dlsym(so, "rocblas_set_pointer_mode");
-    set_stream = (set_stream_t)dlsym(so, "rocblas_set_stream");
-    sgemm = (sgemm_t)dlsym(so, "rocblas_sgemm");
-    if (!create || !set_pm || !set_stream || !sgemm || create(&h) != 0) return state;
-    set_pm(h, pointer_mode_host);
-    return state = 1;
-}
-}  // namespace rb
-static int gemm_ready(hipStream_t st) {
-    if (rb::load() != 1) return -1;
-    return rb::set_stream(rb::h, st) == 0 ? 0 : -1;
-}
-// y[M,N] = x[M,K] w[N,K]^T      (col-major: y^T[N,M] = w_cm^T[N,K] x_cm[K,M])
-static int gemm_nt_lib(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
-    if (gemm_ready(st)) return -1;
-    const float one = 1.f, zero = 0.f;
-    return rb::sgemm(rb::h, rb::op_transpose, rb::op_none, N, (int)M, K, &one, w, K, x, K, &zero, y, N) == 0 ? 0 : -1;
-}
-// dx[M,K] = dy[M,N] w[N,K]      (col-major: dx^T[K,M] = w_cm[K,N] dy_cm[N,M])
-static int gemm_nn_lib(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
-    if (gemm_ready(st)) return -1;
-    const float one = 1.f, zero = 0.f;
-    return rb::sgemm(rb::h, rb::op_none, rb::op_none, K, (int)M, N, &one, w, K, dy, N, &zero, dx, K) == 0 ? 0 : -1;
-}
-// dw[N,K] = dy[M,N]^T x[M,K]    (col-major: dw^T[K,N] = x_cm[K,M] dy_cm^T[M,N])
-static int gemm_tn_lib(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
-    if (gemm_ready(st)) return -1;
-    const float one = 1.f, zero = 0.f;
-    return rb::sgemm(rb::h, rb::op_none, rb::op_transpose, K, N, (int)M, &one, x, K, dy, N, &zero, dw, K) == 0 ? 0 : -1;
-}
-#endif
-
-// ---- dispatch: CFFM_GEMM=lib selects the exact-fp32 library path (rocBLAS SGEMM; host loops in the emulator build) --------
-static int gemm_use_lib() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CFFM_GEMM"); v = (e && e[0] == 'l') ? 1 : 0; }
-    return v;
-}
+// ---- the three products of a Linear layer ------------------------------------------------------------------------------
 static int gemm_nt(const float* x, const float* w, float* y, long M, int N, int K, hipStream_t st) {
-    return gemm_use_lib() ? gemm_nt_lib(x, w, y, M, N, K, st) : gemm_nt_split(x, w, y, M, N, K, st);
+    return gemm_nt_split(x, w, y, M, N, K, st);
 }
 static int gemm_nn(const float* dy, const float* w, float* dx, long M, int N, int K, hipStream_t st) {
-    return gemm_use_lib() ? gemm_nn_lib(dy, w, dx, M, N, K, st) : gemm_nn_split(dy, w, dx, M, N, K, st);
+    return gemm_nn_split(dy, w, dx, M, N, K, st);
 }
 static int gemm_tn(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
-    return gemm_use_lib() ? gemm_tn_lib(dy, x, dw, M, N, K, st) : gemm_tn_split<>(dy, x, dw, M, N, K, st);
+    return gemm_tn_split<>(dy, x, dw, M, N, K, st);
 }
 static int gemm_tn_group(const GemmTN* pr, int n, hipStream_t st, const GemmTNPre* pre = nullptr, float* (*scratch_fn)(size_t) = lib_scratch,
                          int target_wgs = 0, void (*after_gemm)(hipStream_t) = nullptr) {
-    if (!gemm_use_lib()) return gemm_tn_group_split(pr, n, st, pre, scratch_fn, target_wgs, after_gemm);
-    if (pre) return -1;
-    for (int p = 0; p < n; ++p)
-        if (gemm_tn_lib(pr[p].dy, pr[p].x, pr[p].dw, pr[p].M, pr[p].N, pr[p].K, st)) return -1;
-    return 0;
+    return gemm_tn_group_split(pr, n, st, pre, scratch_fn, target_wgs, after_gemm);
 }

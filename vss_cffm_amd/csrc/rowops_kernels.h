@@ -442,11 +442,6 @@ __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict_
     }
 }
 
-// y[r][c] += b[c]   (library-GEMM cross-check path of cffm_linear_bias_fwd)
-__global__ void __launch_bounds__(256) k_add_bias_rows(float* __restrict__ y, const float* __restrict__ b, long M, int N) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < M * N) y[e] += b[e % N];
-}
 
 // a += b (f32x4)
 __global__ void __launch_bounds__(256) k_add_inplace(float* __restrict__ a, const float* __restrict__ b, long n4) {
@@ -491,20 +486,6 @@ __global__ void __launch_bounds__(256) k_sum_splits_group(SumGroup G) {
     ((f32x4*)G.out[p])[i] = a + b;
 }
 
-// q|k|v fp32 product -> f16 with the Linear bias and the q scale folded in (only used by the exact-fp32 library GEMM
-// path; the hand-written GEMM does this in its epilogue)
-__global__ void __launch_bounds__(256) k_qkv_to_f16(const float* __restrict__ raw, const float* __restrict__ bias, h16* __restrict__ out,
-                                                     long n4) {
-    typedef h16 h16x4 __attribute__((ext_vector_type(4)));
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-        const int col = (int)((e * 4) % 768);
-        const f32x4 v = ((const f32x4*)raw)[e] + *(const f32x4*)(bias + col);
-        const float sc = col < CFFM_C ? 0.17677669529663687f : 1.f;
-        h16x4 o;
-        for (int k = 0; k < 4; ++k) o[k] = (h16)(v[k] * sc);
-        ((h16x4*)out)[e] = o;
-    }
-}
 
 // --------------------------------------------------------------------------- AdamW over a table of tensor chunks
 // One workgroup per chunk (<= 2048 consecutive elements of one tensor): 7 streams of 4 B per element (p, g, m, v in;

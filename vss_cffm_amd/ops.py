@@ -123,22 +123,6 @@ def block_ws_layout(lib, g):
 block_grad_hook = None
 
 
-_pad_cache = {}
-
-
-def _pad_index(numels, device):
-    """element indices of the alignment gaps in a flat buffer of 4-element-aligned slices (None when there are none)"""
-    key = (numels, str(device))
-    if key not in _pad_cache:
-        idx, off = [], 0
-        for n in numels:
-            padded = (n + 3) // 4 * 4
-            idx.extend(range(off + n, off + padded))
-            off += padded
-        _pad_cache[key] = torch.tensor(idx, dtype=torch.int64, device=device) if idx else None
-    return _pad_cache[key]
-
-
 class _LayerFn(torch.autograd.Function):
     """BasicLayer3d3.forward (cffm_transformer.py:917-927) as one custom op: x [B,T,256,H,W] and the
     26*depth block parameters -> the new target frame [B,256,H,W]."""
@@ -188,12 +172,10 @@ class _LayerFn(torch.autograd.Function):
         # one allocation for every parameter gradient (16-byte aligned slices), returned as views
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]
         # (the <= 12-byte padding gaps between slices travel through the gradient all-reduce with them and must not carry NaN / Inf
-        # bit patterns of recycled memory: only THEY are zeroed -- every gradient is fully written by the library; a zero-fill of
-        # the whole 6.8 MB buffer was a 7 us kernel on the chain in front of the backward)
+        # bit patterns of recycled memory: the library zeroes them inside the backward of the pooling Linears -- the only tensors
+        # with a gap behind them -- see cffm_grad_slices_padded in include/cffm_hip.h; a zero-fill of the whole 6.8 MB buffer was a
+        # 7 us kernel on the chain in front of the backward, an index_fill_ of the gaps still a 4.7 us one)
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)
-        pads = _pad_index(tuple(p.numel() for p in params), dy.device)
-        if pads is not None:
-            flat.index_fill_(0, pads, 0.0)
         grads = [c[:p.numel()].view(p.shape) if c.numel() != p.numel() else c.view(p.shape)
                  for c, p in zip(flat.split(sizes), params)]
         dx = torch.empty(b, 4, 256, h0, w0, dtype=torch.float32, device=dy.device)
@@ -310,10 +292,7 @@ class _LayerFullFn(torch.autograd.Function):
         g = make_geom(lib, b, h0, w0)
         dy = dy.contiguous()
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)       # (only the alignment gaps are zeroed: see _LayerFn.backward)
-        pads = _pad_index(tuple(p.numel() for p in params), dy.device)
-        if pads is not None:
-            flat.index_fill_(0, pads, 0.0)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)       # (the library zeroes the alignment gaps: see _LayerFn.backward)
         grads = [c[:p.numel()].view(p.shape) if c.numel() != p.numel() else c.view(p.shape)
                  for c, p in zip(flat.split(sizes), params)]
         dx = torch.empty(b, 4, 256, h0, w0, dtype=torch.float32, device=dy.device)
@@ -625,10 +604,7 @@ class _LayerRowsFn(torch.autograd.Function):
         g = make_geom(lib, b, h0, w0)
         dy = dy.contiguous()
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)       # (only the alignment gaps are zeroed: see _LayerFn.backward)
-        pads = _pad_index(tuple(p.numel() for p in params), dy.device)
-        if pads is not None:
-            flat.index_fill_(0, pads, 0.0)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)       # (the library zeroes the alignment gaps: see _LayerFn.backward)
         grads = [c[:p.numel()].view(p.shape) for c, p in zip(flat.split(sizes), params)]
         dx = torch.empty(b, 4, h0 * w0, 256, dtype=torch.float32, device=dy.device)
         _lib.check(lib.cffm_layer_backward_rows(C.byref(g), depth, block_structs(params, depth), block_structs(grads, depth), _ptr(x_rows),
