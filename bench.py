@@ -375,7 +375,7 @@ def main():
     # N > 1 (default): the gradient exchange is overlapped with the backward, block by block -- block 1's slice of the flat
     # gradient buffer is all-reduced (asynchronously, on RCCL's stream) while block 0's backward kernels run
     force1 = bool(os.environ.get('CFFM_BENCH_FORCE_DIST'))
-    reducer = V.distributed.BlockwiseReducer(single_rank_too=force1).install() if (multi and not args.ddp) else None
+    reducer = V.distributed.BlockwiseReducer(single_rank_too=force1).install(list(layer.parameters())) if (multi and not args.ddp) else None
 
     def eager_step():
         fwd_bwd()
@@ -413,6 +413,7 @@ def main():
     # nodes), so it is still timed live, inside the timed region.  --eager / --ddp run the same step launch by launch.
     step, use_graph, graph_events, graph_note = eager_step, False, False, None
     nonlocal_note = []          # set by the capture when it took the experimental one-graph-with-collectives form
+    coll_info = {}              # N > 1: what the gradient exchange moves and a probe that times how long the compute stream waits for it
     if not (args.eager or args.ddp):
         def capture(with_events):
             side = torch.cuda.Stream(dev)
@@ -464,6 +465,21 @@ def main():
                 lib.cffm_profile_collect(ms_buf, n_buf)
             red = V.distributed.BlockwiseReducer(single_rank_too=force1)
             upper = lp.flat[lp.per_block:] if DEPTH > 1 else lp.flat
+
+            def replay_step(ev=None):       # the three-graph form: graphs + host-issued all-reduces
+                ga.replay()
+                red.start(DEPTH - 1, upper)
+                if ga2 is not None:
+                    ga2.replay()
+                    red.start(0, lp.block_slice(0))
+                if ev is not None:
+                    ev[0].record()
+                red.finish()              # the compute stream waits here for whatever part of the exchange the backward did not cover
+                if ev is not None:
+                    ev[1].record()
+                gb.replay()
+            coll_info.update(allreduce_bytes_per_step=int(lp.flat.numel() * 4), allreduce_calls_per_step=2 if DEPTH > 1 else 1,
+                             first_call_bytes=int(upper.numel() * 4), probe=replay_step)
             if try_coll:
                 # default at N > 1: the whole step INCLUDING the RCCL all-reduces as ONE graph -- one graph launch
                 # instead of three + two host-issued collectives (~0.06 ms per step with one rank).  A capture that fails on ANY rank
@@ -501,14 +517,6 @@ def main():
                     return g1.replay
                 nonlocal_note.append('three graphs + host-issued all-reduces (the one-graph capture with RCCL inside failed on at least one rank)')
 
-            def replay_step():
-                ga.replay()
-                red.start(DEPTH - 1, upper)
-                if ga2 is not None:
-                    ga2.replay()
-                    red.start(0, lp.block_slice(0))
-                red.finish()
-                gb.replay()
             return replay_step
 
         for with_events in ((True, False) if stage_timing else (False,)):
@@ -647,6 +655,21 @@ def main():
         lib.cffm_side_streams(side_was)
         lib.cffm_profile_collect(ms_buf, n_buf)
         all_ms, all_n = list(ms_buf), list(n_buf)
+    collective = None
+    if multi and coll_info.get('probe') is not None:
+        # how long the compute stream WAITS for the gradient exchange (the part of the all-reduces the backward does not cover): event
+        # pairs around the reducer's finish() in the three-graph form, a few steps after the timed region (whatever form `value` was
+        # measured in -- inside the one-graph form the wait is a graph edge and cannot be bracketed from the host)
+        n_probe = 8
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)]
+        coll_info['probe']()
+        for ev in evs:
+            coll_info['probe'](ev)
+        torch.cuda.synchronize(dev)
+        waits = sorted(a.elapsed_time(b_) for a, b_ in evs)
+        collective = {'allreduce_bytes_per_step': coll_info['allreduce_bytes_per_step'], 'allreduce_calls_per_step': coll_info['allreduce_calls_per_step'],
+                      'first_call_bytes': coll_info['first_call_bytes'], 'capture_form': (nonlocal_note[-1] if nonlocal_note else 'three graphs + host-issued all-reduces'),
+                      'exposed_wait_ms_per_step': round(waits[len(waits) // 2], 4), 'exposed_wait_note': 'median over %d steps of the interval around BlockwiseReducer.finish() in the three-graph form, rank 0' % n_probe}
     with torch.no_grad():
         params_finite = bool(all(torch.isfinite(p).all().item() for p in params_list))
     ranks_in_sync = None
@@ -739,7 +762,7 @@ def main():
                        'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'ranks_in_sync': ranks_in_sync, 'params_finite': params_finite, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else (nonlocal_note[-1] if nonlocal_note else 'graph(forward + backward of block 1) | all-reduce(block 1) overlapping graph(backward of block 0) | all-reduce(block 0) | graph(AdamW)')),
                        'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one asynchronous all-reduce per block of the flat gradient buffer, overlapped with the backward of the next block') if multi else 'none'},
             'roofline': roof, 'roofline_kernels': rk, 'head_step': hs,
-            'rccl': {'world': world, 'backend': (dist.get_backend() if multi else None)},
+            'rccl': {'world': world, 'backend': (dist.get_backend() if multi else None)}, 'collective': collective,
             'tolerance': {'forward': 5e-4, 'gradients': 2e-3, 'contract': 1e-3,
                           'note': 'max|a-b|/max|b| vs the reference (tests/test_gpu_parity.py): forward measured 1.3-1.6e-4; gradients '
                                   'measured <= 1.1e-3 (f16 operands of dS/dP in the attention backward), gated at 2e-3'},

@@ -356,10 +356,12 @@ int cffm_adamw_step_dev(const cffm_adamw_chunk* chunks /* device */, int nchunks
  * `pos_block` decay_mult 0: local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:35-39 -- makes several): a chunk names the
  * ROW of the hyper-parameter tables it is updated with.  Device tables, `nrows` rows each:
  *   consts [nrows][12] double: beta1, beta2, eps, schedule kind, max_iters, power, min_lr, warmup_iters, warmup_ratio, first
- *                              iteration, (2 unused).  kind 0: lr_t = sched's lr.  kind 1: the reference's schedule evaluated ON THE
- *                              DEVICE from the step count t (mmcv poly decay + linear warm-up, cffm.b1...160k.py:41-45):
- *                              it = t - 1 - first; lr_t = (lr - min_lr) (1 - it/max_iters)^power + min_lr, times
- *                              1 - (1 - it/warmup_iters)(1 - warmup_ratio) while it < warmup_iters; 0 for it < 0
+ *                              iteration, GLOBAL iteration (slot 10: how many steps the optimizer has taken -- the call ADVANCES it
+ *                              for every row, whether or not the row owns a chunk), (1 unused).  kind 0: lr_t = sched's lr.  kind 1:
+ *                              the reference's schedule evaluated ON THE DEVICE (mmcv poly decay + linear warm-up,
+ *                              cffm.b1...160k.py:41-45) from the global iteration, as mmcv derives every group's rate from the
+ *                              runner's iteration: it = global - first; lr_t = (lr - min_lr) (1 - it/max_iters)^power + min_lr,
+ *                              times 1 - (1 - it/warmup_iters)(1 - warmup_ratio) while it < warmup_iters; 0 for it < 0
  *   sched  [nrows][2] float : (base) lr, weight_decay                -- refreshed by the caller; vss_cffm_amd.optim copies it
  *                              from a pinned host mirror INSIDE the captured step, so graph replays see the current values
  *                              (the caller must order mirror writes against replays in flight; kind 1 needs no writes)
@@ -380,7 +382,7 @@ typedef struct {
  * launch (one kernel; the workgroup that finishes last stores the new state) -- same results as the two-launch form used without.
  * sched is read by the device when the launch runs: it may be device memory or pinned, device-visible host memory. */
 int cffm_adamw_step_rows(const cffm_adamw_chunk2* chunks /* device */, int nchunks, const float* grad_base, float* state,
-                         const float* sched, const double* consts, int nrows, const int* active_rows, int* ticket, void* stream);
+                         const float* sched, double* consts, int nrows, const int* active_rows, int* ticket, void* stream);
 
 #ifdef __cplusplus
 }

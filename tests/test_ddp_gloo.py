@@ -216,16 +216,32 @@ def _worker_blockwise_preexisting(rank, world, port, out):
         V.distributed.broadcast_parameters(m, 0)
         for p in m.parameters():
             p.grad = torch.zeros_like(p)            # what optimizer.zero_grad(set_to_none=False) leaves behind
+        # (a) the reducer does not know the parameters until finish(): it exchanges the slices, finish(params) notices that they are
+        #     not the gradients -- raising by default, exchanging the real ones on request
         red = V.distributed.BlockwiseReducer().install()
         try:
             x, g = _clip(rank)
             (m(x)[:, -1] * g).sum().backward()
             params = list(m.parameters())
             with pytest.raises(RuntimeError):
-                V.distributed.BlockwiseReducer.finish(_Replay(red), params, on_mismatch='raise')
-            assert red.finish(params) == 1 and red.fallbacks == 1
+                V.distributed.BlockwiseReducer.finish(_Replay(red), params)
+            assert red.finish(params, on_mismatch='fallback') == 1 and red.fallbacks == 1
         finally:
             red.remove()
+        mine = {k: p.grad.clone() for k, p in m.named_parameters()}
+        # (b) installed WITH the parameters it sees the pre-existing gradients at the first block: no slice is exchanged
+        #     (no all-reduce racing with autograd's accumulation), finish() exchanges the accumulated gradients once
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+        red = V.distributed.BlockwiseReducer().install(m.parameters())
+        try:
+            (m(x)[:, -1] * g).sum().backward()
+            assert red.accumulating and not red.pending
+            assert red.finish() == 0 and red.fallbacks == 1 and not red.accumulating
+        finally:
+            red.remove()
+        for k, p in m.named_parameters():
+            assert torch.allclose(p.grad, mine[k], rtol=1e-5, atol=1e-7 * float(mine[k].abs().max())), k
     torch.save({k: p.grad.clone() for k, p in m.named_parameters()}, os.path.join(out, 'pgrad%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -235,7 +251,7 @@ class _Replay:
     """a reducer whose pending list is a copy: lets the 'raise' policy be exercised without consuming the real exchanges"""
 
     def __init__(self, red):
-        self.pending, self.average = list(red.pending), red.average
+        self.pending, self.average, self.params, self.accumulating, self.fallbacks = list(red.pending), red.average, None, False, 0
 
     def __setattr__(self, k, v):
         object.__setattr__(self, k, v)

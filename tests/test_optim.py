@@ -264,6 +264,43 @@ def run_adamw_device_schedule(device, graph=False):
         torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-5, atol=2e-6 * float(p.abs().max()))
 
 
+def run_adamw_schedule_follows_the_global_iteration(device):
+    """mmcv's PolyLrUpdaterHook derives every group's rate from the runner's iteration.  A parameter that sits steps out
+    keeps its own step count for the bias correction but must take the rate of the GLOBAL iteration when it takes part again; one
+    that first gets a gradient at iteration 5 (the reference trains with find_unused_parameters=True) joins the schedule there
+    instead of restarting the linear warm-up.  Against torch.optim.AdamW driven with mmcv's rate of the global iteration."""
+    gen = torch.Generator().manual_seed(31)
+    init = [torch.randn(200, generator=gen), torch.randn(90, generator=gen), torch.randn(40, generator=gen)]
+    mine = [torch.nn.Parameter(t.clone().to(device)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    o_mine = V.optim.AdamW([dict(params=mine, lr=5e-3, weight_decay=0.01)])
+    o_ref = torch.optim.AdamW([dict(params=ref, lr=5e-3, weight_decay=0.01)])
+    sch = dict(max_iters=30, power=1.0, min_lr=0.0, warmup_iters=8, warmup_ratio=1e-4)
+    o_mine.set_poly_schedule(**sch)
+    for it in range(12):
+        takes_part = [True, it in (0, 1, 4, 9), it >= 5]          # always | intermittent | late
+        for p, q, on in zip(mine, ref, takes_part):
+            g = torch.randn(p.shape, generator=gen)
+            p.grad, q.grad = (g.to(device), g.double()) if on else (None, None)
+        o_ref.param_groups[0]['lr'] = mmcv_poly_lr(5e-3, it, **sch)
+        o_ref.step()
+        o_mine.step()
+    for p, q in zip(mine, ref):
+        assert float((p.detach().cpu().double() - q.detach()).abs().max()) < 2e-6 * max(1.0, float(q.abs().max()))
+    sd = o_mine.state_dict()['state']
+    assert [int(sd[i]['step']) for i in range(3)] == [12, 4, 7]       # the bias correction stays per parameter
+
+
+def test_adamw_schedule_follows_the_global_iteration_emulated():
+    with emu.active():
+        run_adamw_schedule_follows_the_global_iteration(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_adamw_schedule_follows_the_global_iteration_gpu():
+    run_adamw_schedule_follows_the_global_iteration(torch.device('cuda:0'))
+
+
 def test_adamw_device_side_poly_schedule_emulated():
     with emu.active():
         run_adamw_device_schedule(torch.device('cpu'))

@@ -955,7 +955,7 @@ int cffm_adamw_step_dev(const cffm_adamw_chunk* chunks, int nchunks, const float
 }
 
 int cffm_adamw_step_rows(const cffm_adamw_chunk2* chunks, int nchunks, const float* grad_base, float* state, const float* sched,
-                         const double* consts, int nrows, const int* active_rows, int* ticket, void* stream) {
+                         double* consts, int nrows, const int* active_rows, int* ticket, void* stream) {
     static_assert(sizeof(cffm_adamw_chunk2) == sizeof(AdamwChunk2), "chunk layout");
     if (nchunks <= 0) return 0;
     REQUIRE(chunks && state && sched && consts && nrows >= 1, "adamw_step_rows: null table or no rows");

@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) k_adamw_dev(const AdamwChunk* __restrict_
 
 // Multi-group form (one launch for EVERY parameter group of the optimizer): a chunk names the ROW of the hyper-parameter
 // tables it is updated with.  Per row: consts[ADAMW_NCONST] (double: beta1, beta2, eps, schedule kind, max_iters, power, min_lr,
-// warmup_iters, warmup_ratio, first iteration), sched[2] (float: base lr, weight decay -- a device copy of a pinned host mirror,
+// warmup_iters, warmup_ratio, first iteration, and -- slot 10, the one WRITTEN here -- the optimizer's global iteration count), sched[2] (float: base lr, weight decay -- a device copy of a pinned host mirror,
 // refreshed by a copy that is part of the captured step), state[4] (float: t, lr_t / (1 - b1^t), 1 / sqrt(1 - b2^t),
 // 1 - lr_t wd; advanced by k_adamw_tick_rows).  Schedule kind 1 evaluates the reference's learning-rate schedule ON THE DEVICE
 // from the step count (mmcv PolyLrUpdaterHook with linear warm-up: local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:41-45),
@@ -587,8 +587,11 @@ __device__ __forceinline__ void adamw_next_state(const float* __restrict__ state
     const double* c = consts + (long)ADAMW_NCONST * r;
     const double t = (double)state[4 * r] + 1.0, wd = (double)sched[2 * r + 1];
     double lr = (double)sched[2 * r];
-    if (c[3] == 1.0) {                      // poly decay with linear warm-up, iteration it = t - 1 - first
-        const double it = t - 1.0 - c[9], max_iters = c[4], min_lr = c[6], wi = c[7];
+    if (c[3] == 1.0) {                      // poly decay with linear warm-up.  The iteration is the OPTIMIZER's (c[10]: steps taken so far,
+                                            // advanced for every row on every step), not the row's own count t: mmcv derives every group's rate
+                                            // from the runner's iteration, so a parameter that sits steps out, or first gets a gradient late
+                                            // (find_unused_parameters=True), neither lags behind nor restarts the warm-up
+        const double it = c[10] - c[9], max_iters = c[4], min_lr = c[6], wi = c[7];
         const double frac = it < max_iters ? 1.0 - it / max_iters : 0.0;
         lr = (lr - min_lr) * (c[5] == 1.0 ? frac : pow(frac, c[5])) + min_lr;
         if (it < wi) lr *= 1.0 - (1.0 - it / wi) * (1.0 - c[8]);
@@ -599,13 +602,16 @@ __device__ __forceinline__ void adamw_next_state(const float* __restrict__ state
     out[2] = (float)(1.0 / sqrt(1.0 - adamw_ipow(c[1], t)));
     out[3] = (float)(1.0 - lr * wd);
 }
-__global__ void k_adamw_tick_rows(float* __restrict__ state, const float* __restrict__ sched, const double* __restrict__ consts, int nrows,
+__global__ void k_adamw_tick_rows(float* __restrict__ state, const float* __restrict__ sched, double* __restrict__ consts, int nrows,
                                   const int* __restrict__ active) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows || (active && !active[r])) return;
-    float o[4];
-    adamw_next_state(state, sched, consts, r, o);
-    state[4 * r] = o[0]; state[4 * r + 1] = o[1]; state[4 * r + 2] = o[2]; state[4 * r + 3] = o[3];
+    if (r >= nrows) return;
+    if (!active || active[r]) {
+        float o[4];
+        adamw_next_state(state, sched, consts, r, o);
+        state[4 * r] = o[0]; state[4 * r + 1] = o[1]; state[4 * r + 2] = o[2]; state[4 * r + 3] = o[3];
+    }
+    consts[ADAMW_NCONST * r + 10] += 1.0;        // the global iteration: every row, active or not
 }
 // one element of the update; no FMA contraction, so that every caller rounds the same way whatever the surrounding code looks like
 // (the prefetching form of k_adamw_rows_tick and the loop below must agree bit for bit)
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(256) k_adamw_rows(const AdamwChunk2* __restric
 // the active rows; the tickets are back at zero for the next launch.
 __global__ void __launch_bounds__(256) k_adamw_rows_tick(const AdamwChunk2* __restrict__ chunks, const float* __restrict__ grad_base,
                                                           float* __restrict__ state, const float* __restrict__ sched,
-                                                          const double* __restrict__ consts, int nrows, const int* __restrict__ active,
+                                                          double* __restrict__ consts, int nrows, const int* __restrict__ active,
                                                           int* __restrict__ ticket) {
     __shared__ float sc[4];
     __shared__ int last;
@@ -704,10 +710,12 @@ __global__ void __launch_bounds__(256) k_adamw_rows_tick(const AdamwChunk2* __re
     __syncthreads();
     if (!last) return;
     for (int r = threadIdx.x; r < nrows; r += 256) {
-        if (active && !active[r]) continue;
-        float o[4];
-        adamw_next_state(state, sched, consts, r, o);
-        state[4 * r] = o[0]; state[4 * r + 1] = o[1]; state[4 * r + 2] = o[2]; state[4 * r + 3] = o[3];
+        if (!active || active[r]) {
+            float o[4];
+            adamw_next_state(state, sched, consts, r, o);
+            state[4 * r] = o[0]; state[4 * r + 1] = o[1]; state[4 * r + 2] = o[2]; state[4 * r + 3] = o[3];
+        }
+        consts[ADAMW_NCONST * r + 10] += 1.0;    // the global iteration: every row, active or not
     }
     if (threadIdx.x == 0) *ticket = 0;
 }

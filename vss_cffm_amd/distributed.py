@@ -95,17 +95,26 @@ class BlockwiseReducer:
     per-parameter hooks or bucket copies.  ``finish()`` (before the optimizer step) makes the compute stream wait for every
     pending exchange and divides by the world size where the backend has no averaging reduction.
 
-        red = BlockwiseReducer(); red.install()
+        red = BlockwiseReducer(); red.install(layer.parameters())
         loss.backward(); red.finish(); optimizer.step()
     """
 
-    def __init__(self, average=True, on_block=None, single_rank_too=False):
+    def __init__(self, average=True, on_block=None, single_rank_too=False, params=None):
         # single_rank_too: issue the collectives even in a one-rank group (exercises RCCL itself on a one-GPU box)
+        # params: the parameters whose gradients the layer's backward produces (see install)
         self.average, self.on_block, self.single_rank_too = average, on_block, single_rank_too
+        self.params = list(params) if params is not None else None
         self.pending, self.log = [], []
+        self.accumulating = False      # this backward adds into pre-existing .grad tensors: nothing is exchanged block by block
+        self.fallbacks = 0
 
-    def install(self):
+    def install(self, params=None):
+        """``params``: the layer's parameters.  With them the reducer notices by itself -- at the first block of every backward --
+        that ``.grad`` tensors already exist (``zero_grad(set_to_none=False)``, gradient accumulation), and ``finish()`` always checks
+        that what was exchanged really is the parameters' gradients (the check used to be opt-in)."""
         from . import ops
+        if params is not None:
+            self.params = list(params)
         ops.block_grad_hook = self._hook
         return self
 
@@ -125,19 +134,29 @@ class BlockwiseReducer:
             self.on_block(block, flat_slice, depth)
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.single_rank_too):
             return
+        if self.params is not None and not self.pending and not self.accumulating:
+            # First block of a backward.  The hook runs INSIDE the layer's autograd node, so .grad still shows the state before this
+            # backward: with gradients already there autograd will ADD the flat views into them once the node returns -- reading
+            # the views on the compute stream while an asynchronous in-place all-reduce of the same memory is under way would even
+            # race.  Nothing is exchanged block by block then; finish() exchanges the real .grad tensors once.
+            self.accumulating = any(p.grad is not None for p in self.params)
+        if self.accumulating:
+            return
         avg = self.average and dist.get_backend() == 'nccl' and hasattr(dist.ReduceOp, 'AVG')
         work = dist.all_reduce(flat_slice, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
         self.pending.append((work, flat_slice, self.average and not avg))
 
-    def finish(self, params=None, on_mismatch='fallback'):
+    def finish(self, params=None, on_mismatch='raise'):
         """Wait (stream-side for RCCL) for every exchange started since the last call; returns how many there were.
 
         The slices that were exchanged are pieces of the backward's own flat buffer.  They ARE the parameters' gradients only when
         autograd adopted them as ``.grad`` -- i.e. when ``.grad`` was None before the backward (``zero_grad(set_to_none=True)``, the
-        torch default).  With pre-existing gradients (``set_to_none=False``, gradient accumulation) autograd ADDS the views into
-        the old ``.grad`` tensors instead, and the averaged buffer is one nobody reads.  Pass the parameters to have that checked:
-        every ``.grad`` must lie inside an exchanged slice; otherwise ``on_mismatch='fallback'`` exchanges the real ``.grad``
-        tensors now (`allreduce_gradients`: correct, not overlapped), ``'raise'`` raises."""
+        torch default).  With the parameters known (``install(params)`` or the argument) this is checked on every call: a backward
+        that found gradients in place exchanged nothing block by block and its real ``.grad`` tensors are exchanged here
+        (`allreduce_gradients`: correct, not overlapped); a ``.grad`` that does not lie inside an exchanged slice although slices were
+        exchanged raises (``on_mismatch='fallback'``: exchange those gradients now instead).  Without parameters nothing can be
+        checked -- pass them."""
+        params = list(params) if params is not None else self.params
         n = len(self.pending)
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         spans = []
@@ -147,13 +166,19 @@ class BlockwiseReducer:
                 t.div_(world)
             spans.append((t.data_ptr(), t.data_ptr() + 4 * t.numel()))
         self.pending = []
+        if self.accumulating:
+            self.accumulating = False
+            self.fallbacks += 1
+            allreduce_gradients([p for p in params if p.grad is not None], average=self.average)
+            return n
         if params is not None and n:
             stray = [p for p in params if p.grad is not None and
                      not any(lo <= p.grad.data_ptr() and p.grad.data_ptr() + 4 * p.grad.numel() <= hi for lo, hi in spans)]
             if stray:
                 if on_mismatch == 'raise':
                     raise RuntimeError('BlockwiseReducer: %d gradients do not alias the exchanged buffer (the parameters had .grad set '
-                                       'before the backward: use zero_grad(set_to_none=True))' % len(stray))
-                self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+                                       'before the backward: use zero_grad(set_to_none=True), or install(params) so that the reducer '
+                                       'sees it coming)' % len(stray))
+                self.fallbacks += 1
                 allreduce_gradients(stray, average=self.average)
         return n

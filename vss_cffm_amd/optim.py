@@ -53,6 +53,7 @@ class _DeviceRows:
         self.schedule = None      # device-side schedule fields (consts[3:10]) given to rows made later
         self.inflight = []        # pinned staging buffers of eager-mode `sched` copies that may still be queued
         self.members = {}         # row -> ids of the parameters updated with it
+        self.gstep = 0            # host mirror of the global iteration count (consts[:, 10]; the device's runs ahead after graph replays)
         self.ticket = torch.zeros(65, dtype=torch.int32, device=device)   # workgroup tickets of the fused tick + update launch (CFFM_ADAMW_TICKETS)
 
     def row_for(self, gi, step, group):
@@ -72,10 +73,8 @@ class _DeviceRows:
             state[:n - 1] = old_state.cpu()
         consts[n - 1, 0], consts[n - 1, 1], consts[n - 1, 2] = b1, b2, group['eps']
         if self.schedule is not None:
-            sched = list(self.schedule)
-            if sched[6] is None:              # "iteration 0 = the next step of the row": resolved now that the row exists
-                sched[6] = float(step)
-            consts[n - 1, 3:10] = torch.tensor(sched, dtype=torch.float64)
+            consts[n - 1, 3:10] = torch.tensor(list(self.schedule), dtype=torch.float64)
+        consts[n - 1, 10] = float(self.gstep)     # the optimizer's iteration, not the row's: a row made late joins the schedule where it is
         state[n - 1, 0] = float(step)
         self.consts, self.state = consts.to(dev), state.to(dev)
         self.sched = torch.zeros(n, 2, dtype=torch.float32, device=dev)
@@ -104,6 +103,7 @@ class _DeviceRows:
             t = self.state[:, 0].cpu()
             for r in range(len(self.rows)):
                 self.rows[r][1] = int(round(float(t[r])))
+            self.gstep = int(round(float(self.consts[0, 10].item())))
 
 
 class AdamW(torch.optim.Optimizer):
@@ -223,21 +223,23 @@ class AdamW(torch.optim.Optimizer):
         local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:41-45) from the device-side step count: with iteration
         ``it = step - first_step``, ``lr = (base - min_lr) (1 - it / max_iters)^power + min_lr``, scaled by
         ``1 - (1 - it / warmup_iters)(1 - warmup_ratio)`` during warm-up; ``param_groups[i]['lr']`` is then the BASE rate.
-        Replayed HIP graphs follow the schedule with no host write at all.  ``first_step``: the step count at which iteration 0
-        happens (default: the next step of every row).  ``set_poly_schedule(None)`` goes back to host-provided rates.
+        Replayed HIP graphs follow the schedule with no host write at all.  ``first_step``: the global step count at which iteration 0
+        happens (default: the optimizer's next step).  ``set_poly_schedule(None)`` goes back to host-provided rates.
         Rows must exist (take one step first) -- or call it before the first step and it applies to the rows as they are made."""
         kind = 0.0 if max_iters is None else 1.0
+        gstep = 0
         for dr in self._devs.values():
             dr.sync_host()
+            gstep = max(gstep, dr.gstep)
+        first = float(gstep if first_step is None else first_step)       # resolved NOW, to the optimizer's global step (ADVICE r3)
+        for dr in self._devs.values():
             if dr.consts is None:
                 continue
             c = dr.consts.cpu()
             for r in range(len(dr.rows)):
-                first = float(dr.rows[r][1] if first_step is None else first_step)
                 c[r, 3:10] = torch.tensor([kind, float(max_iters or 0), power, min_lr, float(warmup_iters), warmup_ratio, first], dtype=torch.float64)
             dr.consts.copy_(c)
-        self._pending_schedule = None if max_iters is None else (kind, float(max_iters), power, min_lr, float(warmup_iters), warmup_ratio,
-                                                                 None if first_step is None else float(first_step))
+        self._pending_schedule = None if max_iters is None else (kind, float(max_iters), power, min_lr, float(warmup_iters), warmup_ratio, first)
         for dr in self._devs.values():
             dr.schedule = self._pending_schedule
 
@@ -287,6 +289,7 @@ class AdamW(torch.optim.Optimizer):
                 self.state[p]['step'] += 1
             for r in set(rows):
                 dr.rows[r][1] += 1
+            dr.gstep += 1
             self.refresh_hyper()
             capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
             now = dr.sched_host.clone() if not capturing else None
