@@ -189,6 +189,57 @@ def test_head_config4_512x512_batch2_against_reference_golden_gpu():
     run_head_b1_480_golden(torch.device('cuda:0'), 'head_b1_512_b2', G.SIZE_C4, G.BATCH_C4, G.STRIDE_C4, G.DFEAT_STRIDE_C4, (80, 81, 82))
 
 
+def run_cffmpp_head_b1_480_golden(device):
+    """BASELINE config 5 at head level and full size (VERDICT r3 missing #3): the CFFM++ head, CFFM-B1 features of 480x480 x 4 frames,
+    8 prototypes from <save_path>/<video>/centers.pt, against what the REFERENCE head produced (tests/golden/headpp_b1_480_k8.npz,
+    make_golden_head_b1.py pp; cffm_head.py:423-535): eval logits, train logits, which parameters train, and the sums of |.| / squares
+    of every trained parameter's gradient under a seeded upstream gradient."""
+    import tempfile
+    from tests.golden.make_golden_head import feature_maps
+    from tests.golden import make_golden_head_b1 as G
+    g = H.load_golden('headpp_b1_480_k8')
+    seeds, tol = (90, 91, 92), 1e-3
+    pp = build_head(RI.head_cfg(kind='CFFMHead_clips_resize1_8_finetune_w_prototype3', in_channels=G.B1, depths=2))
+    assert not pp.load_state_dict(R.synth_state(pp, seed=seeds[0]), strict=False).unexpected_keys
+    pp.dropout.p = pp.dropout3.p = 0.0
+    if device.type == 'cpu':
+        Hd.revert_sync_batchnorm(pp)
+    pp.to(device)
+    feats = [f.to(device) for f in feature_maps(1, 4, G.SIZE, chans=G.B1, seed=seeds[1])]
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, 'vid0'))
+        torch.save(R.synth_input('centers', (1, 8, 256), seed=seeds[2], scale=1.0), os.path.join(tmp, 'vid0', 'centers.pt'))
+        pp.save_path = tmp + '/'
+        metas = [{'filename': tmp + '/data/vid0/origin/0001.jpg'}]
+        pp.eval()
+        with torch.no_grad():
+            y = pp(feats, 1, 4, None, metas)
+        assert H.rel_err(y[..., ::G.STRIDE, ::G.STRIDE].cpu(), g['eval_logits_s4']) < tol
+        np.testing.assert_allclose(_stats(y)[1:3], g['eval_logits_stats'][1:3], rtol=tol)
+        pp.train()
+        out = pp(feats, 1, 4, None, metas)
+        assert tuple(out.shape) == tuple(int(v) for v in g['train_shape'])
+        assert H.rel_err(out.detach()[..., ::G.STRIDE, ::G.STRIDE].cpu(), g['train_logits_s4']) < tol
+        np.testing.assert_allclose(_stats(out)[1:3], g['train_logits_stats'][1:3], rtol=tol)
+        wgt = torch.as_tensor(np.random.RandomState(seeds[2]).randn(*out.shape[-3:]).astype(np.float32)).to(device)
+        (out * wgt).sum().backward()
+    trained = {n: p for n, p in pp.named_parameters() if p.grad is not None}
+    assert sorted({n.split('.')[0] for n in trained}) == [str(v) for v in g['trained']]
+    worst = ('', 0.0)
+    for n, p in trained.items():
+        want, got = g['pg/' + n], _stats(p.grad)
+        for k in (1, 2):                                       # sum |g|, sum g^2
+            e = abs(got[k] - want[k]) / want[k]
+            worst = max(worst, (n, e), key=lambda t: t[1])
+            assert e < 5e-3, (n, k, e)
+    print('CFFM++ B1 480 K=8: worst gradient statistic', worst)
+
+
+@pytest.mark.gpu
+def test_cffmpp_head_b1_480_k8_against_reference_golden_gpu():
+    run_cffmpp_head_b1_480_golden(torch.device('cuda:0'))
+
+
 def test_head_against_reference_golden_emulated():
     with emu.active():
         run_head_golden(torch.device('cpu'))

@@ -13,7 +13,10 @@ from tests import emu, helpers as H
 from vss_cffm_amd import _lib, geometry, ops
 
 FWD_TOL = 5e-4   # f16 MFMA operands, f32 accumulate (SURVEY.md 8d tolerance ladder)
-BWD_TOL = 2e-3
+# Gradients: the contract's 1e-3 is stated for outputs; what bounds the gradients is the f16 STORAGE of q, k, v and of the position bias that
+# the forward's MFMA operands need -- each of the four moves the worst parameter gradient by 4-5e-4 of its maximum on the goldens, 8.5e-4
+# together, before any arithmetic of the backward (oracle with straight-through f16 rounding: DESIGN.md section 3); measured worst 1.14e-3.
+BWD_TOL = 1.5e-3
 
 
 def P(t):

@@ -13,7 +13,7 @@ from oracle import cffm_oracle as O, recipe as R
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
-FWD_TOL, BWD_TOL = 5e-4, 2e-3
+FWD_TOL, BWD_TOL = 5e-4, 1.5e-3     # (gradients: see tests/test_emu_kernels.py -- the floor set by the f16 storage of q, k, v, bias is 8.5e-4)
 
 
 def dev():

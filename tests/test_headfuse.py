@@ -73,7 +73,8 @@ def run_bn_relu_pool(device, n=2, h=6, w=10):
     #  in one implementation and off in the other; each such element moves its own gradient by a whole term.  At most 8 of them.)
     dgrad = (ya.grad.cpu() - yb.grad).abs()
     assert int((dgrad > 2e-5 * float(yb.grad.abs().max())).sum()) <= 8, float(dgrad.max())
-    assert H.rel_err(bn.weight.grad.cpu(), ref.weight.grad) < 1e-4 and H.rel_err(bn.bias.grad.cpu(), ref.bias.grad) < 1e-4
+    # (the same handful of elements enters the per-channel sums with whole terms)
+    assert H.rel_err(bn.weight.grad.cpu(), ref.weight.grad) < 2e-3 and H.rel_err(bn.bias.grad.cpu(), ref.bias.grad) < 2e-3
     with pytest.raises(_lib.CffmError):
         ops.bn_relu_pool(ya, bn, drop_mask=torch.ones(n, 255, device=device))
     # only one of the two outputs used downstream; stack not requested

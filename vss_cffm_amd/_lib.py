@@ -131,8 +131,6 @@ def bind(path):
         fn.restype, fn.argtypes = res, args
     if lib.cffm_abi_version() != ABI_VERSION:
         raise CffmError('%s: ABI version %d, expected %d' % (path, lib.cffm_abi_version(), ABI_VERSION))
-    # vss_cffm_amd.ops keeps every gradient in a 16-byte-aligned slice of one flat buffer: the library zeroes the padding (include/cffm_hip.h)
-    lib.cffm_grad_slices_padded(1)
     return lib
 
 

@@ -753,7 +753,7 @@ static int attn_bwd_fused(const cffm_geom* g, const void* qkv16, const int* key_
 static int attn_bwd_bias_sum(const float* dbp, int ng, float* dbiasT, void* stream) {
     PROF2(ST_ATTN_BWD_KV);
     const long nb = (long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD;
-    CFFM_LAUNCH(k_sum_splits, ((unsigned)((nb / 4 + 255) / 256)), (256), 0, (hipStream_t)stream, dbp, ng, nb, dbiasT);
+    CFFM_LAUNCH(k_sum_splits, ((unsigned)((nb / 4 + 63) / 64)), (256), 0, (hipStream_t)stream, dbp, ng, nb, dbiasT);
     CHECK_LAUNCH("attn_bwd bias sum");
     return 0;
 }

@@ -55,7 +55,7 @@ static int gemm_split_launch(const float* A, const float* B, float* C, int M, in
 #undef GEMM_GO
     if (ksplit > 1) {
         const long n4 = split_stride / 4;
-        CFFM_LAUNCH(k_sum_splits, ((unsigned)((n4 + 255) / 256)), (256), 0, st, (const float*)out, ksplit, split_stride, C);
+        CFFM_LAUNCH(k_sum_splits, ((unsigned)((n4 + 63) / 64)), (256), 0, st, (const float*)out, ksplit, split_stride, C);
     }
     return 0;
 }

@@ -5,6 +5,7 @@ the hot path happens inside libcffm_hip.so.  Tensors must be fp32, contiguous an
 tensor raises (there is no CPU fallback -- the reference's CPU path is the oracle under oracle/,
 which this package never imports).
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -62,6 +63,24 @@ def _require_int64(t, what):
 
 
 _geom_cache = {}
+
+
+@contextlib.contextmanager
+def _padded_grad_slices(lib):
+    """The gradients handed to the library inside this block are 16-byte-aligned slices of ONE flat buffer: the library zeroes the
+    padding behind the odd-sized ones itself (include/cffm_hip.h cffm_grad_slices_padded).  Switched on only around these calls: a
+    caller of the C ABI with gradient tensors of their own (tests/test_emu_kernels.py block API) must not have 3 floats written
+    behind them."""
+    lib.cffm_grad_slices_padded(1)
+    try:
+        yield
+    finally:
+        lib.cffm_grad_slices_padded(0)
+
+
+def _checked_padded(lib, fn, *args):
+    with _padded_grad_slices(lib):
+        _lib.check(fn(*args), lib)
 
 
 def make_geom(lib, b, h0, w0):
@@ -183,18 +202,18 @@ class _LayerFn(torch.autograd.Function):
         gstructs = block_structs(grads, depth)
         hook = block_grad_hook
         if hook is None:
-            _lib.check(lib.cffm_layer_backward(C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx), _ptr(key_src),
+            _checked_padded(lib, lib.cffm_layer_backward, C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx), _ptr(key_src),
                                                _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch),
-                                               _stream(dy)), lib)
+                                               _stream(dy))
         else:
             # block by block (last block first, as the chain runs): once a block's kernels are enqueued its slice of the
             # flat gradient buffer is handed to the hook -- data-parallel training starts that block's all-reduce there,
             # overlapping it with the backward of the blocks still to come (vss_cffm_amd.distributed.BlockwiseReducer)
             per = sum(sizes[:NPB])
             for i in range(depth - 1, -1, -1):
-                _lib.check(lib.cffm_layer_backward_range(C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx),
+                _checked_padded(lib, lib.cffm_layer_backward_range, C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx),
                                                          _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved),
-                                                         _ptr(ctx.scratch), i, i, _stream(dy)), lib)
+                                                         _ptr(ctx.scratch), i, i, _stream(dy))
                 hook(i, flat[i * per:(i + 1) * per], depth)
         return (dx, None) + tuple(grads)
 
@@ -245,10 +264,10 @@ class LayerPieces:
         if not (dy.dim() == 4 and dy.stride()[1:] == (h0 * w0, w0, 1) and (b == 1 or dy.stride(0) >= img)):
             raise _lib.CffmError('LayerPieces.backward: dy must be dense inside a clip')
         dy_bs = dy.stride(0) if b > 1 else img
-        _lib.check(self.lib.cffm_layer_backward_range(C.byref(self.g), self.depth, self.pstructs, self.gstructs, _ptr(dy), dy_bs,
+        _checked_padded(self.lib, self.lib.cffm_layer_backward_range, C.byref(self.g), self.depth, self.pstructs, self.gstructs, _ptr(dy), dy_bs,
                                                       _ptr(self.dx), _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx),
                                                       _ptr(self.saved), _ptr(self.scratch), first_block, last_block,
-                                                      _stream(self.x)), self.lib)
+                                                      _stream(self.x))
 
 
 class _LayerFullFn(torch.autograd.Function):
@@ -300,9 +319,9 @@ class _LayerFullFn(torch.autograd.Function):
         hook = block_grad_hook
         per = sum(sizes[:NPB])
         for first, last in ([(depth - 1, 0)] if hook is None else [(i, i) for i in range(depth - 1, -1, -1)]):
-            _lib.check(lib.cffm_layer_backward_full(C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst),
+            _checked_padded(lib, lib.cffm_layer_backward_full, C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst),
                                                     _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch), first, last,
-                                                    _stream(dy)), lib)
+                                                    _stream(dy))
             if hook is not None:
                 hook(first, flat[first * per:(first + 1) * per], depth)
         return (dx, None) + tuple(grads)
@@ -607,9 +626,9 @@ class _LayerRowsFn(torch.autograd.Function):
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dy.device)       # (the library zeroes the alignment gaps: see _LayerFn.backward)
         grads = [c[:p.numel()].view(p.shape) for c, p in zip(flat.split(sizes), params)]
         dx = torch.empty(b, 4, h0 * w0, 256, dtype=torch.float32, device=dy.device)
-        _lib.check(lib.cffm_layer_backward_rows(C.byref(g), depth, block_structs(params, depth), block_structs(grads, depth), _ptr(x_rows),
+        _checked_padded(lib, lib.cffm_layer_backward_rows, C.byref(g), depth, block_structs(params, depth), block_structs(grads, depth), _ptr(x_rows),
                                                 _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved),
-                                                _ptr(ctx.scratch), _stream(dy)), lib)
+                                                _ptr(ctx.scratch), _stream(dy))
         return (dx, None, None, None) + tuple(grads)
 
 
