@@ -716,11 +716,11 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     return 0;
 }
 
-// window groups of the fused backward: 8 heads x groups <= 2 workgroups per CU on 256 CUs, every group the same length
+// window groups of the fused backward: 8 heads x groups <= one 10-wave workgroup per CU on 256 CUs, every group the same length
 static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
     const int total = g->B * g->nW;
     static int want = -1;   // tuning aid: CFFM_BWD_GROUPS
-    if (want < 0) { const char* e = cffm_tune("CFFM_BWD_GROUPS"); want = e ? atoi(e) : 64; if (want < 1) want = 64; }
+    if (want < 0) { const char* e = cffm_tune("CFFM_BWD_GROUPS"); want = e ? atoi(e) : 32; if (want < 1) want = 32; }
     int ng = total < want ? total : want;
     *per_group = (total + ng - 1) / ng;
     return (total + *per_group - 1) / *per_group;
@@ -739,12 +739,12 @@ static int attn_bwd_fused(const cffm_geom* g, const void* qkv16, const int* key_
 #ifndef CFFM_EMU
     static bool granted = false;
     if (!granted) {
-        REQUIRE(hipFuncSetAttribute((const void*)k_cfm_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_BWD_LDS) == hipSuccess,
+        REQUIRE(hipFuncSetAttribute((const void*)k_cfm_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_BK_LDS) == hipSuccess,
                 "attn_bwd: LDS grant failed");
         granted = true;
     }
 #endif
-    CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (256), ATT_BWD_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias,
+    CFFM_LAUNCH(k_cfm_attn_bwd, (CFFM_HEADS, ng), (ATT_BK_THREADS), ATT_BK_LDS, (hipStream_t)stream, to_geo(g), (const h16*)qkv16, key_src, q_dst, bias,
                 ao, dao, lse, dqkv, dbp, dkv_part, per);
     CHECK_LAUNCH("attn_bwd");
     *dbp_out = dbp; *ng_out = ng;

@@ -56,7 +56,6 @@ __device__ __forceinline__ f32x4 vflag4(const float* vflag, int o) {
 #endif
 }
 #define CFFM_FIRST_POOLED_KEY 181   // keys 0..180 = own window + ring: always present; 181.. = pooled cells (may fall off the grid)
-#define ATT_VROWS (CFFM_NKEY_PAD + 16)   // rows of an image that is read transposed 32 keys at a time: 16 zero rows past key 303
 #define ATT_FWD_LDS (2 * CFFM_NKEY_PAD * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
 // MFMA A-operand fragment of the TRANSPOSED view of a row image `img` (ATT_ROW layout): A[i = column c0 + (lane & 15)]
 // [k-slots 8 (lane >> 4) + j] = img[row r0 + 4 (lane >> 4) + j (+16 for j >= 4)][that column] -- the k-slot <-> row map of the
@@ -353,115 +352,220 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
 }
 
 // =====================================================================================================
-// Fused backward (round 2): ONE kernel does what k_cfm_attn_bwd_q + k_cfm_attn_bwd_kv did with two stagings, two S / dP
-// recomputations and two exp passes.  grid (8 heads, NG window groups), 256 threads = 4 waves x 16 queries, two workgroups
-// per CU (66 KB of LDS, <= 256 registers).  Per window, the 304 key slots are walked in 10 chunks of 32 keys:
-//   query-owner half (S^T orientation: C rows = keys, C columns = queries; a wave owns 16 queries):
-//       S^T = K Q^T + bias (+mask), dP^T = V dO^T, P = 2^(S log2e - LSE log2e), dS = P (dP - D);
-//       the head's bias gradient accumulates in registers over the whole window group (19 x 4 per lane);
-//       dQ^T += K^T dS^T with dS^T straight from the C registers (contraction over keys = C rows);
-//       P and dS (f16) are also written to a [64 queries][32 keys] exchange image in LDS;
-//   key-owner half (after ONE barrier; the exchange image is double-buffered): contraction over QUERIES, which the C layout of
-//       the S^T orientation cannot feed from registers -- the exchange image read back through the LDS transpose read can:
-//       wave (u, which): key tile 2 kt + u, dV^T = dO^T P (which = 0) or dK^T = Q^T dS (which = 1), both operands via
-//       att_tr_frag so that their k-slot <-> query maps agree; the finished 16-key x 32-channel tile goes to the window's
-//       partial rows (k_dkv_gather sums them per token row, deterministic).
-// dO is rescaled per window by a power of two so that every f16 gradient operand sits near 1 (training-size gradients of 1e-6
-// would flush to zero in f16); results are scaled back in f32.
+// Fused backward (round 4: key-split form; rounds 2-3 ran 4 waves x 16 queries in the S^T orientation and exchanged P and dS through
+// LDS per 32-key chunk, 12 barriers per window -- scripts/r03_attn_bwd_chunked/).  grid (8 heads, NG window groups).
+//   * ONE workgroup of 10 waves per CU walks its window group; wave p owns key tiles 2p, 2p+1 of every window (tile 19 does not
+//     exist: wave 9 carries one) against ALL 64 queries, in the S = Q K^T orientation (C rows = queries, C columns = keys, a lane
+//     = one key): P and dS of a tile contract over QUERIES -- dV^T = dO^T P, dK^T = Q^T dS -- straight from the C registers (B operand,
+//     the k-slot <-> query map of att_tr_frag on the Q / dO rows), so P never leaves the registers and the head's bias gradient of
+//     the wave's two tiles accumulates in 32 registers over the whole group;
+//   * only dS crosses LDS, once per window: two [320 keys][32 queries] images (ATT_ROW rows, the lane's 4 queries = 8 bytes) that
+//     the query phase -- after ONE barrier per window -- reads back transposed for dQ^T = K^T dS^T (8 of the waves: one (query tile,
+//     channel half) each, 10 MFMAs);
+//   * K / V / Q rows of window i+1 arrive by LDS-DMA into the other image while window i is multiplied (the table slices that
+//     address them by LDS-DMA a window before that); the dO / O / LSE rows of window i+1 land, fp32 as fetched, in a parking
+//     area during window i's key phase and are converted (window-wide power-of-two scale, D from the rounded values) by two waves
+//     during its query phase.  No staging registers, no VALU staging pass; waits are counted (vmcnt(N)), never vmcnt(0).
+// Two barriers per window instead of twelve, one exp per (query, key) as before.
 // =====================================================================================================
-#define ATT_BWD_XROWS 64
-#define ATT_BWD_LDS ((ATT_VROWS + CFFM_NKEY_PAD + 2 * 64 + 4 * ATT_BWD_XROWS) * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4 + 64 * 4 + 64 * 4 + 16 * 4)
-#ifdef BWD_TIMING   // profiling builds only: shader-clock stamps of wave 0 of workgroups (head 0, group 0 / 7 / 30), first window
+#define ATT_BK_THREADS 640
+#define ATT_BK_IMG (2 * CFFM_NKEY_PAD * ATT_KS_STRIDE)      // halfs of one K | V image
+#define ATT_BK_DSROWS 320                                   // dS image rows: 10 pairs x 32 keys (rows 304.. stay zero)
+#define ATT_BK_TAB (320 + 64)                               // ints of one table buffer: the window's key-table slice, its q_dst slice
+#define ATT_BK_RAW (2 * 64 * CFFM_HD + 64)                  // floats of the parking area: dO rows, O rows, the LSE row
+#define ATT_BK_LDS ((2 * ATT_BK_IMG + 4 * 64 * ATT_KS_STRIDE + 2 * ATT_BK_DSROWS * ATT_KS_STRIDE) * 2 + (ATT_BK_RAW + 2 * CFFM_NKEY_PAD + 4 * 64 + 4 + 8 + 2 * ATT_BK_TAB) * 4)
+#ifndef BK_ABLATE
+#define BK_ABLATE 0   // profiling builds only: 1 no DMA, 2 no key phase, 4 no query phase, 8 no partial-row stores, 16 no exp
+#endif
+#ifdef BWD_TIMING   // profiling builds only: shader-clock stamps of the third window of (head 0, group 0) wave 0 / wave 5 and (head 0, group 13) wave 9
 __device__ long long g_bwd_t[3 * 16];
-#define BWD_STAMP(i) do { if (tid == 0 && blockIdx.x == 0 && wb == wb0 && (grp == 0 || grp == 7 || grp == 30)) g_bwd_t[(grp == 0 ? 0 : grp == 7 ? 1 : 2) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define KS_STAMP(i) do { if (lane == 0 && blockIdx.x == 0 && (wb == wb0 + 2 || (wb == wb0 + 3 && (i) == 0)) && ((grp == 0 && (wave == 0 || wave == 5)) || (grp == 13 && wave == 9))) \
+    g_bwd_t[(grp == 13 ? 2 : wave == 5 ? 1 : 0) * 16 + (wb == wb0 + 3 ? 9 : (i))] = __builtin_readcyclecounter(); } while (0)
 #else
-#define BWD_STAMP(i)
+#define KS_STAMP(i)
 #endif
-#ifndef BWD_ABLATE
-#define BWD_ABLATE 0   // profiling builds only: 1 no key-owner half, 2 no partial-row stores, 4 no exp
+__device__ __forceinline__ void wait_vm0() {   // every outstanding global access of this wave -- LDS-DMA included -- has completed
+#ifndef CFFM_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), gfx9 encoding
 #endif
-__global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
-                                                           const int* __restrict__ q_dst, const h16* __restrict__ biasH,
-                                                           const float* __restrict__ ao, const float* __restrict__ dao,
-                                                           const float* __restrict__ lse_in, float* __restrict__ dqkv,
-                                                           float* __restrict__ dbias_part, float* __restrict__ dkv_part, int per_group) {
+}
+// all but the N youngest global accesses of this wave have completed (gfx9: loads, LDS-DMA and stores share one in-order counter;
+// vmcnt bits [3:0] and [15:14], the other counters left at their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+#ifndef CFFM_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+#endif
+}
+__global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h16* __restrict__ qkv, const int* __restrict__ key_src,
+                                                                     const int* __restrict__ q_dst, const h16* __restrict__ biasH,
+                                                                     const float* __restrict__ ao, const float* __restrict__ dao,
+                                                                     const float* __restrict__ lse_in, float* __restrict__ dqkv,
+                                                                     float* __restrict__ dbias_part, float* __restrict__ dkv_part, int per_group) {
     CFFM_DYN_SMEM(smem);
-    f16* Ks = (f16*)smem;                                   // K rows (+16 zero rows: read transposed 32 keys at a time)
-    f16* Vs = Ks + ATT_VROWS * ATT_KS_STRIDE;
-    f16* Qs = Vs + CFFM_NKEY_PAD * ATT_KS_STRIDE;           // 64 query rows
-    f16* dOs = Qs + 64 * ATT_KS_STRIDE;
-    f16* Xs = dOs + 64 * ATT_KS_STRIDE;                     // exchange images: [buffer 2][P | dS][64 queries][32 keys]
-    float* vflag = (float*)(Xs + 4 * ATT_BWD_XROWS * ATT_KS_STRIDE);
-    float* slse = vflag + CFFM_NKEY_PAD;                    // LSE * log2(e) per query
-    float* sD = slse + 64;                                  // rowsum(dO * O) * sc per query
-    float* smax = sD + 64;
+    f16* img = (f16*)smem;                                   // [2][K rows | V rows]
+    f16* Qs = img + 2 * ATT_BK_IMG;                          // [2][64 query rows]
+    f16* dOs = Qs + 2 * 64 * ATT_KS_STRIDE;                  // [2][64 query rows], dO * sc
+    f16* DS = dOs + 2 * 64 * ATT_KS_STRIDE;                  // [2 query halves][320 key rows][32 queries]
+    float* raw = (float*)(DS + 2 * ATT_BK_DSROWS * ATT_KS_STRIDE);   // the NEXT window's dO [64][32] | O [64][32] | LSE [64], fp32 as fetched
+    float* vfl = raw + ATT_BK_RAW;                           // [2][304] key validity (0 / -inf)
+    float* lse2 = vfl + 2 * CFFM_NKEY_PAD;                   // [2][64] LSE * log2(e)
+    float* sD = lse2 + 128;                                  // [2][64] rowsum(dO_h * O)
+    float* sisc = sD + 128;                                  // [2] 1 / sc of the window
+    float* smax = sisc + 4;                                  // [8] |dO| maxima of the parked rows, one per fetching wave
+    int* tabs = (int*)(smax + 8);                            // [2][key-table slice 320 | q_dst slice 64] of the windows to come
 
     const int h = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
-    const int qcol = 16 * wave + l15;
     const float scale = 0.17677669529663687f;
     const int wb0 = grp * per_group;
     const int wb1 = (wb0 + per_group < G.B * G.nW) ? wb0 + per_group : G.B * G.nW;
-    // the bias tiles and the partial rows go through buffer resources: one 32-bit per-lane offset each, everything else is a
-    // scalar offset (with plain pointers the compiler hoists one 64-bit per-lane address per tile out of the unrolled loops
-    // and spills: 85 registers in the first version of this kernel)
     const buf_t rs_bias = biash_rsrc(biasH);
-    const uint32_t bias_soff = biash_soff(h, wave, 0), bias_voff = biash_voff(lane);
-    const f16x8 sel0 = bias_sel_frag(lane, 0), sel1 = bias_sel_frag(lane, 1);
-    // partial rows as f16 (row = 512 halfs: K | V x 8 heads x 32) in units of the window's power-of-two dO scale, which goes to
-    // part_scale[window][head]: half the bytes of fp32 rows on the way out and in k_dkv_gather
     const buf_t rs_part = buf_make(dkv_part, (uint32_t)((long)G.B * G.nW * CFFM_NKEY_PAD * 512 * 2));
     float* part_scale = dkv_part + (long)G.B * G.nW * CFFM_NKEY_PAD * 256;
-    const buf_t rs_qkv = qkv_rsrc(G, qkv);
-    const buf_t rs_ao = buf_make(ao, (uint32_t)((long)G.B * G.HW * CFFM_C * 4));
-    const buf_t rs_dao = buf_make(dao, (uint32_t)((long)G.B * G.HW * CFFM_C * 4));
-    const int srow = tid >> 2, sc4 = tid & 3;               // staging role: row (query) srow, 16-byte chunk sc4 of Q / 8 channels of dO, O
+    const dma_t dm_qkv = dma_make(qkv, (uint32_t)((long)G.B * G.RC * 768 * 2));
+    const dma_t dm_ao = dma_make(ao, (uint32_t)((long)G.B * G.HW * CFFM_C * 4));
+    const dma_t dm_dao = dma_make(dao, (uint32_t)((long)G.B * G.HW * CFFM_C * 4));
+    const dma_t dm_lse = dma_make(lse_in, (uint32_t)((long)G.B * G.nW * CFFM_HEADS * CFFM_NQ_PAD * 4));
+    const dma_t dm_tab = dma_make(key_src, (uint32_t)(G.nW * CFFM_NKEY_PAD * 4));
+    const dma_t dm_qd = dma_make(q_dst, (uint32_t)(G.nW * CFFM_WA * 4));
+    const int drow = lane >> 2, sc4 = lane & 3;              // K / V / Q DMA role: row of the wave's tile, chunk position
+    const int rrow = 8 * wave + (lane >> 3);                 // dO / O DMA role (waves 0..7): query row, 16-byte chunk lane & 7 of its 128 bytes
+    // per-lane LDS address parts (element offsets; tiles / pairs add multiples of 512)
+    const int lrow = ATT_ROW(l15, g);                        // row-fragment reads: row 16 t + l15, chunk g
+    const int ltr0 = att_tr_lane(0, lane), ltr1 = att_tr_lane(16, lane);
+    // transposed reads of the Q / dO rows for the key-owner products with the CHANNELS permuted: the LDS transpose read hands lane i the
+    // column its source lanes address, so letting quad c of a 16-lane group read columns 8 c + 4 mt .. + 3 makes C row 4 g + r of
+    // product mt channel 8 g + 4 mt + r -- a lane then owns 8 CONSECUTIVE channels of its key over mt = 0, 1: one 16-byte store
+    const int ltp0 = ATT_ROW(4 * g + (l15 >> 2), l15 & 3), ltp1 = ltp0 + 4;
+    const int dsw0 = ATT_ROW(l15, (g >> 1)) + 4 * (g & 1), dsw1 = ATT_ROW(l15, 2 + (g >> 1)) + 4 * (g & 1);   // dS image writes
+    const f16x8 sel0 = bias_sel_frag(lane, 0), sel1 = bias_sel_frag(lane, 1);
 
-    f32x4 dB[19];
+    // the wave's bias fragments: pair `wave` for the four query tiles (A operands: rows = queries)
+    f16x8 bT[4];
 #pragma unroll
-    for (int t = 0; t < 19; ++t) dB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tid < 64) {
+    for (int qt = 0; qt < 4; ++qt) bT[qt] = buf_ld_h8(rs_bias, biash_voff(lane), biash_soff(h, qt, wave));
+    f32x4 dB[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) dB[u][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tid < 128) {   // dS rows 304..319 (the missing tile 19) of both halves: zeros, never written again
         f16x8 z8;
         for (int e = 0; e < 8; ++e) z8[e] = (f16)0.f;
-        *(f16x8*)(Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE + 8 * tid) = z8;
+        *(f16x8*)(DS + ((tid >> 6) * ATT_BK_DSROWS + CFFM_NKEY_PAD) * ATT_KS_STRIDE + 8 * (tid & 63)) = z8;
     }
-    KvTab<256> tab;
-    if (wb0 < wb1) kv_tab_load<256>(tab, key_src + (wb0 % G.nW) * CFFM_NKEY_PAD, tid);
 
-    for (int wb = wb0; wb < wb1; ++wb) {
-        const int w = wb % G.nW, b = wb / G.nW;
-        BWD_STAMP(0);
-        // ---- stage: K / V rows (table entries were fetched during the previous window), Q rows, dO / O rows -> D, |dO| maximum
-        KvRegs<256> kv;
-        kv_rows_load<256>(kv, tab, rs_qkv, qkv_soff_k(G, b, h), tid);
-        const int qd = (srow < CFFM_WA) ? q_dst[w * CFFM_WA + srow] : -1;
-        const f16x8 qrow = buf_ld_h8(rs_qkv, srow < CFFM_WA ? (uint32_t)(w * CFFM_WA + srow) * 1536u + 16u * sc4 : BUF_OOB,
-                                     (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
-        const uint32_t po = qd >= 0 ? (uint32_t)qd * (CFFM_C * 4u) + 32u * sc4 : BUF_OOB;
-        const uint32_t ps = (uint32_t)(((long)b * G.HW * CFFM_C + h * CFFM_HD) * 4);
-        f32x4 r0 = buf_ld16(rs_dao, po, ps), r1 = buf_ld16(rs_dao, po, ps + 16);
-        const f32x4 o0 = buf_ld16(rs_ao, po, ps), o1 = buf_ld16(rs_ao, po, ps + 16);
-        if (tid < 64) slse[tid] = lse_in[((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD + tid] * CFFM_LOG2E;
-        if (wb + 1 < wb1) kv_tab_load<256>(tab, key_src + ((wb + 1) % G.nW) * CFFM_NKEY_PAD, tid);   // next window's entries
-        BWD_STAMP(1);
-        kv_store<256>(kv, Ks, Vs, vflag, tid);
-        *(f16x8*)(Qs + ATT_ROW(srow, sc4)) = qrow;
-        BWD_STAMP(2);
-        float amax = 0.f;
+    // what a lane needs of the tables to address its DMAs: the key-table entries of its two K / V rows and the destination pixel of its
+    // dO / O row (-1: padding).  First window: ordinary loads; afterwards the table slices themselves travel by LDS-DMA a window ahead
+    // (tabs), so that the loop holds NO ordinary global load: the compiler, which cannot see the DMAs, would put an s_waitcnt vmcnt(0)
+    // in front of the first use of any load result -- the round trip of every DMA and store in flight (measured: 4 such stalls per
+    // window in the first version of this kernel).
+    struct Ahead { int src[2]; int qd; };
+    auto ahead_load = [&](int wb, Ahead& a) {
+        const int w = wb % G.nW;
+        const int* ksrc = key_src + w * CFFM_NKEY_PAD;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
-        amax = wave_max(amax);
-        if (lane == 0) smax[wave] = amax;
-        __syncthreads();
-        const float am = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        for (int it = 0; it < 2; ++it) {
+            const int i = wave + 10 * it;
+            a.src[it] = i < 19 ? ksrc[16 * i + drow] : -1;
+        }
+        a.qd = (wave < 8 && rrow < CFFM_WA) ? q_dst[w * CFFM_WA + rrow] : -1;
+    };
+    auto ahead_lds = [&](int tb, Ahead& a) {
+        const int* t = tabs + tb * ATT_BK_TAB;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = wave + 10 * it;
+            a.src[it] = i < 19 ? t[16 * i + drow] : -1;
+        }
+        a.qd = (wave < 8 && rrow < CFFM_WA) ? t[320 + rrow] : -1;
+    };
+    // table slices of window wb -> buffer tb: waves 4..8 one 64-entry piece of the key table each (the last one runs 16 entries into the
+    // next window's slice or off the table: never used), wave 9 the q_dst slice
+    auto tab_issue = [&](int wb, int tb) {
+        const int w = wb % G.nW;
+        if (BK_ABLATE & 1) return;
+        if (wave >= 4 && wave < 9) dma_ld4(dm_tab, 4u * (uint32_t)(64 * (wave - 4) + lane), (uint32_t)(w * CFFM_NKEY_PAD * 4), tabs + tb * ATT_BK_TAB + 64 * (wave - 4));
+        else if (wave == 9) dma_ld4(dm_qd, 4u * (uint32_t)lane, (uint32_t)(w * CFFM_WA * 4), tabs + tb * ATT_BK_TAB + 320);
+        sched_fence();
+    };
+    // window wb by LDS-DMA, in two steps so that the fetched entries are turned into offsets (fresh registers) BEFORE the next window's
+    // entries are fetched into the same registers -- a register copy of a load result would cost an s_waitcnt vmcnt(0), i.e. the
+    // round trip of every access in flight.  dma_prep: byte offsets; dma_issue: the key-validity flags, then in this order: dO / O rows
+    // (waves 0..7: 8 rows x 128 bytes each) and the LSE row (wave 8) -> the parking area; K / V tiles wave, wave + 10 and (waves 0..3)
+    // 16 Q rows -> image bi.
+    struct DmaOff { uint32_t kv[2], q, rows; };
+    auto dma_prep = [&](int wb, const Ahead& a, DmaOff& o) {
+        const int w = wb % G.nW;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = wave + 10 * it, row = 16 * i + drow;
+            o.kv[it] = a.src[it] >= 0 ? (uint32_t)a.src[it] * 1536u + 16u * (uint32_t)(sc4 ^ ATT_SWZ(row)) : BUF_OOB;
+        }
+        const int qrow = 16 * wave + drow;
+        o.q = (wave < 4 && qrow < CFFM_WA) ? (uint32_t)(w * CFFM_WA + qrow) * 1536u + 16u * (uint32_t)(sc4 ^ ATT_SWZ(qrow)) : BUF_OOB;
+        o.rows = a.qd >= 0 ? (uint32_t)a.qd * (CFFM_C * 4u) + 16u * (uint32_t)(lane & 7) : BUF_OOB;
+    };
+    // step 1 (top of the window): the key-validity flags, the dO / O / LSE rows
+    auto dma_rows = [&](int wb, const DmaOff& o, int bi) {
+        const int b = wave_uniform(wb / G.nW);   // (the division runs on the vector unit: the scalar offsets below need a scalar)
+        const uint32_t ps = (uint32_t)(((long)b * G.HW * CFFM_C + h * CFFM_HD) * 4);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = wave + 10 * it;
+            if (i < 19 && sc4 == 0) vfl[bi * CFFM_NKEY_PAD + 16 * i + drow] = o.kv[it] != BUF_OOB ? 0.f : -INFINITY;
+        }
+        sched_fence();
+        if (BK_ABLATE & 1) return;
+        if (wave < 8) {
+            dma_ld16(dm_dao, o.rows, ps, raw + 8 * wave * CFFM_HD);
+            dma_ld16(dm_ao, o.rows, ps, raw + 64 * CFFM_HD + 8 * wave * CFFM_HD);
+        } else if (wave == 8) {
+            dma_ld4(dm_lse, 4u * (uint32_t)lane, (uint32_t)((((long)wb * CFFM_HEADS + h) * CFFM_NQ_PAD) * 4), raw + 2 * 64 * CFFM_HD);
+        }
+        sched_fence();
+    };
+    // step 2, piece k = 0..4: K, V of tile wave; K, V of tile wave + 10; (waves 0..3) 16 Q rows.  The pieces go out one at a time between the
+    // chains of the wave's first key tile: all ten waves issuing their five to seven DMAs at once right behind the barrier kept every wave
+    // of the CU in the texture addresser's queue for ~2 k cycles (shader-clock stamps, scripts/r04_ks_timing.py).
+    auto dma_piece = [&](int wb, const DmaOff& o, int bi, int k) {
+        if (BK_ABLATE & 1) return;
+        const int b = wave_uniform(wb / G.nW);
+        const uint32_t soff_k = qkv_soff_k(G, b, h);
+        f16* Ks = img + bi * ATT_BK_IMG;
+        f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+        if (k < 4) {
+            const int it = k >> 1, i = wave + 10 * it;
+            if (i < 19) dma_ld16(dm_qkv, o.kv[it], soff_k + 512 * (k & 1), ((k & 1) ? Vs : Ks) + 16 * i * ATT_KS_STRIDE);
+        } else if (wave < 4) {
+            dma_ld16(dm_qkv, o.q, (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2), Qs + (bi * 64 + 16 * wave) * ATT_KS_STRIDE);
+        }
+    };
+    // |dO| maximum of the 8 rows this wave fetched (they have landed: its own wait) -> smax[wave]
+    auto rows_max = [&]() {
+        const f32x4 r = *(const f32x4*)(raw + 8 * wave * CFFM_HD + 4 * lane);
+        const float am = wave_max(fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+        if (lane == 0) smax[wave] = am;
+    };
+    // parked rows -> dO_h = f16(dO * sc) rows of image bi, D = rowsum(dO_h * O), LSE * log2(e), 1 / sc.  dO is rescaled per window by
+    // a power of two so that every f16 gradient operand sits near 1 (training-size gradients of 1e-6 would flush to zero in f16);
+    // results are scaled back in f32.  D comes from the ROUNDED dO: with dP = dO_h V^T the kernel then sees sum_n P_n (dP_n - D) = 0
+    // exactly, i.e. the exact softmax backward of a dO perturbed by 2^-12 per element; with D from the unrounded dO the rounding error
+    // of dP met an exact D in the cancelling difference dP - D (stage test: 7e-4 of max|dq| against 2.8e-4).  Waves 8 and 9 (the other eight run the query phase): lane l of wave 8 + v owns 8 channels l & 3 of rows 32 v + (l >> 2) + 16 j.
+    auto rows_convert = [&](int wb, int bi) {
+        const f32x4 m0 = *(const f32x4*)(smax), m1 = *(const f32x4*)(smax + 4);
+        const float am = fmaxf(fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3])));
         int ex = 0;
         if (am > 0.f) frexpf(am, &ex);
         const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f, isc = 1.f / sc;   // max|dO * sc| in [1,2) over the window
-        {
-            // D = rowsum(dO * O) from the ROUNDED dO (round 4): with dP = V dO_h^T the kernel then sees sum_n P_n (dP_n - D) = 0 exactly,
-            // i.e. the exact softmax backward of a dO perturbed by 2^-12 per element.  With D from the unrounded dO the rounding error of
-            // dP met an exact D in the cancelling difference dP - D (two-pass experiment, stage test: 7e-4 of max|dq| against 2.8e-4).
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 32 * (wave - 8) + (lane >> 2) + 16 * j, c = lane & 3;
+            const float* p = raw + row * CFFM_HD + 8 * c;
+            const f32x4 r0 = *(const f32x4*)(p), r1 = *(const f32x4*)(p + 4);
+            const f32x4 o0 = *(const f32x4*)(p + 64 * CFFM_HD), o1 = *(const f32x4*)(p + 64 * CFFM_HD + 4);
             f16x8 dh;
             float d = 0.f;
 #pragma unroll
@@ -472,116 +576,162 @@ __global__ void __launch_bounds__(256, 2) k_cfm_attn_bwd(Geo G, const h16* __res
             }
             d += __shfl_xor(d, 1, 64);
             d += __shfl_xor(d, 2, 64);
-            if (sc4 == 0) sD[srow] = d;
-            *(f16x8*)(dOs + ATT_ROW(srow, sc4)) = dh;
+            if (c == 0) sD[bi * 64 + row] = d;
+            *(f16x8*)(dOs + bi * 64 * ATT_KS_STRIDE + ATT_ROW(row, c)) = dh;
         }
+        if (wave == 8) {
+            lse2[bi * 64 + lane] = raw[2 * 64 * CFFM_HD + lane] * CFFM_LOG2E;
+            if (lane == 0) { part_scale[(long)wb * CFFM_HEADS + h] = isc; sisc[bi] = isc; }
+        }
+    };
+
+    if (wb0 < wb1) {
+        Ahead a;
+        DmaOff o;
+        ahead_load(wb0, a);
+        dma_prep(wb0, a, o);
+        dma_rows(wb0, o, 0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dma_piece(wb0, o, 0, k);
+        sched_fence();
+        if (wb0 + 1 < wb1) tab_issue(wb0 + 1, 1);
+        wait_vm0();
+        if (wave < 8) rows_max();
+        // (the bias fragments are complete: say so to the compiler, which otherwise waits for them -- vmcnt(0) -- at their first use
+        // in EVERY window, behind the DMAs issued there)
+#ifndef CFFM_EMU
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) asm volatile("" : "+v"(bT[qt]));
+#endif
         __syncthreads();
-
-        BWD_STAMP(3);
-        const f16x8 qfrag = *(const f16x8*)(Qs + ATT_ROW(qcol, g));
-        const f16x8 dofrag = *(const f16x8*)(dOs + ATT_ROW(qcol, g));
-        const float lq2 = slse[qcol], Dq = sD[qcol];
-        f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-        const int ku = wave & 1, kwhich = wave >> 1;          // key-owner role of this wave
-        const f16* kimg = kwhich ? Qs : dOs;
-        const uint32_t part_voff = (uint32_t)(l15 * 1024 + ((kwhich ? 0 : 256) + h * CFFM_HD + 4 * g) * 2);
-        if (tid == 0) part_scale[(long)wb * CFFM_HEADS + h] = isc;
-
-        // Software pipeline over the 10 chunks: between two barriers a wave runs the key-owner half of chunk kt AND the
-        // query-owner half of chunk kt + 1 -- two independent dependency chains the scheduler interleaves (one chain alone
-        // leaves the wave parked on LDS / MFMA / exp latencies: the first version, one chain per barrier interval, ran at 45 %
-        // issue utilisation).  The bias tiles of a chunk are loaded one interval ahead, BEFORE the previous interval's
-        // partial-row stores (a load older than the stores never waits for them: gfx9's vmcnt counts both, in order).
-        f16x8 cb = buf_ld_h8(rs_bias, bias_voff, bias_soff);             // chunk kt = tile pair kt: one fragment (cfm_attn_kernels.h, bias_sel_frag)
-        f16x8 nb = buf_ld_h8(rs_bias, bias_voff, bias_soff + 1024);
-#define BWD_QHALF(KT)                                                                                                                  \
-        {                                                                                                                               \
-            f16* Px_ = Xs + ((KT) & 1) * 2 * ATT_BWD_XROWS * ATT_KS_STRIDE;                                                             \
-            f16* Sx_ = Px_ + ATT_BWD_XROWS * ATT_KS_STRIDE;                                                                             \
-            f16x4 dsh[2];                                                                                                               \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                             \
-                const int t = 2 * (KT) + u;                                                                                             \
-                if (t < 19) {                                                                                                           \
-                    const f16x8 kf = *(const f16x8*)(Ks + ATT_ROW((16 * t + l15), g));                                                  \
-                    const f16x8 vf = *(const f16x8*)(Vs + ATT_ROW((16 * t + l15), g));                                                  \
-                    const f32x4 c0 = (16 * t + 15 >= CFFM_FIRST_POOLED_KEY) ? vflag4(vflag, 16 * t + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f}; \
-                    const f32x4 sv = mfma16x16x32_f16(kf, qfrag, mfma16x16x32_f16(u ? sel1 : sel0, cb, c0));                             \
-                    const f32x4 dp = mfma16x16x32_f16(vf, dofrag, (f32x4){0.f, 0.f, 0.f, 0.f});                                         \
-                    f32x4 pr, ds;                                                                                                       \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                     \
-                        pr[r] = (BWD_ABLATE & 4) ? fmaf(sv[r], CFFM_LOG2E, -lq2) : fast_exp2(fmaf(sv[r], CFFM_LOG2E, -lq2));            \
-                        ds[r] = pr[r] * (dp[r] - Dq);                                                                                   \
-                    }                                                                                                                   \
-                    dB[t < 19 ? t : 0] += ds * isc;                                                                                     \
-                    dsh[u] = to_f16x4(ds);                                                                                              \
-                    /* exchange images: row = query, 8 bytes = keys 16u + 4g .. +3 of this chunk */                                     \
-                    *(f16x4*)(Px_ + ATT_ROW(qcol, 2 * u + (g >> 1)) + 4 * (g & 1)) = to_f16x4(pr);                                      \
-                    *(f16x4*)(Sx_ + ATT_ROW(qcol, 2 * u + (g >> 1)) + 4 * (g & 1)) = dsh[u];                                            \
-                } else {                                                                                                                \
-                    dsh[u] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};                                                           \
-                }                                                                                                                       \
-            }                                                                                                                           \
-            const f16x8 dsf = cat_f16x4(dsh[0], dsh[1]);                                                                                \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                            \
-                dq[mt] = mfma16x16x32_f16(att_tr_frag(Ks, 32 * (KT), 16 * mt, lane), dsf, dq[mt]);                                      \
+        if (wave >= 8) rows_convert(wb0, 0);
+    }
+    for (int wb = wb0; wb < wb1; ++wb) {
+        const int bi = (wb - wb0) & 1, w = wb % G.nW, b = wb / G.nW;
+        // The K / V / Q DMAs of this window were issued a window ago; the only accesses younger than them are the wave's stores of the
+        // previous window (4 partial-row stores, 2 for wave 9, and at most one more): waiting for those as well would expose their round
+        // trip to HBM at every window.  (Not so for the first window: its DMAs were issued just now.)
+        KS_STAMP(0);
+        if ((BK_ABLATE & 32) || wb == wb0) wait_vm0(); else if (wave == 9) wait_vm<2>(); else wait_vm<4>();
+        KS_STAMP(1);
+        __syncthreads();   // B1: window wb's K / V / Q rows are in image bi, its dO_h rows, D, LSE, 1 / sc are written; image bi ^ 1, the dS
+                           //     images and the parking area are free
+        KS_STAMP(2);
+        const bool more = wb + 1 < wb1;
+        DmaOff o = {{BUF_OOB, BUF_OOB}, BUF_OOB, BUF_OOB};
+        if (more) {   // window wb + 1 (its table slices are in tabs[bi ^ 1]): offsets, flags, the row DMAs; the rest goes out inside the key phase
+            Ahead a;
+            ahead_lds(bi ^ 1, a);
+            dma_prep(wb + 1, a, o);
+            dma_rows(wb + 1, o, bi ^ 1);
         }
-        BWD_QHALF(0)
-        BWD_STAMP(4);
+        KS_STAMP(3);
+        const f16* Ks = img + bi * ATT_BK_IMG;
+        const f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
+        const f16* Q = Qs + bi * 64 * ATT_KS_STRIDE;
+        const f16* dO = dOs + bi * 64 * ATT_KS_STRIDE;
+        const float isc = sisc[bi];
+        // ---- key phase: the wave's two key tiles against all 64 queries
+        if (!(BK_ABLATE & 2)) {
 #pragma unroll
-        for (int kt = 0; kt < 10; ++kt) {
-            const f16* Px = Xs + (kt & 1) * 2 * ATT_BWD_XROWS * ATT_KS_STRIDE;
-            const f16* Sx = Px + ATT_BWD_XROWS * ATT_KS_STRIDE;
-            __syncthreads();   // chunk kt's P / dS images are complete (double-buffered: this buffer is rewritten only after the next barrier)
-            BWD_STAMP(5 + kt);
-            sched_fence();
-            // bias tiles: chunk kt + 1's become current, chunk kt + 2's go in flight
-            cb = nb;
-            if (kt + 2 < 10) nb = buf_ld_h8(rs_bias, bias_voff, bias_soff + 1024 * (kt + 2));
-            // ---- query-owner half of the NEXT chunk (independent of the key-owner half below: interleaved by the scheduler)
-            if (kt + 1 < 10) BWD_QHALF(kt + 1)
-            // ---- key-owner half: wave (ku, kwhich) finishes key tile 2 kt + ku for dV (kwhich 0) or dK (kwhich 1)
-            const int tk = 2 * kt + ku;
-            if (tk < 19 && !(BWD_ABLATE & 1)) {
-                const f16* X = kwhich ? Sx : Px;
-                f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * wave + u;
+                if (t < 19) {
+                    sched_fence();
+                    const f16x8 kf = *(const f16x8*)(Ks + 512 * t + lrow);
+                    const f16x8 vf = *(const f16x8*)(Vs + 512 * t + lrow);
+                    const float mk = t >= 11 ? vfl[bi * CFFM_NKEY_PAD + 16 * t + l15] : 0.f;   // only keys >= 181 can be absent
+                    const f32x4 c0 = (f32x4){mk, mk, mk, mk};
+                    f16x4 ph[4], dsh[4];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 xb = att_tr_frag(X, 32 * ks, 16 * ku, lane);
+                    for (int qt = 0; qt < 4; ++qt) {
+                        if (u == 0 && more) dma_piece(wb + 1, o, bi ^ 1, qt);
+                        const f16x8 qf = *(const f16x8*)(Q + 512 * qt + lrow);
+                        const f16x8 dof = *(const f16x8*)(dO + 512 * qt + lrow);
+                        const f32x4 sv = mfma16x16x32_f16(qf, kf, mfma16x16x32_f16(bT[qt], u ? sel1 : sel0, c0));   // Q K^T + bias + mask
+                        const f32x4 dp = mfma16x16x32_f16(dof, vf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                        const f32x4 lq = *(const f32x4*)(lse2 + bi * 64 + 16 * qt + 4 * g), Dq = *(const f32x4*)(sD + bi * 64 + 16 * qt + 4 * g);
+                        f32x4 pr, ds;
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) acc[dt] = mfma16x16x32_f16(att_tr_frag(kimg, 32 * ks, 16 * dt, lane), xb, acc[dt]);
+                        for (int r = 0; r < 4; ++r) {
+                            pr[r] = (BK_ABLATE & 16) ? fmaf(sv[r], CFFM_LOG2E, -lq[r]) : fast_exp2(fmaf(sv[r], CFFM_LOG2E, -lq[r]));
+                            ds[r] = pr[r] * (dp[r] - Dq[r]);
+                        }
+                        dB[u][qt] += ds * isc;
+                        ph[qt] = to_f16x4(pr);
+                        dsh[qt] = to_f16x4(ds);
+                        // dS image: row = key, 8 bytes = queries 16 qt + 4 g .. + 3
+                        *(f16x4*)(DS + (qt >> 1) * ATT_BK_DSROWS * ATT_KS_STRIDE + 512 * t + ((qt & 1) ? dsw1 : dsw0)) = dsh[qt];
+                    }
+                    if (u == 0 && more) {   // the last pieces: Q rows, the table slices of window wb + 2 -- all DMAs precede the wave's stores
+                        dma_piece(wb + 1, o, bi ^ 1, 4);
+                        if (wb + 2 < wb1) tab_issue(wb + 2, bi);
+                    }
+                    f32x4 aK[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, aV[2] = {aK[0], aK[0]};
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const f16x8 pf = cat_f16x4(ph[2 * a], ph[2 * a + 1]), dsf = cat_f16x4(dsh[2 * a], dsh[2 * a + 1]);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            aV[mt] = mfma16x16x32_f16(att_tr_frag_at(dO + 1024 * a, mt ? ltp1 : ltp0), pf, aV[mt]);
+                            aK[mt] = mfma16x16x32_f16(att_tr_frag_at(Q + 1024 * a, mt ? ltp1 : ltp0), dsf, aK[mt]);
+                        }
+                    }
+                    // tiles [channel 8 g + 4 mt + r][key = l15]: 16 bytes of the key's partial row (8 heads x (K 32 | V 32) halfs) per store,
+                    // a quarter-wave covers the head's whole 64-byte K (V) slice; an absent key's stores go out of range and are dropped
+                    if (!(BK_ABLATE & 8)) {
+                        const uint32_t so = (uint32_t)(((long)wb * CFFM_NKEY_PAD + 16 * t) * 1024);
+                        const uint32_t vo = mk == 0.f ? (uint32_t)(l15 * 1024 + (h * 2 * CFFM_HD + 8 * g) * 2) : BUF_OOB;
+                        buf_st16_pair(rs_part, __builtin_bit_cast(f32x4, cat_f16x4(to_f16x4(aK[0]), to_f16x4(aK[1]))),
+                                      __builtin_bit_cast(f32x4, cat_f16x4(to_f16x4(aV[0]), to_f16x4(aV[1]))), vo, so, so + 64);
+                    }
                 }
-                // tile [d = 16 dt + 4 g + r][key = l15]: every lane owns 16 contiguous bytes of a key row of this window's slot;
-                // present keys only (flag 0, -inf otherwise): an absent key's store goes out of range and is dropped
-                const int key = 16 * tk + l15;
-                if (!(BWD_ABLATE & 2)) {
-                    const uint32_t so = (uint32_t)(((long)wb * CFFM_NKEY_PAD + 16 * tk) * 1024);
-                    const uint32_t vo = vflag[key] == 0.f ? part_voff : BUF_OOB;
-                    buf_st8(rs_part, __builtin_bit_cast(f32x2, to_f16x4(acc[0])), vo, so);
-                    buf_st8(rs_part, __builtin_bit_cast(f32x2, to_f16x4(acc[1])), vo, so + 32);
-                }
+                KS_STAMP(4 + u);
             }
         }
-#undef BWD_QHALF
-        sched_fence();
-        BWD_STAMP(15);
-        if (qcol < CFFM_WA) {
-            float* drow = dqkv + ((long)b * G.RC + w * CFFM_WA + qcol) * 768 + h * CFFM_HD + 4 * g;
-            *(f32x4*)(drow) = dq[0] * (scale * isc);      // d(raw q): the stored q carries the 32^-0.5 factor
-            *(f32x4*)(drow + 16) = dq[1] * (scale * isc);
+        // the next window's dO / O / LSE rows have landed: of this wave's accesses only its K / V DMAs (4), the Q or table DMA and the
+        // partial-row stores (4) are younger than the row DMAs
+        if (more && wave < 9) {
+            if (BK_ABLATE & 32) wait_vm0(); else wait_vm<8>();
+            if (wave < 8) rows_max();
         }
-        __syncthreads();  // LDS is restaged for the next window
+        KS_STAMP(6);
+        __syncthreads();   // B2: the dS images of window wb and the parked rows of window wb + 1 are complete
+        KS_STAMP(7);
+        if (wave >= 8) {
+            if (more) rows_convert(wb + 1, bi ^ 1);
+        } else {
+            // ---- query phase: dQ^T[16 channels mt][16 queries qt] = K^T dS^T over the 10 key pairs
+            if (!(BK_ABLATE & 4)) {
+                const int qt = wave & 3, mt = wave >> 2;
+                const f16* D = DS + (qt >> 1) * ATT_BK_DSROWS * ATT_KS_STRIDE;
+                const int la = mt ? ltr1 : ltr0, lb = (qt & 1) ? ltr1 : ltr0;
+                f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < 10; ++p)
+                    dq = mfma16x16x32_f16(att_tr_frag_at(Ks + 1024 * p, la, p == 9), att_tr_frag_at(D + 1024 * p, lb), dq);
+                const int q = 16 * qt + l15;
+                if (q < CFFM_WA)
+                    *(f32x4*)(dqkv + ((long)b * G.RC + w * CFFM_WA + q) * 768 + h * CFFM_HD + 16 * mt + 4 * g) = dq * (scale * isc);
+            }
+        }
+        KS_STAMP(8);
     }
     // the group's bias gradient: one plain [304 keys][64 queries] tile per (group, head); k_sum_splits adds the groups
-    // (rows of padded queries / keys are exact zeros)
-    float* dst = dbias_part + (((long)grp * CFFM_HEADS + h) * CFFM_NKEY_PAD) * CFFM_NQ_PAD + qcol;
+    const buf_t rs_dbp = buf_make(dbias_part + (((long)grp * CFFM_HEADS + h) * CFFM_NKEY_PAD) * CFFM_NQ_PAD,
+                                  (uint32_t)(CFFM_NKEY_PAD * CFFM_NQ_PAD * 4));
 #pragma unroll
-    for (int t = 0; t < 19; ++t)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(16 * t + 4 * g + r) * CFFM_NQ_PAD] = dB[t][r];
+        for (int qt = 0; qt < 4; qt += 2)
+            if (2 * wave + u < 19) {
+                const uint32_t so = (uint32_t)(((16 * (2 * wave + u)) * CFFM_NQ_PAD + 16 * qt) * 4);
+                buf_st16_pair(rs_dbp, dB[u][qt], dB[u][qt + 1], (uint32_t)((l15 * CFFM_NQ_PAD + 4 * g) * 4), so, so + 64);
+            }
 }
 
 // dqkv[b][row][256..767] = sum over the (window, key slot) pairs that read `row` of the partial rows dkv_part[b*nW + window][slot]
-// (512 halfs each, in units of part_scale[window][head]); inv_ptr [RC+1], inv_idx [nnz] = CSR inverse of key_src (per clip).
+// (512 halfs each: 8 heads x (K 32 | V 32), in units of part_scale[window][head]); inv_ptr [RC+1], inv_idx [nnz] = CSR inverse of key_src (per clip).
 // One wave per token row, a lane owns 8 channels of one head; pooled rows also get their (unused) q third zeroed so the qkv
 // weight/bias gradient GEMMs see zeros there.  grid (ceil(RC/4), B).
 __global__ void __launch_bounds__(256) k_dkv_gather(Geo G, const int* __restrict__ inv_ptr, const int* __restrict__ inv_idx,
@@ -589,8 +739,8 @@ __global__ void __launch_bounds__(256) k_dkv_gather(Geo G, const int* __restrict
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (row >= G.RC) return;
     const int e0 = inv_ptr[row], e1 = inv_ptr[row + 1];
-    const h16* part = (const h16*)dkv_part + (long)b * G.nW * CFFM_NKEY_PAD * 512 + 8 * lane;
-    const float* scl = dkv_part + (long)G.B * G.nW * CFFM_NKEY_PAD * 256 + (long)b * G.nW * CFFM_HEADS + ((lane & 31) >> 2);
+    const h16* part = (const h16*)dkv_part + (long)b * G.nW * CFFM_NKEY_PAD * 512 + 8 * lane;     // partial row: 8 heads x (K 32 | V 32)
+    const float* scl = dkv_part + (long)G.B * G.nW * CFFM_NKEY_PAD * 256 + (long)b * G.nW * CFFM_HEADS + (lane >> 3);
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
     for (int eb = e0; eb < e1; eb += 64) {          // a row has at most 49 readers; the loop is for generality
         const int n = (e1 - eb < 64) ? e1 - eb : 64;
@@ -617,7 +767,8 @@ __global__ void __launch_bounds__(256) k_dkv_gather(Geo G, const int* __restrict
         }
     }
     float* drow = dqkv + ((long)b * G.RC + row) * 768;
-    *(f32x4*)(drow + 256 + 8 * lane) = a0;
-    *(f32x4*)(drow + 256 + 8 * lane + 4) = a1;
+    const int dcol = 256 + 256 * ((lane >> 2) & 1) + CFFM_HD * (lane >> 3) + 8 * (lane & 3);   // lane = (head, K / V, 8 channels)
+    *(f32x4*)(drow + dcol) = a0;
+    *(f32x4*)(drow + dcol + 4) = a1;
     if (row >= CFFM_WA * G.nW) *(f32x4*)(drow + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
