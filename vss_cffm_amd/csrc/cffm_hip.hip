@@ -716,7 +716,7 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     return 0;
 }
 
-// window groups of the fused backward: 8 heads x groups <= one 10-wave workgroup per CU on 256 CUs, every group the same length
+// window groups of the fused backward: 8 heads x groups <= one 12-wave workgroup per CU on 256 CUs, every group the same length
 static int attn_bwd_groups(const cffm_geom* g, int* per_group) {
     const int total = g->B * g->nW;
     static int want = -1;   // tuning aid: CFFM_BWD_GROUPS
@@ -778,7 +778,7 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
 }
 
 #ifdef BWD_TIMING
-extern "C" int cffm_debug_bwd_stamps(long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwd_t), sizeof(long long) * 48) == hipSuccess ? 0 : -1; }
+extern "C" int cffm_debug_bwd_stamps(long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwd_t), sizeof(long long) * 256) == hipSuccess ? 0 : -1; }
 #endif
 #ifdef FWD_TIMING
 extern "C" int cffm_debug_fwd_stamps(long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fwd_t), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : -1; }

@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
 // =====================================================================================================
 // Fused backward (round 4: key-split form; rounds 2-3 ran 4 waves x 16 queries in the S^T orientation and exchanged P and dS through
 // LDS per 32-key chunk, 12 barriers per window -- scripts/r03_attn_bwd_chunked/).  grid (8 heads, NG window groups).
-//   * ONE workgroup of 10 waves per CU walks its window group; wave p owns key tiles 2p, 2p+1 of every window (tile 19 does not
-//     exist: wave 9 carries one) against ALL 64 queries, in the S = Q K^T orientation (C rows = queries, C columns = keys, a lane
+//   * ONE workgroup of 12 waves per CU walks its window group; waves 0..7 own key tiles 2w, 2w+1 of every window, waves 8..10
+//     tiles 16..18 (5 / 5 / 5 / 4 tiles per SIMD) against ALL 64 queries, in the S = Q K^T orientation (C rows = queries, C columns = keys, a lane
 //     = one key): P and dS of a tile contract over QUERIES -- dV^T = dO^T P, dK^T = Q^T dS -- straight from the C registers (B operand,
 //     the k-slot <-> query map of att_tr_frag on the Q / dO rows), so P never leaves the registers and the head's bias gradient of
 //     the wave's two tiles accumulates in 32 registers over the whole group;
@@ -368,19 +368,19 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
 //     during its query phase.  No staging registers, no VALU staging pass; waits are counted (vmcnt(N)), never vmcnt(0).
 // Two barriers per window instead of twelve, one exp per (query, key) as before.
 // =====================================================================================================
-#define ATT_BK_THREADS 640
+#define ATT_BK_THREADS 768
 #define ATT_BK_IMG (2 * CFFM_NKEY_PAD * ATT_KS_STRIDE)      // halfs of one K | V image
 #define ATT_BK_DSROWS 320                                   // dS image rows: 10 pairs x 32 keys (rows 304.. stay zero)
 #define ATT_BK_TAB (320 + 64)                               // ints of one table buffer: the window's key-table slice, its q_dst slice
 #define ATT_BK_RAW (2 * 64 * CFFM_HD + 64)                  // floats of the parking area: dO rows, O rows, the LSE row
-#define ATT_BK_LDS ((2 * ATT_BK_IMG + 4 * 64 * ATT_KS_STRIDE + 2 * ATT_BK_DSROWS * ATT_KS_STRIDE) * 2 + (ATT_BK_RAW + 2 * CFFM_NKEY_PAD + 4 * 64 + 4 + 8 + 2 * ATT_BK_TAB) * 4)
+#define ATT_BK_LDS ((2 * ATT_BK_IMG + 4 * 64 * ATT_KS_STRIDE + 2 * ATT_BK_DSROWS * ATT_KS_STRIDE) * 2 + (ATT_BK_RAW + 2 * CFFM_NKEY_PAD + 4 * 64 + 4 + 8 + 3 * ATT_BK_TAB) * 4)
 #ifndef BK_ABLATE
 #define BK_ABLATE 0   // profiling builds only: 1 no DMA, 2 no key phase, 4 no query phase, 8 no partial-row stores, 16 no exp
 #endif
-#ifdef BWD_TIMING   // profiling builds only: shader-clock stamps of the third window of (head 0, group 0) wave 0 / wave 5 and (head 0, group 13) wave 9
-__device__ long long g_bwd_t[3 * 16];
-#define KS_STAMP(i) do { if (lane == 0 && blockIdx.x == 0 && (wb == wb0 + 2 || (wb == wb0 + 3 && (i) == 0)) && ((grp == 0 && (wave == 0 || wave == 5)) || (grp == 13 && wave == 9))) \
-    g_bwd_t[(grp == 13 ? 2 : wave == 5 ? 1 : 0) * 16 + (wb == wb0 + 3 ? 9 : (i))] = __builtin_readcyclecounter(); } while (0)
+#ifdef BWD_TIMING   // profiling builds only: shader-clock stamps of the third window of (head 0, group 0), every wave (scripts/r04_ks_timing.py)
+__device__ long long g_bwd_t[16 * 16];
+#define KS_STAMP(i) do { if (lane == 0 && blockIdx.x == 0 && grp == 0 && (wb == wb0 + 2 || (wb == wb0 + 3 && (i) == 0))) \
+    g_bwd_t[wave * 16 + (wb == wb0 + 3 ? 9 : (i))] = __builtin_readcyclecounter(); } while (0)
 #else
 #define KS_STAMP(i)
 #endif
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     float* sD = lse2 + 128;                                  // [2][64] rowsum(dO_h * O)
     float* sisc = sD + 128;                                  // [2] 1 / sc of the window
     float* smax = sisc + 4;                                  // [8] |dO| maxima of the parked rows, one per fetching wave
-    int* tabs = (int*)(smax + 8);                            // [2][key-table slice 320 | q_dst slice 64] of the windows to come
+    int* tabs = (int*)(smax + 8);                            // [3][key-table slice 320 | q_dst slice 64] of the windows to come
 
     const int h = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -432,6 +432,10 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     const dma_t dm_qd = dma_make(q_dst, (uint32_t)(G.nW * CFFM_WA * 4));
     const int drow = lane >> 2, sc4 = lane & 3;              // K / V / Q DMA role: row of the wave's tile, chunk position
     const int rrow = 8 * wave + (lane >> 3);                 // dO / O DMA role (waves 0..7): query row, 16-byte chunk lane & 7 of its 128 bytes
+    // key-phase role: waves 0..7 own key tiles 2 w, 2 w + 1, waves 8..10 tiles 16..18, wave 11 none -- a workgroup's waves go to the four
+    // SIMDs cyclically, so every SIMD runs 5 tiles (one 4): with ten waves x 2 tiles two SIMDs ran 6 and 5 tiles against 4 on the
+    // others and the barrier waited ~2 k cycles per window for the third wave of the fullest SIMD (shader-clock stamps)
+    const int ntile = wave < 8 ? 2 : (wave < 11 ? 1 : 0), t0 = wave < 8 ? 2 * wave : 8 + wave;
     // per-lane LDS address parts (element offsets; tiles / pairs add multiples of 512)
     const int lrow = ATT_ROW(l15, g);                        // row-fragment reads: row 16 t + l15, chunk g
     const int ltr0 = att_tr_lane(0, lane), ltr1 = att_tr_lane(16, lane);
@@ -440,12 +444,13 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     // product mt channel 8 g + 4 mt + r -- a lane then owns 8 CONSECUTIVE channels of its key over mt = 0, 1: one 16-byte store
     const int ltp0 = ATT_ROW(4 * g + (l15 >> 2), l15 & 3), ltp1 = ltp0 + 4;
     const int dsw0 = ATT_ROW(l15, (g >> 1)) + 4 * (g & 1), dsw1 = ATT_ROW(l15, 2 + (g >> 1)) + 4 * (g & 1);   // dS image writes
-    const f16x8 sel0 = bias_sel_frag(lane, 0), sel1 = bias_sel_frag(lane, 1);
+    // the selector of the wave's first / second tile inside its pair's bias fragment
+    const f16x8 sel0 = bias_sel_frag(lane, wave_uniform(wave < 8 ? 0 : (t0 & 1))), sel1 = bias_sel_frag(lane, 1);
 
-    // the wave's bias fragments: pair `wave` for the four query tiles (A operands: rows = queries)
+    // the wave's bias fragments: the pair of its tiles for the four query tiles (A operands: rows = queries)
     f16x8 bT[4];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) bT[qt] = buf_ld_h8(rs_bias, biash_voff(lane), biash_soff(h, qt, wave));
+    for (int qt = 0; qt < 4; ++qt) bT[qt] = buf_ld_h8(rs_bias, biash_voff(lane), biash_soff(h, qt, t0 >> 1));
     f32x4 dB[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -463,12 +468,13 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     // in front of the first use of any load result -- the round trip of every DMA and store in flight (measured: 4 such stalls per
     // window in the first version of this kernel).
     struct Ahead { int src[2]; int qd; };
-    auto ahead_load = [&](int wb, Ahead& a) {
-        const int w = wb % G.nW;
+    struct Win { int wb, w, b; };       // window, its index inside the clip, the clip (kept incrementally: no division in the loop)
+    auto win_next = [&](const Win& x) { Win y = {x.wb + 1, x.w + 1, x.b}; if (y.w == G.nW) { y.w = 0; y.b += 1; } return y; };
+    auto ahead_load = [&](int w, Ahead& a) {
         const int* ksrc = key_src + w * CFFM_NKEY_PAD;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int i = wave + 10 * it;
+            const int i = wave + 12 * it;
             a.src[it] = i < 19 ? ksrc[16 * i + drow] : -1;
         }
         a.qd = (wave < 8 && rrow < CFFM_WA) ? q_dst[w * CFFM_WA + rrow] : -1;
@@ -477,31 +483,28 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
         const int* t = tabs + tb * ATT_BK_TAB;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int i = wave + 10 * it;
+            const int i = wave + 12 * it;
             a.src[it] = i < 19 ? t[16 * i + drow] : -1;
         }
         a.qd = (wave < 8 && rrow < CFFM_WA) ? t[320 + rrow] : -1;
     };
-    // table slices of window wb -> buffer tb: waves 4..8 one 64-entry piece of the key table each (the last one runs 16 entries into the
-    // next window's slice or off the table: never used), wave 9 the q_dst slice
-    auto tab_issue = [&](int wb, int tb) {
-        const int w = wb % G.nW;
+    // table slices of window wb -> buffer tb: waves 7..11 one 64-entry piece of the key table each (the last one runs 16 entries into the
+    // next window's slice or off the table: never used), wave 6 the q_dst slice
+    auto tab_issue = [&](int w, int tb) {
         if (BK_ABLATE & 1) return;
-        if (wave >= 4 && wave < 9) dma_ld4(dm_tab, 4u * (uint32_t)(64 * (wave - 4) + lane), (uint32_t)(w * CFFM_NKEY_PAD * 4), tabs + tb * ATT_BK_TAB + 64 * (wave - 4));
-        else if (wave == 9) dma_ld4(dm_qd, 4u * (uint32_t)lane, (uint32_t)(w * CFFM_WA * 4), tabs + tb * ATT_BK_TAB + 320);
+        if (wave >= 7) dma_ld4(dm_tab, 4u * (uint32_t)(64 * (wave - 7) + lane), (uint32_t)(w * CFFM_NKEY_PAD * 4), tabs + tb * ATT_BK_TAB + 64 * (wave - 7));
+        else if (wave == 6) dma_ld4(dm_qd, 4u * (uint32_t)lane, (uint32_t)(w * CFFM_WA * 4), tabs + tb * ATT_BK_TAB + 320);
         sched_fence();
     };
-    // window wb by LDS-DMA, in two steps so that the fetched entries are turned into offsets (fresh registers) BEFORE the next window's
-    // entries are fetched into the same registers -- a register copy of a load result would cost an s_waitcnt vmcnt(0), i.e. the
-    // round trip of every access in flight.  dma_prep: byte offsets; dma_issue: the key-validity flags, then in this order: dO / O rows
-    // (waves 0..7: 8 rows x 128 bytes each) and the LSE row (wave 8) -> the parking area; K / V tiles wave, wave + 10 and (waves 0..3)
-    // 16 Q rows -> image bi.
+    // A window's DMAs: dma_prep turns table entries into byte offsets (plain registers: a register copy of a load result would cost an
+    // s_waitcnt vmcnt(0), i.e. the round trip of every access in flight); dma_rows (step 1, right behind B1): the key-validity flags,
+    // the dO / O rows (waves 0..7: 8 rows x 128 bytes each) and the LSE row (wave 8) -> the parking area; dma_piece (step 2, inside the
+    // key phase): K / V tiles wave, wave + 12 and (waves 0..3) 16 Q rows -> image bi.
     struct DmaOff { uint32_t kv[2], q, rows; };
-    auto dma_prep = [&](int wb, const Ahead& a, DmaOff& o) {
-        const int w = wb % G.nW;
+    auto dma_prep = [&](int w, const Ahead& a, DmaOff& o) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int i = wave + 10 * it, row = 16 * i + drow;
+            const int i = wave + 12 * it, row = 16 * i + drow;
             o.kv[it] = a.src[it] >= 0 ? (uint32_t)a.src[it] * 1536u + 16u * (uint32_t)(sc4 ^ ATT_SWZ(row)) : BUF_OOB;
         }
         const int qrow = 16 * wave + drow;
@@ -509,12 +512,12 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
         o.rows = a.qd >= 0 ? (uint32_t)a.qd * (CFFM_C * 4u) + 16u * (uint32_t)(lane & 7) : BUF_OOB;
     };
     // step 1 (top of the window): the key-validity flags, the dO / O / LSE rows
-    auto dma_rows = [&](int wb, const DmaOff& o, int bi) {
-        const int b = wave_uniform(wb / G.nW);   // (the division runs on the vector unit: the scalar offsets below need a scalar)
+    auto dma_rows = [&](const Win& x, const DmaOff& o, int bi) {
+        const int wb = x.wb, b = x.b;
         const uint32_t ps = (uint32_t)(((long)b * G.HW * CFFM_C + h * CFFM_HD) * 4);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int i = wave + 10 * it;
+            const int i = wave + 12 * it;
             if (i < 19 && sc4 == 0) vfl[bi * CFFM_NKEY_PAD + 16 * i + drow] = o.kv[it] != BUF_OOB ? 0.f : -INFINITY;
         }
         sched_fence();
@@ -527,17 +530,16 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
         }
         sched_fence();
     };
-    // step 2, piece k = 0..4: K, V of tile wave; K, V of tile wave + 10; (waves 0..3) 16 Q rows.  The pieces go out one at a time between the
-    // chains of the wave's first key tile: all ten waves issuing their five to seven DMAs at once right behind the barrier kept every wave
+    // step 2, piece k = 0..4: K, V of tile wave; K, V of tile wave + 12; (waves 0..3) 16 Q rows.  The pieces go out one at a time between the
+    // chains of the wave's first key tile: all waves issuing their five to seven DMAs at once right behind the barrier kept every wave
     // of the CU in the texture addresser's queue for ~2 k cycles (shader-clock stamps, scripts/r04_ks_timing.py).
-    auto dma_piece = [&](int wb, const DmaOff& o, int bi, int k) {
+    auto dma_piece = [&](int b, const DmaOff& o, int bi, int k) {
         if (BK_ABLATE & 1) return;
-        const int b = wave_uniform(wb / G.nW);
         const uint32_t soff_k = qkv_soff_k(G, b, h);
         f16* Ks = img + bi * ATT_BK_IMG;
         f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
         if (k < 4) {
-            const int it = k >> 1, i = wave + 10 * it;
+            const int it = k >> 1, i = wave + 12 * it;
             if (i < 19) dma_ld16(dm_qkv, o.kv[it], soff_k + 512 * (k & 1), ((k & 1) ? Vs : Ks) + 16 * i * ATT_KS_STRIDE);
         } else if (wave < 4) {
             dma_ld16(dm_qkv, o.q, (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2), Qs + (bi * 64 + 16 * wave) * ATT_KS_STRIDE);
@@ -553,16 +555,15 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     // a power of two so that every f16 gradient operand sits near 1 (training-size gradients of 1e-6 would flush to zero in f16);
     // results are scaled back in f32.  D comes from the ROUNDED dO: with dP = dO_h V^T the kernel then sees sum_n P_n (dP_n - D) = 0
     // exactly, i.e. the exact softmax backward of a dO perturbed by 2^-12 per element; with D from the unrounded dO the rounding error
-    // of dP met an exact D in the cancelling difference dP - D (stage test: 7e-4 of max|dq| against 2.8e-4).  Waves 8 and 9 (the other eight run the query phase): lane l of wave 8 + v owns 8 channels l & 3 of rows 32 v + (l >> 2) + 16 j.
+    // of dP met an exact D in the cancelling difference dP - D (stage test: 7e-4 of max|dq| against 2.8e-4).  Waves 8..11 (the other eight run the query phase): lane l of wave 8 + v owns 8 channels l & 3 of row 16 v + (l >> 2).
     auto rows_convert = [&](int wb, int bi) {
         const f32x4 m0 = *(const f32x4*)(smax), m1 = *(const f32x4*)(smax + 4);
         const float am = fmaxf(fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3])));
         int ex = 0;
         if (am > 0.f) frexpf(am, &ex);
         const float sc = (am > 0.f) ? ldexpf(1.f, 1 - ex) : 1.f, isc = 1.f / sc;   // max|dO * sc| in [1,2) over the window
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 32 * (wave - 8) + (lane >> 2) + 16 * j, c = lane & 3;
+        {
+            const int row = 16 * (wave - 8) + (lane >> 2), c = lane & 3;
             const float* p = raw + row * CFFM_HD + 8 * c;
             const f32x4 r0 = *(const f32x4*)(p), r1 = *(const f32x4*)(p + 4);
             const f32x4 o0 = *(const f32x4*)(p + 64 * CFFM_HD), o1 = *(const f32x4*)(p + 64 * CFFM_HD + 4);
@@ -585,16 +586,22 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
         }
     };
 
+    // loop-carried: the current window and the DMA offsets of the next one (plain arithmetic results, computed in the tail of the previous
+    // key phase from table slices that landed a window before: nothing in flight crosses the back edge, nothing is prepared behind B1)
+    Win cur = {wb0, wave_uniform(wb0 % G.nW), wave_uniform(wb0 / G.nW)};
+    DmaOff onx = {{BUF_OOB, BUF_OOB}, BUF_OOB, BUF_OOB};
     if (wb0 < wb1) {
+        const Win n1 = win_next(cur), n2 = win_next(n1);
         Ahead a;
         DmaOff o;
-        ahead_load(wb0, a);
-        dma_prep(wb0, a, o);
-        dma_rows(wb0, o, 0);
+        ahead_load(cur.w, a);
+        dma_prep(cur.w, a, o);
+        dma_rows(cur, o, 0);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) dma_piece(wb0, o, 0, k);
+        for (int k = 0; k < 5; ++k) dma_piece(cur.b, o, 0, k);
         sched_fence();
-        if (wb0 + 1 < wb1) tab_issue(wb0 + 1, 1);
+        if (n1.wb < wb1) { ahead_load(n1.w, a); dma_prep(n1.w, a, onx); }
+        if (n2.wb < wb1) tab_issue(n2.w, 2);
         wait_vm0();
         if (wave < 8) rows_max();
         // (the bias fragments are complete: say so to the compiler, which otherwise waits for them -- vmcnt(0) -- at their first use
@@ -606,37 +613,33 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
         __syncthreads();
         if (wave >= 8) rows_convert(wb0, 0);
     }
+    int r3 = 0;   // (wb - wb0) % 3: table buffer r3 is free (it held window wb's slices), buffer (r3 + 2) % 3 holds window wb + 2's
     for (int wb = wb0; wb < wb1; ++wb) {
-        const int bi = (wb - wb0) & 1, w = wb % G.nW, b = wb / G.nW;
+        const int bi = (wb - wb0) & 1, w = cur.w, b = cur.b;
+        const Win n1 = win_next(cur), n2 = win_next(n1), n3 = win_next(n2);
         // The K / V / Q DMAs of this window were issued a window ago; the only accesses younger than them are the wave's stores of the
-        // previous window (4 partial-row stores, 2 for wave 9, and at most one more): waiting for those as well would expose their round
+        // previous window (2 partial-row stores per key tile and at most one more): waiting for those as well would expose their round
         // trip to HBM at every window.  (Not so for the first window: its DMAs were issued just now.)
         KS_STAMP(0);
-        if ((BK_ABLATE & 32) || wb == wb0) wait_vm0(); else if (wave == 9) wait_vm<2>(); else wait_vm<4>();
+        if ((BK_ABLATE & 32) || wb == wb0 || ntile == 0) wait_vm0(); else if (ntile == 1) wait_vm<2>(); else wait_vm<4>();
         KS_STAMP(1);
         __syncthreads();   // B1: window wb's K / V / Q rows are in image bi, its dO_h rows, D, LSE, 1 / sc are written; image bi ^ 1, the dS
                            //     images and the parking area are free
         KS_STAMP(2);
         const bool more = wb + 1 < wb1;
-        DmaOff o = {{BUF_OOB, BUF_OOB}, BUF_OOB, BUF_OOB};
-        if (more) {   // window wb + 1 (its table slices are in tabs[bi ^ 1]): offsets, flags, the row DMAs; the rest goes out inside the key phase
-            Ahead a;
-            ahead_lds(bi ^ 1, a);
-            dma_prep(wb + 1, a, o);
-            dma_rows(wb + 1, o, bi ^ 1);
-        }
+        if (more) dma_rows(n1, onx, bi ^ 1);   // flags and row DMAs of window wb + 1; the rest goes out inside the key phase
         KS_STAMP(3);
         const f16* Ks = img + bi * ATT_BK_IMG;
         const f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
         const f16* Q = Qs + bi * 64 * ATT_KS_STRIDE;
         const f16* dO = dOs + bi * 64 * ATT_KS_STRIDE;
         const float isc = sisc[bi];
-        // ---- key phase: the wave's two key tiles against all 64 queries
+        // ---- key phase: the wave's key tiles against all 64 queries
         if (!(BK_ABLATE & 2)) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int t = 2 * wave + u;
-                if (t < 19) {
+                const int t = t0 + u;
+                if (u < ntile) {
                     sched_fence();
                     const f16x8 kf = *(const f16x8*)(Ks + 512 * t + lrow);
                     const f16x8 vf = *(const f16x8*)(Vs + 512 * t + lrow);
@@ -645,7 +648,7 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
                     f16x4 ph[4], dsh[4];
 #pragma unroll
                     for (int qt = 0; qt < 4; ++qt) {
-                        if (u == 0 && more) dma_piece(wb + 1, o, bi ^ 1, qt);
+                        if (u == 0 && more) dma_piece(n1.b, onx, bi ^ 1, qt);
                         const f16x8 qf = *(const f16x8*)(Q + 512 * qt + lrow);
                         const f16x8 dof = *(const f16x8*)(dO + 512 * qt + lrow);
                         const f32x4 sv = mfma16x16x32_f16(qf, kf, mfma16x16x32_f16(bT[qt], u ? sel1 : sel0, c0));   // Q K^T + bias + mask
@@ -663,9 +666,9 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
                         // dS image: row = key, 8 bytes = queries 16 qt + 4 g .. + 3
                         *(f16x4*)(DS + (qt >> 1) * ATT_BK_DSROWS * ATT_KS_STRIDE + 512 * t + ((qt & 1) ? dsw1 : dsw0)) = dsh[qt];
                     }
-                    if (u == 0 && more) {   // the last pieces: Q rows, the table slices of window wb + 2 -- all DMAs precede the wave's stores
-                        dma_piece(wb + 1, o, bi ^ 1, 4);
-                        if (wb + 2 < wb1) tab_issue(wb + 2, bi);
+                    if (u == 0 && more) {   // the last pieces: Q rows, the table slices of window wb + 3 -- all DMAs precede the wave's stores
+                        dma_piece(n1.b, onx, bi ^ 1, 4);
+                        if (wb + 3 < wb1) tab_issue(n3.w, r3);
                     }
                     f32x4 aK[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, aV[2] = {aK[0], aK[0]};
 #pragma unroll
@@ -689,10 +692,21 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
                 KS_STAMP(4 + u);
             }
         }
-        // the next window's dO / O / LSE rows have landed: of this wave's accesses only its K / V DMAs (4), the Q or table DMA and the
-        // partial-row stores (4) are younger than the row DMAs
-        if (more && wave < 9) {
-            if (BK_ABLATE & 32) wait_vm0(); else wait_vm<8>();
+        // the next window's dO / O / LSE rows have landed: of this wave's accesses only its K / V DMAs, the Q or table DMA and the
+        // partial-row stores are younger than the row DMAs
+        if (more && ntile == 0) {   // wave 11 has no key tile to issue its DMA pieces from
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dma_piece(n1.b, onx, bi ^ 1, k);
+            if (wb + 3 < wb1) tab_issue(n3.w, r3);
+        }
+        if (wb + 2 < wb1) {   // the offsets of window wb + 2 (its slices landed before B1), behind the last use of window wb + 1's
+            Ahead a;
+            sched_fence();
+            ahead_lds(r3 + 2 >= 3 ? r3 - 1 : r3 + 2, a);
+            dma_prep(n2.w, a, onx);
+        }
+        if (more && wave < 9) {   // younger than the row DMAs: waves 0..6 >= 9 accesses, wave 7 (one K / V tile to fetch) 7, wave 8 (one key tile) 5
+            if (BK_ABLATE & 32) wait_vm0(); else if (wave < 7) wait_vm<8>(); else if (wave == 7) wait_vm<6>(); else wait_vm<4>();
             if (wave < 8) rows_max();
         }
         KS_STAMP(6);
@@ -716,6 +730,8 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
             }
         }
         KS_STAMP(8);
+        cur = n1;
+        r3 = r3 == 2 ? 0 : r3 + 1;
     }
     // the group's bias gradient: one plain [304 keys][64 queries] tile per (group, head); k_sum_splits adds the groups
     const buf_t rs_dbp = buf_make(dbias_part + (((long)grp * CFFM_HEADS + h) * CFFM_NKEY_PAD) * CFFM_NQ_PAD,
@@ -724,8 +740,8 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int qt = 0; qt < 4; qt += 2)
-            if (2 * wave + u < 19) {
-                const uint32_t so = (uint32_t)(((16 * (2 * wave + u)) * CFFM_NQ_PAD + 16 * qt) * 4);
+            if (u < ntile) {
+                const uint32_t so = (uint32_t)(((16 * (t0 + u)) * CFFM_NQ_PAD + 16 * qt) * 4);
                 buf_st16_pair(rs_dbp, dB[u][qt], dB[u][qt + 1], (uint32_t)((l15 * CFFM_NQ_PAD + 4 * g) * 4), so, so + 64);
             }
 }
