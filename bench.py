@@ -119,7 +119,8 @@ def roofline_kernels(stages, b, nw, hw):
         out[name]['ms_per_step'] = st['ms_per_step']
         if name == 'attn_bwd_fused':   # also HBM-side: reads f16 q/k/v + O + dO, writes dQ + f16 dK/dV partial rows + bias-gradient tiles
             rd = b * (nr // b * 768 * 2 + 2 * hw * 256 * 4)
-            wr = b * (hw * 256 * 4) + b * nw * 304 * 512 * 2 + 54 * 8 * 64 * 304 * 4
+            per = -(-(b * nw) // min(32, b * nw))        # window groups of the launch: cffm_hip.hip, attn_bwd_groups
+            wr = b * (hw * 256 * 4) + b * nw * 304 * 512 * 2 + -(-(b * nw) // per) * 8 * 64 * 304 * 4
             out[name].update({'hbm_bytes': int(rd + wr), 'hbm_write_bytes': int(wr), 'hbm_frac': round((rd + wr) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
     out['note'] = ('HIP-event intervals of the separate instrumented pass, every kernel on one stream (each includes ~2-3 us of event-record cost); GEMM peak = 2500/3 TF '
                    '(three bf16 MFMA products per fp32 product), attention backward against the f16 MFMA peak, row kernels against 8 TB/s')
