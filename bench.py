@@ -759,6 +759,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f32 accumulate; MFMA operands: split-bf16 (hi+lo, ~2^-17) in the Linear GEMMs, f16 in QK^T/AV',
             'data': 'synthetic',
+            'data_note': ('every step consumes the SAME resident synthetic clip batch (29.5 MB at B = 2) and upstream gradient: they stay in the 256 MB MALL '
+                          'between steps, so a step does not pay the first-touch HBM read a fresh batch would (~7 us at ~4 TB/s, ~1 % of the step)'),
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
                        'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'ranks_in_sync': ranks_in_sync, 'params_finite': params_finite, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else (nonlocal_note[-1] if nonlocal_note else 'graph(forward + backward of block 1) | all-reduce(block 1) overlapping graph(backward of block 0) | all-reduce(block 0) | graph(AdamW)')),
                        'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one asynchronous all-reduce per block of the flat gradient buffer, overlapped with the backward of the next block') if multi else 'none'},
