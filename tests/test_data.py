@@ -61,11 +61,22 @@ def run_clip_cases(device):
         assert torch.equal(gt.cpu(), torch.from_numpy(g['photo/%d/gt' % clip_seed]))
         torch.testing.assert_close(img.cpu(), torch.from_numpy(g['photo/%d/img' % clip_seed]), rtol=0, atol=1e-6)
         assert any(v == v for v in params['photo']['beta'] + params['photo']['alpha'])       # (something was actually distorted)
-    # a stream that draws saturation / hue: refused by default, those two steps left out with on_hsv='skip'
+    # a stream that draws saturation / hue: those two steps are left out with ONE warning per instance by default, silently with
+    # on_hsv='skip', refused with on_hsv='raise'
     np.random.seed(3)
     with pytest.raises(_lib.CffmError):
         for _ in range(8):
-            D.PhotoMetricDistortionClips().draw(4)
+            D.PhotoMetricDistortionClips(on_hsv='raise').draw(4)
+    np.random.seed(3)
+    dflt = D.PhotoMetricDistortionClips()
+    with pytest.warns(RuntimeWarning, match='saturation / hue'):
+        for _ in range(8):
+            dflt.draw(4)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        for _ in range(8):
+            dflt.draw(4)                      # (warned once: silent from then on)
     np.random.seed(3)
     ph = D.PhotoMetricDistortionClips(on_hsv='skip').draw(4)
     assert len(ph['saturation']) == 4 and len(ph['hue']) == 4

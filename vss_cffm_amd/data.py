@@ -60,13 +60,16 @@ class PhotoMetricDistortionClips:
     ``randint(2)`` saturation (+ ``uniform``), ``randint(2)`` hue (+ ``randint(-delta, delta)``), [mode 0: contrast] -- so a seeded run stays in
     step with the reference's stream.  Brightness and contrast are applied by the clip kernel (``convert()``, :2057-2061, in float32 as
     numpy does).  Saturation and hue go through cv2's 8-bit BGR<->HSV conversion (mmcv.bgr2hsv / hsv2bgr), whose rounding cannot be
-    pinned without cv2: a frame that draws them raises (``on_hsv='raise'``, default) or has just those two steps left out
-    (``on_hsv='skip'``: a documented deviation, never an approximation of the colour conversion)."""
+    pinned without cv2: a frame that draws them has just those two steps left out -- a documented deviation, never an approximation of
+    the colour conversion -- with one RuntimeWarning per instance (``on_hsv='warn'``, the default: each step is taken with probability
+    1/2 per frame, so a policy that refuses them refuses 15 of 16 four-frame clips), silently (``'skip'``), or raises (``'raise'``:
+    for runs that must match the reference's augmentation bit for bit or not run at all)."""
 
-    def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, on_hsv='raise',
+    def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, on_hsv='warn',
                  np_random=np.random):
-        if on_hsv not in ('raise', 'skip'):
-            raise ValueError("on_hsv must be 'raise' or 'skip'")
+        if on_hsv not in ('raise', 'skip', 'warn'):
+            raise ValueError("on_hsv must be 'warn', 'skip' or 'raise'")
+        self._warned = False
         self.brightness_delta, self.contrast_range = brightness_delta, tuple(contrast_range)
         self.saturation_range, self.hue_delta, self.on_hsv, self.rng = tuple(saturation_range), hue_delta, on_hsv, np_random
 
@@ -88,6 +91,11 @@ class PhotoMetricDistortionClips:
         if self.on_hsv == 'raise' and any(v is not None for v in sat + hue):
             raise _lib.CffmError('PhotoMetricDistortionClips: a frame drew the saturation / hue distortion, which needs cv2\'s 8-bit HSV '
                                  'conversion (not available here; on_hsv=\'skip\' leaves those two steps out)')
+        if self.on_hsv == 'warn' and not self._warned and any(v is not None for v in sat + hue):
+            import warnings
+            warnings.warn('PhotoMetricDistortionClips: the saturation / hue steps (cv2 8-bit HSV arithmetic) are left out; brightness and '
+                          'contrast are applied as the reference does (on_hsv=\'raise\' refuses such frames instead)', RuntimeWarning, stacklevel=2)
+            self._warned = True
         return dict(beta=beta, alpha=alpha, saturation=sat, hue=hue)
 
 
