@@ -296,6 +296,32 @@ def test_adamw_schedule_follows_the_global_iteration_emulated():
         run_adamw_schedule_follows_the_global_iteration(torch.device('cpu'))
 
 
+def test_adamw_keeps_captured_tables_alive_when_a_new_row_reallocates_them():
+    """a HIP graph captured around step() holds the raw addresses of the optimizer's device tables.  A parameter that gets its
+    first gradient later adds a row and REPLACES those tables: the old ones must stay alive (a replay of the stale graph then writes into
+    memory the optimizer still owns instead of freed memory) and the caller must be told to capture again."""
+    import warnings
+    from vss_cffm_amd.optim import AdamW
+    with emu.active():
+        gen = torch.Generator().manual_seed(5)
+        p0, p1 = torch.nn.Parameter(torch.randn(64, generator=gen)), torch.nn.Parameter(torch.randn(32, generator=gen))
+        opt = AdamW([p0, p1], lr=1e-3)
+        p0.grad = torch.randn(64, generator=gen)
+        opt.step()
+        dr = next(iter(opt._devs.values()))
+        old = (dr.consts, dr.state)
+        dr.captured = True                       # what step() records when the current stream is being captured
+        p0.grad, p1.grad = torch.randn(64, generator=gen), torch.randn(32, generator=gen)
+        with pytest.warns(RuntimeWarning, match='captured again'):
+            opt.step()                            # p1 joins with step count 0: a new (group, count) row
+        assert len(dr.retired) == 1 and dr.retired[0][0] is old[0] and dr.retired[0][1] is old[1] and not dr.captured
+        assert dr.consts is not old[0] and dr.consts.shape[0] == old[0].shape[0] + 1
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')        # no capture since: further rows replace the tables silently
+            p0.grad, p1.grad = torch.randn(64, generator=gen), None
+            opt.step()
+
+
 @pytest.mark.gpu
 def test_adamw_schedule_follows_the_global_iteration_gpu():
     run_adamw_schedule_follows_the_global_iteration(torch.device('cuda:0'))

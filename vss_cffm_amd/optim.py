@@ -54,12 +54,26 @@ class _DeviceRows:
         self.inflight = []        # pinned staging buffers of eager-mode `sched` copies that may still be queued
         self.members = {}         # row -> ids of the parameters updated with it
         self.gstep = 0            # host mirror of the global iteration count (consts[:, 10]; the device's runs ahead after graph replays)
+        self.captured = False     # a step was recorded into a HIP graph: that graph holds the addresses of the current tables
+        self.retired = []         # tables a captured graph may still point at, kept alive (see _retire)
         self.ticket = torch.zeros(65, dtype=torch.int32, device=device)   # workgroup tickets of the fused tick + update launch (CFFM_ADAMW_TICKETS)
+
+    def _retire(self):
+        """Called before the tables are replaced.  A HIP graph captured earlier holds their raw addresses: it must be captured again to
+        see the new rows.  Replaying the OLD graph anyway would write through dangling pointers, so the superseded tables are kept
+        alive -- such a replay then updates stale rows (wrong, but confined to memory this optimizer owns) -- and a RuntimeWarning says so."""
+        if self.captured and self.state is not None:
+            import warnings
+            self.retired.append((self.consts, self.state, self.sched, self.sched_host, dict(self.tables)))
+            warnings.warn('vss_cffm_amd.optim.AdamW: the device tables of a step that was captured in a HIP graph are being reallocated '
+                          '(new parameter row); graphs captured before this point must be captured again', RuntimeWarning, stacklevel=3)
+            self.captured = False
 
     def row_for(self, gi, step, group):
         for r, (g, t) in enumerate(self.rows):
             if g == gi and t == step:
                 return r
+        self._retire()
         self.sync_host()
         old_state = self.state
         self.rows.append([gi, step])
@@ -86,6 +100,7 @@ class _DeviceRows:
     def split_row(self, r):
         """A copy of row r (same group, same step count, same constants), made ON THE DEVICE (no host sync: after graph replays
         only the device knows the count): the parameters of r that sit out a step move there before r advances."""
+        self._retire()
         self.rows.append(list(self.rows[r]))
         dev = self.device
         self.consts = torch.cat([self.consts, self.consts[r:r + 1]])
@@ -292,6 +307,7 @@ class AdamW(torch.optim.Optimizer):
             dr.gstep += 1
             self.refresh_hyper()
             capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+            dr.captured = dr.captured or capturing
             now = dr.sched_host.clone() if not capturing else None
             sched_ptr = None
             if capturing and self.zero_copy_sched:
