@@ -102,7 +102,9 @@ def check(errs):
 
 # (7, 7): one window that is its own cyclic neighbour eight times over (up to 4 readings of a key by one window); (5, 20): one row of
 # windows; (8, 8): 2 x 2 windows (every neighbour direction wraps); (14, 21): no padding, non-square; (13, 30): ragged
-@pytest.mark.parametrize('shape', [(1, 7, 7), (1, 5, 20), (1, 8, 8), (2, 14, 21), (2, 13, 30), (1, 22, 23)])   # noqa: E501
+# (window groups of the launch: 1 window per group up to 32 windows, then 2, 3, ...: (1, 42, 42) = 36 windows walks 2 per workgroup --
+# the shortest run of the kernel's window pipeline that has a 'next' window)
+@pytest.mark.parametrize('shape', [(1, 7, 7), (1, 5, 20), (1, 8, 8), (2, 14, 21), (2, 13, 30), (1, 22, 23), (1, 42, 42)])   # noqa: E501
 def test_attn_bwd_stage_emulated(shape):
     errs = run_attn_bwd_stage(emu.lib(), torch.device('cpu'), *shape)
     check(errs)
@@ -119,7 +121,8 @@ def test_attn_bwd_stage_tiny_gradients_emulated():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(1, 7, 7), (2, 8, 8), (2, 14, 21), (2, 13, 30), (2, 60, 60), (2, 64, 64), (1, 60, 108)])
+# windows per workgroup: 1, 1, 1, 1, 2, 3, 6, 7, 5 (+ a short last group)
+@pytest.mark.parametrize('shape', [(1, 7, 7), (2, 8, 8), (2, 14, 21), (2, 13, 30), (1, 42, 42), (1, 56, 63), (2, 60, 60), (2, 64, 64), (1, 60, 108)])
 def test_attn_bwd_stage_gpu(shape):
     errs = run_attn_bwd_stage(_lib.get(), torch.device('cuda'), *shape)
     print('attn_bwd stage', shape, {k: '%.2e' % v for k, v in errs.items() if '_' not in k})
