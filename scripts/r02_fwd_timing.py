@@ -15,7 +15,7 @@ b, GRID = 2, 60
 g = ops.make_geom(lib, b, GRID, GRID)
 key_src, q_dst = ops.device_tables(GRID, GRID, dev)[:2]
 qkv = (torch.randn(b * g.RC, 768) * 0.5).half().to(dev)
-biasf = (torch.randn(8 * 4 * 19 * 256) * 0.5).half().to(dev)
+biasf = (torch.randn(8 * 4 * 10 * 512) * 0.5).half().to(dev)      # pair fragments (round 4)
 ao = torch.empty(b * g.HW, 256, device=dev); lse = torch.empty(b * g.nW * 8, 64, device=dev)
 P = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
