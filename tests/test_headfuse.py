@@ -218,6 +218,58 @@ def run_head_ab(device, size=64, chans=(32, 64, 160, 256), depths=1):
     assert H.rel_err(a[4], b[4]) < 1e-5
 
 
+def run_headpp_ab(device, size=64, chans=(32, 64, 160, 256), depths=1):
+    """The CFFM++ head (cffm_head.py:423-535; frozen embedding, detached CFFM branch, prototype layer + linear_pred3), training and eval
+    mode: its row path against the same head on the reference's op sequence -- logits, loss, which parameters train and their gradients."""
+    import os, tempfile
+    from tests.golden.make_golden_head import feature_maps, labels
+    head = build_head(RI.head_cfg(kind='CFFMHead_clips_resize1_8_finetune_w_prototype3', in_channels=chans, depths=depths))
+    head.load_state_dict(R.synth_state(head, seed=71), strict=False)
+    head.dropout.p = head.dropout3.p = 0.0
+    Hd.revert_sync_batchnorm(head)
+    head.to(device)
+    feats = [f.to(device) for f in feature_maps(2, 4, size, chans=chans, seed=72)]
+    lab = labels(2, 4, size, seed=73).to(device)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        metas = []
+        for v in range(2):
+            os.makedirs(os.path.join(tmp, 'vid%d' % v))
+            torch.save(R.synth_input('centers%d' % v, (1, 8, 256), seed=74 + v, scale=1.0), os.path.join(tmp, 'vid%d' % v, 'centers.pt'))
+            metas.append({'filename': tmp + '/data/vid%d/origin/0001.jpg' % v})
+        head.save_path = tmp + '/'
+        for impl in ('hip', 'torch'):
+            head.rows_impl = impl
+            for p in head.parameters():
+                p.grad = None
+            head.eval()
+            with torch.no_grad():
+                ev = head(feats, 2, 4, None, metas)
+            head.train()
+            out = head(feats, 2, 4, None, metas)
+            loss = head.losses(out, lab)
+            loss['loss_seg'].backward()
+            res[impl] = (ev, out.detach(), float(loss['loss_seg'].detach()), {k: p.grad for k, p in head.named_parameters() if p.grad is not None})
+    head.rows_impl = 'hip'
+    a, b = res['hip'], res['torch']
+    tol = 2e-5 if device.type == 'cpu' else 3e-4
+    assert a[0].shape == b[0].shape and a[1].shape == b[1].shape
+    assert H.rel_err(a[0], b[0]) < tol and H.rel_err(a[1], b[1]) < tol and abs(a[2] - b[2]) < 10 * tol * abs(b[2])
+    assert set(a[3]) == set(b[3]) and all(k.split('.')[0] in ('linear_pred3', 'decoder_swin') for k in a[3]), sorted(a[3])
+    for k in a[3]:
+        assert H.rel_err(a[3][k], b[3][k]) < (1e-3 if device.type == 'cpu' else 3e-3), k
+
+
+def test_headpp_rows_path_equals_torch_glue_emulated():
+    with emu.active():
+        run_headpp_ab(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_headpp_rows_path_equals_torch_glue_gpu():
+    run_headpp_ab(torch.device('cuda:0'), size=128, chans=(64, 128, 320, 512), depths=2)
+
+
 def test_head_rows_path_equals_torch_glue_emulated():
     with emu.active():
         run_head_ab(torch.device('cpu'))

@@ -295,12 +295,13 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
         return resize(x2, size=size, mode='bilinear', align_corners=False).unsqueeze(1)
 
 
-@HEADS.register_module()
-class CFFMHead_clips_resize1_8(_CffmHeadBase):
+    # ------------------------------------------------------------------ the fused row path around the hot path
+    rows_impl = 'hip'       # 'torch': keep BatchNorm / ReLU / resize / the NCHW layer call in stock PyTorch (A/B partner in the tests)
+
     def _rows_path_ok(self, inputs):
-        """The fused row path around the hot path: embedding -> [BN + ReLU + 2x2-average clip stack] -> the layer on
-        token rows -> classifier on rows; needs libcffm_hip.so, fp32, a 1/4 map with even sides (then the 1/2 bilinear resize IS the
-        2x2 average) and a plain / Sync BatchNorm.  Everything else takes the reference's op sequence (`_fuse` etc.)."""
+        """embedding -> [BN + ReLU + 2x2-average clip stack] -> the layer on token rows -> classifiers on rows; needs libcffm_hip.so,
+        fp32, a 1/4 map with even sides (then the 1/2 bilinear resize IS the 2x2 average) and a plain / Sync BatchNorm.  Everything
+        else takes the reference's op sequence (`_fuse` etc.)."""
         c1 = inputs[self.in_index[0]] if isinstance(self.in_index, (list, tuple)) else inputs[0]
         bn = getattr(self.linear_fuse, 'bn', None)
         return (self.fuse_impl == 'hip' and self.rows_impl == 'hip' and (c1.is_cuda or _lib._override is not None)
@@ -308,9 +309,8 @@ class CFFMHead_clips_resize1_8(_CffmHeadBase):
                 and isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and bn.affine and bn.track_running_stats
                 and isinstance(self.linear_fuse.activate, nn.ReLU))
 
-    rows_impl = 'hip'       # 'torch': keep BatchNorm / ReLU / resize / the NCHW layer call in stock PyTorch (A/B partner in the tests)
-
-    def _forward_rows(self, inputs, batch_size, num_clips):
+    def _rows_front(self, inputs, batch_size, num_clips):
+        """-> (fused [N,256,h,w] channels-last, clip-stack rows [N,h/2,w/2,256] or None, frame logits [B,T,K,h,w])."""
         c1, c2, c3, c4 = self._transform_inputs(inputs)
         lins = (self.linear_c1, self.linear_c2, self.linear_c3, self.linear_c4)
         y = segformer_fuse([c1, c2, c3, c4], [l.proj.weight for l in lins], [l.proj.bias for l in lins], self.linear_fuse.conv.weight)
@@ -322,31 +322,44 @@ class CFFMHead_clips_resize1_8(_CffmHeadBase):
             keep = 1.0 - self.dropout.p
             mask = torch.bernoulli(torch.full((y.shape[0], y.shape[1]), keep, dtype=torch.float32, device=y.device)) / keep
         fused, stack = bn_relu_pool(y, self.linear_fuse.bn, want_stack=need_clip, drop_mask=mask)
-        x = self._frame_logits(fused, batch_size, num_clips, dropped=mask is not None)
-        if not need_clip:
-            return x[:, -1]                                   # short-circuit before CFFM (cffm_head.py:127-129)
-        h, w = fused.shape[2:]
-        h2, w2 = h // 2, w // 2
-        x_rows = stack.view(batch_size, num_clips, h2 * w2, stack.shape[-1])
-        mined = self.decoder_focal.forward_rows(x_rows, h2, w2)                                  # [B, h2*w2, 256]
-        feat = torch.cat([x_rows[:, -1], mined], dim=-1).view(batch_size, h2, w2, -1).permute(0, 3, 1, 2)   # channels-last [B,512,h2,w2]
-        x2 = self._classify(self.linear_pred2, self.dropout(feat) if self.dropout is not None else feat)
+        return fused, stack, mask is not None
+
+    def _rows_logits(self, conv, feat_rows, drop, size):
+        """A 1x1 classifier on [B,h2,w2,C] token rows + the 1/8 -> 1/4 resize (cffm_head.py:147-149) -> [B,1,K,h,w]."""
+        feat = feat_rows.permute(0, 3, 1, 2)                                                      # channels-last [B,C,h2,w2] view
+        x2 = self._classify(conv, drop(feat) if drop is not None else feat)
         if x2.permute(0, 2, 3, 1).is_contiguous() and x2.shape[1] % 4 == 0 and x2.dtype == torch.float32:
-            # the classifier wrote token rows: the 1/8 -> 1/4 resize (cffm_head.py:149) stays on rows (torch's bilinear kernels take
-            # 18 + 55 us forward + backward on this 14 MB map; k_rows_resize_* ~5 + 8) and its gradient is read out of the loss
-            # kernel's buffer in place
-            x2 = rows_resize(x2.permute(0, 2, 3, 1), (h, w)).permute(0, 3, 1, 2).unsqueeze(1)
-        else:
-            x2 = resize(x2, size=(h, w), mode='bilinear', align_corners=False).unsqueeze(1)
-        if not self.training:
-            return x2.squeeze(1)
-        if x.permute(0, 1, 3, 4, 2).is_contiguous():
+            # the classifier wrote token rows: the resize stays on rows (torch's bilinear kernels take 18 + 55 us forward + backward on
+            # this 14 MB map; k_rows_resize_* ~5 + 8) and its gradient is read out of the loss kernel's buffer in place
+            return rows_resize(x2.permute(0, 2, 3, 1), size).permute(0, 3, 1, 2).unsqueeze(1)
+        return resize(x2, size=size, mode='bilinear', align_corners=False).unsqueeze(1)
+
+    @staticmethod
+    def _rows_cat(x, x2):
+        if x.permute(0, 1, 3, 4, 2).is_contiguous() and x2.permute(0, 1, 3, 4, 2).is_contiguous():
             # the classifiers wrote token rows [.., h, w, K]: concatenate THERE (a plain copy; torch.cat of the [B,T,K,h,w] views
             # would transpose 71 MB into plain memory) and hand the result out as the [B,T+1,K,h,w] view the caller expects --
             # `losses` reads it as it lies, and cat's backward is two views of the loss kernel's gradient buffer
             rows = torch.cat([x.permute(0, 1, 3, 4, 2), x2.permute(0, 1, 3, 4, 2)], 1)
             return rows.permute(0, 1, 4, 2, 3)
         return torch.cat([x, x2], 1)
+
+
+@HEADS.register_module()
+class CFFMHead_clips_resize1_8(_CffmHeadBase):
+    def _forward_rows(self, inputs, batch_size, num_clips):
+        fused, stack, dropped = self._rows_front(inputs, batch_size, num_clips)
+        x = self._frame_logits(fused, batch_size, num_clips, dropped=dropped)
+        if stack is None:
+            return x[:, -1]                                   # short-circuit before CFFM (cffm_head.py:127-129)
+        h, w = fused.shape[2:]
+        h2, w2 = h // 2, w // 2
+        x_rows = stack.view(batch_size, num_clips, h2 * w2, stack.shape[-1])
+        mined = self.decoder_focal.forward_rows(x_rows, h2, w2)                                  # [B, h2*w2, 256]
+        x2 = self._rows_logits(self.linear_pred2, torch.cat([x_rows[:, -1], mined], dim=-1).view(batch_size, h2, w2, -1), self.dropout, (h, w))
+        if not self.training:
+            return x2.squeeze(1)
+        return self._rows_cat(x, x2)
 
     def forward(self, inputs, batch_size=None, num_clips=None, imgs=None):
         if self.training:
@@ -442,11 +455,37 @@ class CFFMHead_clips_resize1_8_finetune_w_prototype3(_CffmHeadBase):
             out.append(parts[:, pick])
         return torch.cat(out, dim=0).to(device)
 
+    def _forward_rows(self, inputs, batch_size, num_clips, centers):
+        """The same head on token rows (missing 3): the frozen embedding + BatchNorm + ReLU + clip stack in one pass, the CFFM
+        layer and the prototype layer on rows (the target frame's stack rows ARE the tokens `decoder_swin` takes: no permute / reshape),
+        all three classifiers and both resizes on rows."""
+        with torch.no_grad():                                  # the fuse conv is frozen in eval (cffm_head.py:478-480)
+            self.linear_fuse.eval()
+            fused, stack, dropped = self._rows_front(inputs, batch_size, num_clips)
+        x = self._frame_logits(fused, batch_size, num_clips, dropped=dropped)
+        if stack is None:
+            return x[:, -1]
+        h, w = fused.shape[2:]
+        h2, w2 = h // 2, w // 2
+        c = stack.shape[-1]
+        x_rows = stack.view(batch_size, num_clips, h2 * w2, c)
+        mined = self.decoder_focal.forward_rows(x_rows, h2, w2)
+        x2 = self._rows_logits(self.linear_pred2, torch.cat([x_rows[:, -1], mined], dim=-1).view(batch_size, h2, w2, -1), self.dropout, (h, w))
+        if self.finetune:                                      # the CFFM branch is detached (cffm_head.py:514-518)
+            x_rows, x, x2 = x_rows.detach(), x.detach(), x2.detach()
+        ctx = self.decoder_swin(x_rows[:, -1].contiguous(), h2, w2, centers)[0]                 # [B, h2*w2, C]
+        x3 = self._rows_logits(self.linear_pred3, ctx.reshape(batch_size, h2, w2, c), self.dropout3, (h, w))
+        if not self.training:
+            return x2.squeeze(1) + 0.5 * x3.squeeze(1)
+        return self._rows_cat(x, x3)
+
     def forward(self, inputs, batch_size=None, num_clips=None, imgs=None, img_metas=None):
         assert batch_size == len(img_metas)
         centers = self._load_centers(img_metas, inputs[0].device)
         if self.training:
             assert self.num_clips == num_clips
+        if self._rows_path_ok(inputs):
+            return self._forward_rows(inputs, batch_size, num_clips, centers)
         with torch.no_grad():                                  # the fuse conv is frozen in eval (cffm_head.py:478-480)
             self.linear_fuse.eval()
             fused = self._fuse(inputs)
