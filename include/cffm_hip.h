@@ -117,7 +117,9 @@ int cffm_attn_fwd(const cffm_geom* g, const void* qkv16, const int* key_src /*[n
                   void* stream);
 /* inv_ptr [RC+1] / inv_idx: CSR inverse of key_src (token row -> the window*304+slot pairs reading it);
  * dkv_part: scratch of B*nW*(304*256 + 8) floats: the per-window dK/dV rows the gather pass sums, kept as f16 [B*nW*304][512]
- * in units of a per-(window, head) power-of-two scale, followed by those scales */
+ * (a row = 8 heads x (K 32 | V 32) since ABI 6) in units of a per-(window, head) power-of-two scale, followed by those scales.
+ * Replaces the backward of WindowAttention3d3.forward (cffm_transformer.py:364-606: autograd through the gather / roll / unfold /
+ * softmax chain); one fused key-split kernel + the bias-tile sum + the dK / dV gather (csrc/cfm_attn_kernels.h). */
 int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, const int* q_dst,
                   const int* inv_ptr, const int* inv_idx, const void* biasH, const float* ao,
                   const float* dao, const float* lse, float* dqkv /*[B*RC,768] fp32: d(zall w^T), overwritten*/,
