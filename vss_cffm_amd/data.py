@@ -63,7 +63,10 @@ class PhotoMetricDistortionClips:
     pinned without cv2: a frame that draws them has just those two steps left out -- a documented deviation, never an approximation of
     the colour conversion -- with one RuntimeWarning per instance (``on_hsv='warn'``, the default: each step is taken with probability
     1/2 per frame, so a policy that refuses them refuses 15 of 16 four-frame clips), silently (``'skip'``), or raises (``'raise'``:
-    for runs that must match the reference's augmentation bit for bit or not run at all)."""
+    for runs that must match the reference's augmentation bit for bit or not run at all).  ``draw()`` returns the drawn saturation
+    factors and hue shifts per frame in every mode, so a caller whose host has cv2 can see which frames the reference would have
+    distorted further (the two steps sit BETWEEN brightness / first contrast and the late contrast of `convert()` mode 0, so they cannot
+    simply be applied to the frames before or after this class)."""
 
     def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, on_hsv='warn',
                  np_random=np.random):

@@ -225,8 +225,12 @@ class AdamW(torch.optim.Optimizer):
         """Write the groups' current lr / weight decay into the pinned host mirrors (no launch, no sync).  A captured
         training step copies the mirror to the device as its first node, so an arbitrary host-side LR scheduler only has to
         call this between replays -- AFTER the previous replay has consumed the mirror (e.g. behind an event recorded after
-        it): the copy node reads the mirror when it executes, not when the replay is launched.  The reference's own schedule
-        needs none of this: see set_poly_schedule.  Eager steps call it themselves."""
+        it): the copy node reads the mirror when it executes, not when the replay is launched.  HARD PRECONDITION with the default
+        zero-copy form (`zero_copy_sched`): the update launch's ~800 workgroups each read their row of the mirror at their own moment
+        of the launch, so the mirror must not change while a replay that contains the step is in flight -- call this only after an
+        event recorded behind the previous replay has completed, or set `AdamW.zero_copy_sched = False` (one memcpy node reads the
+        mirror at a single point).  The reference's own schedule needs none of this: see set_poly_schedule (nothing on the host
+        changes between replays).  Eager steps call it themselves."""
         for dr in self._devs.values():
             if dr.sched_host is not None:
                 for r, (gi, _) in enumerate(dr.rows):
