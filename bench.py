@@ -137,7 +137,7 @@ def attn_fwd_back_to_back(lib, dev, b, n=50):
     key_src, q_dst = ops.device_tables(GRID, GRID, dev)[:2]
     gen = torch.Generator().manual_seed(3)
     qkv = (torch.randn(b * g.RC, 768, generator=gen) * 0.5).half().to(dev)
-    biasf = (torch.randn(8 * 4 * 19 * 256, generator=gen) * 0.5).half().to(dev)      # f16 bias fragments
+    biasf = (torch.randn(8 * 4 * 10 * 512, generator=gen) * 0.5).half().to(dev)      # f16 bias fragments: BIASH_HALFS (cffm_common.h), tile pairs
     ao = torch.empty(b * g.HW, 256, device=dev)
     lse = torch.empty(b * g.nW * 8, 64, device=dev)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

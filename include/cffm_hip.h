@@ -91,7 +91,7 @@ int cffm_pool_matrix_bwd(const float* dM, float* const dpool_w[4], void* stream)
  * padded to a multiple of 4 floats (vss_cffm_amd.ops lays them out so; a data-parallel exchange all-reduces that buffer whole), and
  * asks it to zero the padding itself: the backward of the pooling Linears -- owners of the only tensors whose length is not a multiple
  * of 4 (49 / 49 / 9 weights, four scalar biases) -- writes 3 zeros behind each of them.  Off by default (tensors of their own);
- * vss_cffm_amd.ops switches it on around its own layer-backward calls only. */
+ * vss_cffm_amd.ops switches it on around its own layer-backward calls only.  The setting is PER CALLING THREAD (thread_local). */
 void cffm_grad_slices_padded(int yes);
 int cffm_ln_pool_fwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
                      const float* gamma, const float* beta, const float* M, const float* const pool_b[4],

@@ -242,7 +242,24 @@ def _worker_blockwise_preexisting(rank, world, port, out):
             red.remove()
         for k, p in m.named_parameters():
             assert torch.allclose(p.grad, mine[k], rtol=1e-5, atol=1e-7 * float(mine[k].abs().max())), k
-    torch.save({k: p.grad.clone() for k, p in m.named_parameters()}, os.path.join(out, 'pgrad%d.pt' % rank))
+        # (c) ADVICE r4: gradient accumulation after zero_grad(set_to_none=True) -- two backwards, ONE finish().  The first backward's
+        #     slices are exchanged block by block and adopted as .grad; the second one must notice them at ITS first block although
+        #     exchanges are still pending, complete those, and leave the sum to finish()
+        acc_in = dict(m.named_parameters())
+        for p in m.parameters():
+            p.grad = None
+        red = V.distributed.BlockwiseReducer().install(m.parameters())
+        try:
+            (m(x)[:, -1] * g).sum().backward()
+            assert red.pending and not red.accumulating
+            x2, g2 = _clip(rank + 7)
+            (m(x2)[:, -1] * g2).sum().backward()
+            assert red.accumulating and not red.pending and red.drained == 1
+            assert red.finish() == 1 and red.fallbacks == 1 and not red.accumulating
+        finally:
+            red.remove()
+        torch.save({k: p.grad.clone() for k, p in acc_in.items()}, os.path.join(out, 'pgrad_acc%d.pt' % rank))
+    torch.save(mine, os.path.join(out, 'pgrad%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -252,6 +269,11 @@ class _Replay:
 
     def __init__(self, red):
         self.pending, self.average, self.params, self.accumulating, self.fallbacks = list(red.pending), red.average, None, False, 0
+        self.drained = 0
+
+    def _drain(self):
+        import vss_cffm_amd as V
+        return V.distributed.BlockwiseReducer._drain(self)
 
     def __setattr__(self, k, v):
         object.__setattr__(self, k, v)
@@ -273,6 +295,19 @@ def test_blockwise_reducer_with_preexisting_grads_gloo(tmp_path):
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
         assert H.rel_err(g0[k], (per_rank[0][k] + per_rank[1][k]) / world) < 1e-5, k
+    # (c) two micro-batches per rank, one finish(): the averaged sum of all four gradients
+    a0, a1 = (torch.load(os.path.join(str(tmp_path), 'pgrad_acc%d.pt' % r)) for r in range(world))
+    second = []
+    with emu.active():
+        for r in range(world):
+            m = _layer()
+            x, g = _clip(r + 7)
+            (m(x)[:, -1] * g).sum().backward()
+            second.append({k: p.grad for k, p in m.named_parameters()})
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), k
+        want = (per_rank[0][k] + per_rank[1][k] + second[0][k] + second[1][k]) / world
+        assert H.rel_err(a0[k], want) < 1e-5, k
 
 
 def _bn_case(rank_or_all, world):

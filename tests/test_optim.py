@@ -296,6 +296,73 @@ def test_adamw_schedule_follows_the_global_iteration_emulated():
         run_adamw_schedule_follows_the_global_iteration(torch.device('cpu'))
 
 
+def run_adamw_schedule_survives_resume_and_new_groups(device):
+    """the device-side poly schedule counts from the optimizer's GLOBAL iteration.  That count must survive (a) a
+    state_dict() / load_state_dict() round trip -- into the same optimizer and into a freshly built one, as a resumed run does; mmcv
+    restores runner.iter -- and (b) add_param_group() after set_poly_schedule(); both used to restart the linear warm-up (or, with a
+    resolved `first_step`, ran the iteration negative).  Against torch.optim.AdamW driven with mmcv's rate of the global iteration."""
+    gen = torch.Generator().manual_seed(77)
+    init = [torch.randn(300, generator=gen), torch.randn(64, generator=gen), torch.randn(50, generator=gen)]
+    sch = dict(max_iters=40, power=1.0, min_lr=0.0, warmup_iters=9, warmup_ratio=1e-4)
+    mk = lambda ts: [torch.nn.Parameter(t.clone().to(device)) for t in ts]
+    mine = mk(init)
+    ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    o_mine = V.optim.AdamW([dict(params=mine[:2], lr=5e-3, weight_decay=0.01)])
+    o_ref = torch.optim.AdamW([dict(params=ref[:2], lr=5e-3, weight_decay=0.01)])
+    o_mine.set_poly_schedule(**sch)
+
+    def one(it, o_m, ps, n):
+        for p, q in zip(ps[:n], ref[:n]):
+            g = torch.randn(p.shape, generator=gen)
+            p.grad, q.grad = g.to(device), g.double()
+        for grp in o_ref.param_groups:
+            grp['lr'] = mmcv_poly_lr(5e-3, it, **sch)
+        o_ref.step()
+        o_m.step()
+
+    for it in range(4):
+        one(it, o_mine, mine, 2)
+    sd = copy.deepcopy(o_mine.state_dict())
+    assert sd['cffm_global_step'] == 4
+    o_mine.load_state_dict(sd)                       # (a) same optimizer
+    assert o_mine.global_step() == 4
+    for it in range(4, 6):
+        one(it, o_mine, mine, 2)
+    # (a') a new process: new parameters, new optimizer, schedule set before the first step, then the state loaded
+    sd = copy.deepcopy(o_mine.state_dict())
+    mine2 = mk([p.detach().cpu() for p in mine])
+    o2 = V.optim.AdamW([dict(params=mine2[:2], lr=5e-3, weight_decay=0.01)])
+    o2.set_poly_schedule(first_step=0, **sch)
+    o2.load_state_dict(sd)
+    for it in range(6, 8):
+        one(it, o2, mine2, 2)
+    # (b) a third tensor joins as a new group at iteration 8 (torch's reference gets the same group)
+    o2.add_param_group(dict(params=[mine2[2]], lr=5e-3, weight_decay=0.01))
+    o_ref.add_param_group(dict(params=[ref[2]], lr=5e-3, weight_decay=0.01))
+    assert o2.global_step() == 8
+    for it in range(8, 11):
+        one(it, o2, mine2, 3)
+    for p, q in zip(mine2, ref):
+        assert float((p.detach().cpu().double() - q.detach()).abs().max()) < 2e-6 * max(1.0, float(q.abs().max()))
+    # a dict written by torch.optim.AdamW carries no global step: the largest per-parameter count stands in
+    o3 = V.optim.AdamW([dict(params=mk(init)[:2], lr=5e-3, weight_decay=0.01)])
+    tsd = torch.optim.AdamW([dict(params=ref[:2], lr=5e-3)]).state_dict()
+    tsd['state'] = {0: dict(step=torch.tensor(7.), exp_avg=torch.zeros(300), exp_avg_sq=torch.zeros(300)),
+                    1: dict(step=torch.tensor(5.), exp_avg=torch.zeros(64), exp_avg_sq=torch.zeros(64))}
+    o3.load_state_dict(tsd)
+    assert o3.global_step() == 7
+
+
+def test_adamw_schedule_survives_resume_and_new_groups_emulated():
+    with emu.active():
+        run_adamw_schedule_survives_resume_and_new_groups(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_adamw_schedule_survives_resume_and_new_groups_gpu():
+    run_adamw_schedule_survives_resume_and_new_groups(torch.device('cuda'))
+
+
 def test_adamw_keeps_captured_tables_alive_when_a_new_row_reallocates_them():
     """a HIP graph captured around step() holds the raw addresses of the optimizer's device tables.  A parameter that gets its
     first gradient later adds a row and REPLACES those tables: the old ones must stay alive (a replay of the stale graph then writes into

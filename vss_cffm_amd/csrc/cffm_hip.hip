@@ -625,7 +625,7 @@ int cffm_pool_matrix(const float* const pool_w[4], float* M, void* stream) {
     return 0;
 }
 
-static int g_grad_pads = 0;
+static thread_local int g_grad_pads = 0;   // per calling thread (autograd runs one backward thread per device: ADVICE r4)
 void cffm_grad_slices_padded(int yes) { g_grad_pads = yes ? 1 : 0; }
 static int pool_matrix_bwd_impl(const float* dM, float* const dpool_w[4], float* const dpool_b[4], void* stream) {
     PROF(ST_POOLMAT);
@@ -1173,13 +1173,11 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     cffm_block_ws L;
     cffm_block_ws_layout(g, &L);
     const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
-    float* yraw = scratch;  // [NP,256] transient (proj output, later fc2 output)
     hipStream_t st = (hipStream_t)stream;
     // Hand-written GEMMs: the tensors only they read (zall, z2, act) are produced in split-4 storage and the weights come
     // from the split-4 copy k_param_prep made (ws.w_split), so no operand tile is split while it is staged -- except ao,
     // which the attention backward also reads.  CFFM_GEMM=lib (rocBLAS cross-check) keeps everything plain fp32.
     constexpr int sp = 1;   // split-4 storage of what only the GEMMs read (zall, z2, act, dh) and of the weights: always (the library-GEMM form that kept plain fp32 left in round 4)
-    const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
     // (a pending join with the side-stream parameter prep -- layer_forward_impl -- is taken AFTER this launch: the kernel builds its
     //  pooling-matrix rows from the raw weights then, and the chain's first kernel does not wait for another stream)
     const bool late_join = g_prep_join.pending;
@@ -1193,12 +1191,6 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
         PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
         REQUIRE(!panel_qkv_fwd(ws + L.zall, ws + L.w_frag, p->qkv_b, (h16*)(ws + L.qkv), NR, st), "block_forward: qkv gemm failed");
     }
-#ifdef CFFM_EXPERIMENTS   // the tiled q|k|v GEMM (rounds 1-2), CFFM_PANEL_QKV=0
-    else {
-        PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
-        REQUIRE(!gemm_nt_qkv16_split_pre(ws + L.zall, wq_s, p->qkv_b, (h16*)(ws + L.qkv), NR, 768, CFFM_C, st), "block_forward: qkv gemm failed");
-    }
-#endif
     TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, (const void*)(ws + L.bias), ws + L.ao, ws + L.lse, stream));
     if (sp && panel_on()) {
         // proj + residual + norm2 + Mlp in one row-panel launch (panel_kernels.h); weights in fragment order from k_param_prep
@@ -1211,29 +1203,8 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
         CHECK_LAUNCH("block_forward");
         return 0;
     }
-#ifdef CFFM_EXPERIMENTS   // the block as separate tiled GEMMs + row kernels (rounds 1-2), CFFM_PANEL=0
-    {
-        PROF(ST_GEMM); PROF2(ST_G_PROJ_FWD);
-        REQUIRE(!gemm_nt_split_pre<false>(ws + L.ao, wp_s, yraw, NP, CFFM_C, CFFM_C, st), "block_forward: proj gemm failed");
-    }
-    TRY(residual_ln_impl(x_tgt, tgt_bs, g->HW, yraw, p->proj_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2,
-                         ws + L.mean2, ws + L.rstd2, NP, sp, stream));
-    {
-        PROF(ST_GEMM); PROF2(ST_G_FC1_FWD);
-        REQUIRE(!gemm_nt_gelu_split_pre(ws + L.z2, w1_s, p->fc1_b, ws + L.hraw, ws + L.act, NP, CFFM_HID, CFFM_C, st),
-                "block_forward: fc1 gemm failed");
-    }
-    {
-        PROF(ST_GEMM); PROF2(ST_G_FC2_FWD);
-        REQUIRE(!gemm_nt_residual_split_pre(ws + L.act, w2_s, p->fc2_b, ws + L.x1, ws + L.x2, NP, CFFM_C, CFFM_HID, st),
-                "block_forward: fc2 gemm failed");
-    }
-    CHECK_LAUNCH("block_forward");
-    return 0;
-#else
-    (void)yraw; (void)wq_s; (void)wp_s; (void)w1_s; (void)w2_s;
+    (void)scratch;
     return fail(-3, "block_forward: unreachable");
-#endif
 }
 
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
@@ -1356,12 +1327,6 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         const size_t need = gemm_tn_group_partial_floats(all4, 4, 480);
         REQUIRE(!need || lib_scratch2(need), "block_backward: scratch allocation failed");
     }
-    const float* wq_s = ws + L.w_split, *wp_s = wq_s + 768 * 256, *w1_s = wp_s + 256 * 256, *w2_s = w1_s + 1024 * 256;
-#define DX_GEMM(FAM, PRE_DY, dy_, w_plain, w_s_, dx_, M_, N_, K_)                                                         \
-    do {                                                                                                                  \
-        PROF(ST_GEMM); PROF2(FAM);                                                                                        \
-        REQUIRE(!gemm_nn_split_pre<PRE_DY>(dy_, w_s_, dx_, M_, N_, K_, st), "block_backward: input-gradient gemm failed"); \
-    } while (0)
     // x2 = x1 + act W2^T + b2
     // act = gelu(hraw + b1); hraw = z2 W1^T: the GELU backward runs in the epilogue of the fc2 input-gradient GEMM (dact is
     // never materialised; what is stored is dh, in split-4 storage since only GEMMs read it, plus column-sum records of it)
@@ -1388,44 +1353,6 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             side_mark(sa, st, 0);
         }
     }
-#ifdef CFFM_EXPERIMENTS   // the block backward as separate tiled GEMMs + row kernels (rounds 1-2), CFFM_PANEL=0
-    else {
-        PROF(ST_GEMM); PROF2(ST_G_FC2_DX);
-        const int nrec = GEMM_GELUBWD_RECORDS(NP);
-        float* part = red_scratch((size_t)nrec * CFFM_HID, st);
-        REQUIRE(part, "block_backward: scratch allocation failed");
-        REQUIRE(!gemm_nn_gelubwd_split_pre<true>(dout, w2_s, ws + L.hraw, p->fc1_b, dact, part, NP, CFFM_C, CFFM_HID, st),
-                "block_backward: fc2 input-gradient gemm failed");
-        RedSegs segs;
-        segs.nseg = 0;
-        seg_add(segs, 0, CFFM_HID, gr->fc1_b, 0);
-        reduce_records(part, nrec, CFFM_HID, CFFM_HID, segs, st);
-        // (CFFM_DW_GROUP=split, the first round-2 form) first side branch: the weight gradients of fc1 (dh z2) and fc2 (dout act) --
-        // dh is complete, dout and the saved activations were there from the start -- run beside the rest of the chain
-        if (!one_group) {
-        sa = side_fork(st, 0);
-        void* stream_a = (void*)sa;
-        const cffm_wgrad wga[2] = {{dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C}, {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}};
-        const GemmTNPre prea[2] = {{1, 1, nullptr}, {0, (panel && !store_act()) ? 2 : 1, p->fc1_b}};
-        {
-            void* stream = stream_a;
-            PROF2(ST_G_DW);
-            REQUIRE(!gemm_tn_group((const GemmTN*)wga, 2, sa, prea, sa == st ? lib_scratch : lib_scratch2, 320), "block_backward: weight-gradient gemm failed");
-        }
-        side_mark(sa, st, 0);
-        }
-    }
-#endif
-#ifdef CFFM_EXPERIMENTS
-    if (!panel) {
-    DX_GEMM(ST_G_FC1_DX, true, dact, p->fc1_w, w1_s, dz2, NP, CFFM_HID, CFFM_C);
-    // z2 = LN2(x1); x1 also feeds the residual
-    TRY(cffm_ln_bwd_residual(ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, dz2, dout, dx1, gr->norm2_w, gr->norm2_b, NP, 1,
-                             gr->fc2_b /* = colsum(dout) */, gr->proj_b /* = colsum(dx1) */, stream));
-    // x1 = xt + ao Wp^T + bp
-    DX_GEMM(ST_G_PROJ_DX, false, dx1, p->proj_w, wp_s, dao, NP, CFFM_C, CFFM_C);
-    }
-#endif
     // attention: the fused kernel and the dK/dV gather stay on the chain; the bias-gradient tile sum and its scatter into the six
     // tables go to the side stream (branch 1), the q|k|v bias column sum and the weight gradients of q|k|v / proj after the gather
     // (branch 2)
@@ -1536,12 +1463,6 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
         REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st, qkv_rec), "block_backward: q|k|v input-gradient gemm failed");
     }
-#ifdef CFFM_EXPERIMENTS
-    else {
-        DX_GEMM(ST_G_QKV_DX, false, dqkv, p->qkv_w, wq_s, dzall, NR, 768, CFFM_C);
-    }
-#endif
-#undef DX_GEMM
     if (!one_group || dx_tgt == dout) side_join(sa, st, 0);    // fc2's weight gradient has read dout before an in-place ln_pool_bwd overwrites it
 #ifndef CFFM_EMU
     if (g_side.dw_pending[par ^ 1] && g_side.dw_dout[par ^ 1] == dx_tgt) {   // (depth >= 3: the block before still reads its dout = our dx_tgt)

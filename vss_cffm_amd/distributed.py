@@ -107,6 +107,7 @@ class BlockwiseReducer:
         self.pending, self.log = [], []
         self.accumulating = False      # this backward adds into pre-existing .grad tensors: nothing is exchanged block by block
         self.fallbacks = 0
+        self.drained = 0               # exchanges completed early (a second backward arrived before finish())
 
     def install(self, params=None):
         """``params``: the layer's parameters.  With them the reducer notices by itself -- at the first block of every backward --
@@ -134,17 +135,37 @@ class BlockwiseReducer:
             self.on_block(block, flat_slice, depth)
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.single_rank_too):
             return
-        if self.params is not None and not self.pending and not self.accumulating:
-            # First block of a backward.  The hook runs INSIDE the layer's autograd node, so .grad still shows the state before this
-            # backward: with gradients already there autograd will ADD the flat views into them once the node returns -- reading
-            # the views on the compute stream while an asynchronous in-place all-reduce of the same memory is under way would even
-            # race.  Nothing is exchanged block by block then; finish() exchanges the real .grad tensors once.
+        # First block of a backward: blocks come last-to-first, so it is block depth - 1 (callers of start() that do not pass the depth
+        # are recognised by the empty queue, as before).  The hook runs INSIDE the layer's autograd node, so .grad still shows the state
+        # before this backward: with gradients already there autograd will ADD the flat views into them once the node returns --
+        # nothing is exchanged block by block then, finish() exchanges the real .grad tensors once.  That also covers the SECOND
+        # backward of a gradient-accumulation step after zero_grad(set_to_none=True): the first one's slices were adopted as .grad and
+        # may still be mid all-reduce, so their exchange is completed here, before autograd adds into that memory (the
+        # detection used to be keyed to `not self.pending` and skipped exactly this case).  Averaged-then-accumulated gradients stay
+        # correct under finish()'s second average: avg_r(avg(g1) + g2_r) = avg(g1) + avg(g2).
+        first = (block == depth - 1) if depth else (not self.pending)
+        if self.params is not None and first and not self.accumulating:
             self.accumulating = any(p.grad is not None for p in self.params)
+            if self.accumulating and self.pending:
+                self._drain()
         if self.accumulating:
             return
         avg = self.average and dist.get_backend() == 'nccl' and hasattr(dist.ReduceOp, 'AVG')
         work = dist.all_reduce(flat_slice, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
         self.pending.append((work, flat_slice, self.average and not avg))
+
+    def _drain(self):
+        """Complete every pending exchange (stream-side wait for RCCL); -> the address spans that were exchanged."""
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        spans = []
+        for work, t, divide in self.pending:
+            work.wait()
+            if divide:
+                t.div_(world)
+            spans.append((t.data_ptr(), t.data_ptr() + 4 * t.numel()))
+        self.drained += len(self.pending)
+        self.pending = []
+        return spans
 
     def finish(self, params=None, on_mismatch='raise'):
         """Wait (stream-side for RCCL) for every exchange started since the last call; returns how many there were.
@@ -157,15 +178,8 @@ class BlockwiseReducer:
         exchanged raises (``on_mismatch='fallback'``: exchange those gradients now instead).  Without parameters nothing can be
         checked -- pass them."""
         params = list(params) if params is not None else self.params
-        n = len(self.pending)
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        spans = []
-        for work, t, divide in self.pending:
-            work.wait()
-            if divide:
-                t.div_(world)
-            spans.append((t.data_ptr(), t.data_ptr() + 4 * t.numel()))
-        self.pending = []
+        spans = self._drain()
+        n, self.drained = self.drained, 0
         if self.accumulating:
             self.accumulating = False
             self.fallbacks += 1

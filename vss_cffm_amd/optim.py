@@ -136,14 +136,40 @@ class AdamW(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ cache control
     def _reset_device_side(self):
+        """Drops the device rows and tables.  The optimizer's GLOBAL iteration (slot 10 of the constants, what the device-side
+        schedule counts from) survives: the rows made afterwards start from it, as mmcv's runner.iter survives a resume."""
+        carry = getattr(self, '_gstep0', 0)
+        for dr in getattr(self, '_devs', {}).values():
+            dr.sync_host()
+            carry = max(carry, dr.gstep)
+        self._gstep0 = carry
         self._devs = {}       # device -> _DeviceRows
         self._row_of = {}     # id(parameter) -> (device, row)
 
+    def global_step(self):
+        """The number of step() calls / replays so far (device rows consulted: it runs ahead of the host after graph replays)."""
+        g = getattr(self, '_gstep0', 0)
+        for dr in self._devs.values():
+            dr.sync_host()
+            g = max(g, dr.gstep)
+        return g
+
     def load_state_dict(self, state_dict):
         """The loaded moments are new tensors and the loaded step counts seed new device rows: every cached chunk table
-        (it holds raw addresses of the OLD moments) and the device-side step counts are dropped."""
+        (it holds raw addresses of the OLD moments) and the device-side step counts are dropped.  The global iteration is restored
+        from the dict's `cffm_global_step` (written by state_dict()); a dict from torch.optim.AdamW has none: the largest per-parameter
+        step count stands in (equal to it unless parameters sat steps out)."""
         super().load_state_dict(state_dict)
+        self._devs = {}
+        self._gstep0 = 0
         self._reset_device_side()
+        g = state_dict.get('cffm_global_step')
+        if g is None:
+            g = 0
+            for st in self.state.values():
+                t = st.get('step', 0)
+                g = max(g, int(t.item()) if torch.is_tensor(t) else int(t))
+        self._gstep0 = int(g)
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
@@ -167,7 +193,9 @@ class AdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         self._sync_steps()
-        return super().state_dict()
+        sd = super().state_dict()
+        sd['cffm_global_step'] = self.global_step()     # (torch's own load_state_dict ignores unknown top-level keys)
+        return sd
 
     # ------------------------------------------------------------------ helpers
     def _moments(self, p):
@@ -246,10 +274,7 @@ class AdamW(torch.optim.Optimizer):
         happens (default: the optimizer's next step).  ``set_poly_schedule(None)`` goes back to host-provided rates.
         Rows must exist (take one step first) -- or call it before the first step and it applies to the rows as they are made."""
         kind = 0.0 if max_iters is None else 1.0
-        gstep = 0
-        for dr in self._devs.values():
-            dr.sync_host()
-            gstep = max(gstep, dr.gstep)
+        gstep = self.global_step()
         first = float(gstep if first_step is None else first_step)       # resolved NOW, to the optimizer's global step (ADVICE r3)
         for dr in self._devs.values():
             if dr.consts is None:
@@ -284,6 +309,7 @@ class AdamW(torch.optim.Optimizer):
             if dr is None:
                 dr = self._devs[dev] = _DeviceRows(dev)
                 dr.schedule = getattr(self, '_pending_schedule', None)
+                dr.gstep = getattr(self, '_gstep0', 0)      # rows made after a reset / resume continue the global iteration
             fresh = [(gi, group, p) for gi, group, p in items if id(p) not in self._row_of]
             for gi, group, p in fresh:       # (rows are made before any table is looked up: a new row rebuilds the tables)
                 st = self._moments(p)
