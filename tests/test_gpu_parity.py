@@ -296,3 +296,68 @@ def test_layer_goldens_with_either_form_of_the_weight_gradient_groups_gpu(form):
                         'test_layer_against_reference_golden'], env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and '5 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_training_trajectory_against_oracle():
+    """BASELINE's metric says "mIoU parity", i.e. TRAINING with the HIP path must follow the reference's.  30 AdamW
+    steps of the B1 layer (depth 2) on a fixed synthetic batch, HIP path (f16 QK^T / AV operands, split-bf16 Linear layers, gradients
+    within 1.5e-3 of fp32: BWD_TOL) against the fp32 oracle + torch.optim.AdamW from identical initial parameters, under the reference's
+    optimizer settings (local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:35-44: AdamW lr 6e-5, betas (0.9, 0.999), weight decay
+    0.01, paramwise head x10 / norm decay 0, poly schedule power 1 with linear warm-up from ratio 1e-6 -- warm-up and horizon scaled
+    from 1500 / 160 k iterations to 10 / 100 so that 30 steps cross both regimes).  Gates: every step's loss within 1e-3 relative, the
+    final parameters within 2 % of the distance travelled, ||theta_hip - theta_oracle|| <= 0.02 ||theta_oracle - theta_0||."""
+    import vss_cffm_amd as V
+    from tests.test_optim import mmcv_poly_lr
+    depth, b, h, w, steps = 2, 1, 30, 30, 30
+    st0 = R.layer_state(depth, seed=11)
+    x = R.synth_input('x', (b, 4, 256, h, w), seed=12)
+    tgt = R.synth_input('t', (b, 256, h, w), seed=13, scale=1.0)
+    sch = dict(max_iters=100, power=1.0, min_lr=0.0, warmup_iters=10, warmup_ratio=1e-6)
+    full = lambda k: 'decode_head.decoder_focal.' + k
+    # --- HIP path
+    m = build_layer(depth, st0)
+    opt = V.optim.AdamW(V.optim.paramwise_groups([(full(k), p) for k, p in m.named_parameters()], base_lr=6e-5, base_wd=0.01))
+    opt.set_poly_schedule(**sch)
+    xg, tg = x.to(dev()), tgt.to(dev())
+    losses_hip = []
+    for it in range(steps):
+        opt.zero_grad(set_to_none=True)
+        y = m(xg)
+        loss = 0.5 * ((y[:, -1] - tg) ** 2).mean() * 256.0
+        loss.backward()
+        opt.step()
+        losses_hip.append(float(loss))
+    # --- oracle path: fp32 restatement + torch's AdamW, rates from mmcv's schedule of the same iteration
+    ps = {k: torch.nn.Parameter(v.clone()) for k, v in st0.items() if v.dtype.is_floating_point}
+    state = dict(st0)
+    state.update(ps)
+    groups = V.optim.paramwise_groups([(full(k), p) for k, p in ps.items()], base_lr=6e-5, base_wd=0.01)
+    base = [g_['lr'] for g_ in groups]
+    oref = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8)
+    losses_ref = []
+    for it in range(steps):
+        oref.zero_grad(set_to_none=True)
+        yo = O.layer_forward(x, state, depth)
+        loss = 0.5 * ((yo[:, -1] - tgt) ** 2).mean() * 256.0
+        loss.backward()
+        for g_, b0 in zip(oref.param_groups, base):
+            g_['lr'] = mmcv_poly_lr(b0, it, **sch)
+        oref.step()
+        losses_ref.append(float(loss))
+    worst_loss = max(abs(a - r) / abs(r) for a, r in zip(losses_hip, losses_ref))
+    num = den = 0.0
+    worst_t = ('', 0.0)
+    for k, p in m.named_parameters():
+        d = (p.detach().cpu().double() - ps[k].detach().double()).norm().item()
+        t = (ps[k].detach().double() - st0[k].double()).norm().item()
+        num += d * d
+        den += t * t
+        if t > 0 and d / t > worst_t[1]:
+            worst_t = (k, d / t)
+    drift = (num / den) ** 0.5
+    print('trajectory: loss %.4f -> %.4f (oracle %.4f -> %.4f), worst per-step loss deviation %.2e, parameter drift %.2e of the distance '
+          'travelled (%.3e), worst tensor %s %.2e' % (losses_hip[0], losses_hip[-1], losses_ref[0], losses_ref[-1], worst_loss, drift,
+                                                      den ** 0.5, worst_t[0], worst_t[1]))
+    assert losses_ref[-1] < losses_ref[0]
+    assert worst_loss < 1e-3, worst_loss
+    assert drift < 0.02, drift

@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(256) k_pool_matrix(PoolW pw, float* __restrict
 
 // dW_pool[grp][k] = sum_{g in grp, i} dM[g][i] * dM[g][i]/dw.  One wave per weight (111 weights): lanes over
 // the 49 pixels, loop over the group's cells, wave reduction.
-__global__ void __launch_bounds__(64) k_pool_matrix_bwd(const float* __restrict__ dM, PoolWG gw) {
-    const int t = blockIdx.x, i = threadIdx.x;
+__device__ __forceinline__ void pool_matrix_bwd_body(const float* __restrict__ dM, const PoolWG& gw, int t) {
+    const int i = threadIdx.x;
     int grp, k;
     if (t < 49) { grp = 0; k = t; }
     else if (t < 98) { grp = 1; k = t - 49; }
@@ -153,6 +153,11 @@ __global__ void __launch_bounds__(64) k_pool_matrix_bwd(const float* __restrict_
         for (int q = 0; q < 4; ++q) gw.b[q][1 + i] = 0.f;
     }
 }
+__global__ void __launch_bounds__(64) k_pool_matrix_bwd(const float* __restrict__ dM, PoolWG gw) { pool_matrix_bwd_body(dM, gw, blockIdx.x); }
+// the same for up to PMB_MAXD blocks in one launch (grid (111, n)): the end of a layer backward
+#define PMB_MAXD 4
+struct PoolWGN { const float* dM[PMB_MAXD]; PoolWG gw[PMB_MAXD]; };
+__global__ void __launch_bounds__(64) k_pool_matrix_bwd_n(PoolWGN a) { pool_matrix_bwd_body(a.dM[blockIdx.y], a.gw[blockIdx.y], blockIdx.x); }
 
 // --------------------------------------------------------------------------- geometry helpers
 struct Geo {
@@ -290,154 +295,303 @@ __global__ void __launch_bounds__(LNP_THREADS, 6) k_ln_pool_fwd(Geo G, const flo
 }
 
 // --------------------------------------------------------------------------- LN1 + pad + pool (backward)
-// Inputs: dzall (gradient of every token row: target tokens + pooled cells), dres (residual-path gradient
-// of the target frame, may be NULL).  Outputs: dx of the frame (NHWC; `accum_ref` adds to what is there) and
-// one partial record per workgroup, part[blk][LNP_REC] = dgamma[256] | dbeta[256] | dM[15*49] | dpool_bias[4]
-// (zeros outside this frame's cells); k_reduce_partials sums the records -- no contended atomics.
-#define LNP_REC (2 * CFFM_C + CFFM_NCELL * CFFM_WA + 4)
-#ifndef LNPB_BATCH
-#define LNPB_BATCH 4
+// Round 5: the CFFA backward is TWO kernels (it was one per block over all four frames: 96 MB per launch, 38 us alone / 81 us beside
+// the weight gradients, one workgroup per CU).
+//   k_ln_pool_bwd_tgt  per block, on the chain: the target frame only -- dx_tgt for the next block (reads x, dz of the target tokens,
+//                      the residual-path gradient; 30 MB at B = 2);
+//   k_ln_pool_bwd_ref  ONCE per layer backward (per range of blocks): the three reference frames of EVERY block of the range.
+//                      The reference frames pass through the layer unchanged (cffm_transformer.py:826), so every block normalises the
+//                      same x with the same statistics (:716) and the LayerNorm backward is linear in its upstream gradient:
+//                      dx_ref = LNbwd(x, sum_d gamma_d * dZ_d), with dZ_d = M_d^T dP_d expanded from block d's 14 pooled-cell
+//                      gradients per window (:780-805).  One read of x_ref and ONE write of dx_ref per step instead of a read +
+//                      read-modify-write per block; the per-block parameter gradients (norm1, pooling matrix, pool biases) come out
+//                      of the same pass.
+// Inputs: dzall (gradient of every token row of a block: target tokens + pooled cells), dres (residual-path gradient of the target
+// frame, may be NULL).  Every workgroup leaves one RECORD of LNP_RSTRIDE floats per block: dgamma[256] | dbeta[256] | tail, the tail
+// being dM[cell 0][49] | dpool_bias[0] for a target workgroup and dM[cells 1..14][49] | dpool_bias[1..3] for a reference workgroup;
+// k_reduce_records_multi sums them (cffm_hip.hip cffa_reduce) -- deterministic, no atomics.
+#define LNP_RSTRIDE 1216
+#define LNP_TAIL_TGT (CFFM_WA + 1)
+#define LNP_TAIL_REF (14 * CFFM_WA + 3)
+// a window's 49 pixels are dealt out to LNB_SPLIT workgroups of LNB_WAVES waves: pixel i belongs to workgroup i % LNB_SPLIT and there
+// to wave (i / LNB_SPLIT) % LNB_WAVES -- at most LNB_PIX pixels per wave, ALL of whose rows are requested before the first is consumed
+#ifndef LNB_SPLIT
+#define LNB_SPLIT 4
 #endif
+#ifndef LNB_WAVES
+#define LNB_WAVES 4
+#endif
+#define LNB_THREADS (64 * LNB_WAVES)
+#define LNB_PIX ((CFFM_WA + LNB_SPLIT * LNB_WAVES - 1) / (LNB_SPLIT * LNB_WAVES))
 #ifndef LNPB_ABLATE
 #define LNPB_ABLATE 0   // profiling builds only: 1 no dM reductions, 2 no LN reductions, 4 no dx stores
 #endif
-// body for a frame with NC pooled cells per window (1, 4 or 9: compile-time, so the per-cell loops unroll and their LDS
-// reads / wave reductions overlap instead of queueing behind each other)
-template <int NC>
-__device__ __forceinline__ void ln_pool_bwd_body(const Geo& G, const float* __restrict__ xf, float* __restrict__ dxf, bool accum,
-                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 const float* __restrict__ M, const float* __restrict__ mean_in,
-                                                 const float* __restrict__ rstd_in, const float* __restrict__ dzall,
-                                                 const float* __restrict__ dres, float* __restrict__ part, int g0, int w, int frame, int b) {
-    __shared__ float sM[NC * CFFM_WA];
-    __shared__ float sdP[NC][CFFM_C];
-    __shared__ float sdM[NC * CFFM_WA];
-    __shared__ float red[LNP_WAVES][2][CFFM_C];
-    __shared__ float sbs[LNP_WAVES];
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+// grid (B * nW * LNB_SPLIT), LNB_THREADS.  rec: [B * nW * LNB_SPLIT][LNP_RSTRIDE] (columns [0, 512 + LNP_TAIL_TGT) are written)
+__global__ void __launch_bounds__(LNB_THREADS) k_ln_pool_bwd_tgt(Geo G, const float* __restrict__ x_tgt, long tgt_bs,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ M, const float* __restrict__ mean_in,
+                                                                 const float* __restrict__ rstd_in, const float* __restrict__ dzall,
+                                                                 const float* __restrict__ dres, float* __restrict__ dx_tgt, long dtgt_bs,
+                                                                 float* __restrict__ rec) {
+    __shared__ float red[LNB_WAVES][2][CFFM_C];
+    __shared__ float sdM[CFFM_WA];
+    __shared__ float sbs;
+    const int s = blockIdx.x % LNB_SPLIT, wb = blockIdx.x / LNB_SPLIT;
+    const int w = wb % G.nW, b = wb / G.nW;
     const int wy = w / G.gx, wx = w % G.gx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < NC * CFFM_WA; e += LNP_THREADS) { sM[e] = M[g0 * CFFM_WA + e]; sdM[e] = 0.f; }
-    float bsum = 0.f;
-    for (int e = threadIdx.x; e < NC * CFFM_C; e += LNP_THREADS) {
-        const int c = e / CFFM_C, ch = e % CFFM_C;
-        const float v = dzall[((long)b * G.RC + cell_row(G, wy, wx, g0 + c)) * CFFM_C + ch];
-        sdP[c][ch] = v;
-        bsum += v;
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    const float* xf = x_tgt + (long)b * tgt_bs;
+    float* dxf = dx_tgt + (long)b * dtgt_bs;
+    if (threadIdx.x < CFFM_WA) sdM[threadIdx.x] = 0.f;
+    // every global read of the wave's pixels is requested here: x rows, LN statistics, the target-token gradients, the residual row
+    f32x4 xr[LNB_PIX], dzr[LNB_PIX], addr[LNB_PIX];
+    float mur[LNB_PIX], rsr[LNB_PIX], m0[LNB_PIX];
+#pragma unroll
+    for (int k = 0; k < LNB_PIX; ++k) {
+        const int i = s + LNB_SPLIT * (wave + LNB_WAVES * k);
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        xr[k] = dzr[k] = addr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mur[k] = rsr[k] = m0[k] = 0.f;
+        if (i < CFFM_WA && y < G.H0 && x < G.W0) {
+            const long pix = (long)y * G.W0 + x;
+            xr[k] = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
+            mur[k] = mean_in[((long)b * 4 + 3) * G.HW + pix];
+            rsr[k] = rstd_in[((long)b * 4 + 3) * G.HW + pix];
+            m0[k] = M[i];
+            dzr[k] = *(const f32x4*)(dzall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane);
+            if (dres) addr[k] = *(const f32x4*)(dres + ((long)b * G.HW + pix) * CFFM_C + 4 * lane);
+        }
     }
-    bsum = wave_sum(bsum);
-    if (lane == 0) sbs[wave] = bsum;
+    const f32x4 dp = *(const f32x4*)(dzall + ((long)b * G.RC + cell_row(G, wy, wx, 0)) * CFFM_C + 4 * lane);
     const f32x4 gm = *(const f32x4*)(gamma + 4 * lane), bt = *(const f32x4*)(beta + 4 * lane);
+    if (wave == 0) {
+        const float bs = wave_sum(dp[0] + dp[1] + dp[2] + dp[3]);
+        if (lane == 0) sbs = (s == 0) ? bs : 0.f;          // the window's pool-bias gradient is counted once
+    }
     f32x4 ag = (f32x4){0.f, 0.f, 0.f, 0.f}, ab = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // The wave's LNP_PIX pixels (12-13 with four waves, 6-7 with eight) go in batches of LNPB_BATCH = 4 (measured: 13 at once 47 us, 7: 42, 5: 34, 4: 30.5, 3: 30.8).  ALL global reads of a batch are requested before its first pixel
-    // is consumed: x rows, LN statistics, the target-token gradients, and the row that is added to the result (the
-    // residual-path gradient of the target frame, or the dx a later block already accumulated for a reference frame).
-    // Read inside the pixel loop that last row would sit between stores to the same array, where the compiler cannot hoist
-    // it -- one exposed memory round trip per pixel.  Small batches keep the kernel at three workgroups per CU.
     __syncthreads();
 #pragma unroll
-    for (int k0 = 0; k0 < LNP_PIX; k0 += LNPB_BATCH) {
-        f32x4 xr[LNPB_BATCH], dzr[LNPB_BATCH], addr[LNPB_BATCH];
-        float mur[LNPB_BATCH], rsr[LNPB_BATCH];
-#pragma unroll
-        for (int kk = 0; kk < LNPB_BATCH; ++kk) {
-            const int i = wave + LNP_WAVES * (k0 + kk);
-            const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
-            xr[kk] = dzr[kk] = addr[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mur[kk] = rsr[kk] = 0.f;
-            if (k0 + kk < LNP_PIX && i < CFFM_WA && y < G.H0 && x < G.W0) {
-                const long pix = (long)y * G.W0 + x;
-                xr[kk] = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
-                mur[kk] = mean_in[((long)b * 4 + frame) * G.HW + pix];
-                rsr[kk] = rstd_in[((long)b * 4 + frame) * G.HW + pix];
-                if (frame == 3) {
-                    dzr[kk] = *(const f32x4*)(dzall + ((long)b * G.RC + w * CFFM_WA + i) * CFFM_C + 4 * lane);
-                    if (dres) addr[kk] = *(const f32x4*)(dres + ((long)b * G.HW + pix) * CFFM_C + 4 * lane);
-                } else if (accum) {
-                    addr[kk] = *(const f32x4*)(dxf + pix * CFFM_C + 4 * lane);
-                }
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < LNPB_BATCH; ++kk) {
-            const int i = wave + LNP_WAVES * (k0 + kk);
-            if (k0 + kk >= LNP_PIX || i >= CFFM_WA) break;
-            const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
-            if (!((y < G.H0) && (x < G.W0))) continue;  // padded pixel: z is the constant 0
-            const long pix = (long)y * G.W0 + x;
-            const float rs = rsr[kk];
-            const f32x4 xh = (xr[kk] - mur[kk]) * rs;
-            const f32x4 z = xh * gm + bt;
-            f32x4 dz = dzr[kk];
-            float dm[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const f32x4 dp = *(const f32x4*)(&sdP[c][4 * lane]);
-                dz += sM[c * CFFM_WA + i] * dp;
-                dm[c] = dp[0] * z[0] + dp[1] * z[1] + dp[2] * z[2] + dp[3] * z[3];
-            }
+    for (int k = 0; k < LNB_PIX; ++k) {
+        const int i = s + LNB_SPLIT * (wave + LNB_WAVES * k);
+        if (i >= CFFM_WA) break;
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        if (!((y < G.H0) && (x < G.W0))) continue;      // padded pixel: z is the constant 0
+        const long pix = (long)y * G.W0 + x;
+        const float rs = rsr[k];
+        const f32x4 xh = (xr[k] - mur[k]) * rs;
+        const f32x4 z = xh * gm + bt;
+        const f32x4 dz = dzr[k] + m0[k] * dp;
 #if !(LNPB_ABLATE & 1)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dm[c] = wave_sum(dm[c]);   // independent chains: they overlap
-            if (lane == 0)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) sdM[c * CFFM_WA + i] = dm[c];   // pixel i belongs to exactly one wave: no conflict
+        const float dm = wave_sum_hi(dot4(dp, z));
+        if (lane == 63) sdM[i] = dm;                    // pixel i belongs to exactly one wave of one workgroup
 #endif
-            ag += dz * xh;
-            ab += dz;
-            const f32x4 gz = dz * gm;
+        ag += dz * xh;
+        ab += dz;
+        const f32x4 gz = dz * gm;
 #if LNPB_ABLATE & 2
-            const float m1 = gz[0], m2 = gz[1];
+        const float m1 = gz[0], m2 = gz[1];
 #else
-            const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
-            const float m2 = wave_sum(gz[0] * xh[0] + gz[1] * xh[1] + gz[2] * xh[2] + gz[3] * xh[3]) * (1.f / CFFM_C);
+        const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
+        const float m2 = wave_sum(dot4(gz, xh)) * (1.f / CFFM_C);
 #endif
-            const f32x4 dx = (gz - m1 - xh * m2) * rs + addr[kk];
+        const f32x4 dx = (gz - m1 - xh * m2) * rs + addr[k];
 #if LNPB_ABLATE & 4
-            ag += dx;
+        ag += dx;
 #else
-            *(f32x4*)(dxf + pix * CFFM_C + 4 * lane) = dx;
+        *(f32x4*)(dxf + pix * CFFM_C + 4 * lane) = dx;
 #endif
-        }
     }
     *(f32x4*)(&red[wave][0][4 * lane]) = ag;
     *(f32x4*)(&red[wave][1][4 * lane]) = ab;
     __syncthreads();
-    float* rec = part + ((long)(b * 4 + frame) * G.nW + w) * LNP_REC;
-    for (int e = threadIdx.x; e < 2 * CFFM_C; e += LNP_THREADS) {
+    float* r = rec + (long)blockIdx.x * LNP_RSTRIDE;
+    for (int e = threadIdx.x; e < 2 * CFFM_C; e += LNB_THREADS) {
         const int which = e / CFFM_C, ch = e % CFFM_C;
-        float t = (red[0][which][ch] + red[1][which][ch]) + (red[2][which][ch] + red[3][which][ch]);
-        if (LNP_WAVES == 8) t += (red[4][which][ch] + red[5][which][ch]) + (red[6][which][ch] + red[7][which][ch]);
-        rec[which * CFFM_C + ch] = t;
+        float t = red[0][which][ch];
+#pragma unroll
+        for (int q = 1; q < LNB_WAVES; ++q) t += red[q][which][ch];
+        r[e] = t;
     }
-    for (int e = threadIdx.x; e < CFFM_NCELL * CFFM_WA + 4; e += LNP_THREADS) {
-        float v = 0.f;
-        if (e < CFFM_NCELL * CFFM_WA) {
-            if (e >= g0 * CFFM_WA && e < (g0 + NC) * CFFM_WA) v = sdM[e - g0 * CFFM_WA];
-        } else if (e - CFFM_NCELL * CFFM_WA == frame_group(frame)) {
-            v = sbs[0] + sbs[1] + sbs[2] + sbs[3];
-            if (LNP_WAVES == 8) v += sbs[4] + sbs[5] + sbs[6] + sbs[7];
-        }
-        rec[2 * CFFM_C + e] = v;
-    }
-}
-// (one workgroup per CU at 140 VGPRs and 69 KB of LDS -- the three instantiations' arrays add up; sharing one set through a struct
-// measured 46 -> 55 us, capping the registers at 128 / 96 spills: 56 / 79 us)
-__global__ void __launch_bounds__(LNP_THREADS) k_ln_pool_bwd(Geo G, const float* __restrict__ x_ref, long ref_bs,
-                                                      const float* __restrict__ x_tgt, long tgt_bs,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ M, const float* __restrict__ mean_in,
-                                                      const float* __restrict__ rstd_in, const float* __restrict__ dzall,
-                                                      const float* __restrict__ dres,
-                                                      float* __restrict__ dx_ref, long dref_bs, int accum_ref,
-                                                      float* __restrict__ dx_tgt, long dtgt_bs, float* __restrict__ part) {
-    const int w = blockIdx.x, frame = blockIdx.y, b = blockIdx.z;
-    int g0, ncell;
-    frame_cells(frame, g0, ncell);
-    const float* xf = (frame == 3) ? x_tgt + (long)b * tgt_bs : x_ref + (long)b * ref_bs + (long)frame * G.HW * CFFM_C;
-    float* dxf = (frame == 3) ? dx_tgt + (long)b * dtgt_bs : dx_ref + (long)b * dref_bs + (long)frame * G.HW * CFFM_C;
-    const bool accum = (frame == 3) ? false : (accum_ref != 0);
-    if (ncell == 1) ln_pool_bwd_body<1>(G, xf, dxf, accum, gamma, beta, M, mean_in, rstd_in, dzall, dres, part, g0, w, frame, b);
-    else if (ncell == 4) ln_pool_bwd_body<4>(G, xf, dxf, accum, gamma, beta, M, mean_in, rstd_in, dzall, dres, part, g0, w, frame, b);
-    else ln_pool_bwd_body<9>(G, xf, dxf, accum, gamma, beta, M, mean_in, rstd_in, dzall, dres, part, g0, w, frame, b);
+    if (threadIdx.x < CFFM_WA) r[2 * CFFM_C + threadIdx.x] = sdM[threadIdx.x];
+    if (threadIdx.x == CFFM_WA) r[2 * CFFM_C + CFFM_WA] = sbs;
 }
 
+// The reference frames of up to RB_MAXD blocks in one pass.  grid (B * nW * LNB_SPLIT), LNB_THREADS; dynamic LDS: cffa_ref_lds(D).
+#define RB_MAXD 4
+struct CffaRefBlocks {
+    int n;                                   // blocks in this launch (1..RB_MAXD), any order
+    const float* gamma[RB_MAXD];
+    const float* beta[RB_MAXD];
+    const float* M[RB_MAXD];                 // the block's composed pooling matrix [15][49]
+    const float* dzall[RB_MAXD];             // the block's token-row gradient [B * RC][256] (its pooled-cell rows are read)
+    float* rec[RB_MAXD];                     // [B * nW * LNB_SPLIT][LNP_RSTRIDE] (columns [0, 512 + LNP_TAIL_REF) are written)
+};
+// floats of LDS per block: pooled-cell gradients of the 14 reference cells | their pooling-matrix rows | the dM rows of this workgroup
+#define RB_LDS_BLOCK (14 * CFFM_C + 2 * 14 * CFFM_WA)
+__host__ __device__ constexpr int cffa_ref_lds(int D) {
+    return 4 * ((D * RB_LDS_BLOCK > LNB_WAVES * D * 2 * CFFM_C + 14 * D * CFFM_WA ? D * RB_LDS_BLOCK : LNB_WAVES * D * 2 * CFFM_C + 14 * D * CFFM_WA) + 4 * D + 4);
+}
+
+// the rows of one reference frame a wave works on: requested as a whole (ln_pool_ref_load), consumed a frame later
+struct RefRows { f32x4 x[LNB_PIX], add[LNB_PIX]; float mu[LNB_PIX], rs[LNB_PIX]; };
+template <bool ACC>
+__device__ __forceinline__ void ln_pool_ref_load(RefRows& R, const Geo& G, const float* __restrict__ xf, const float* __restrict__ dxf,
+                                                 const float* __restrict__ mean_f, const float* __restrict__ rstd_f, int s, int wy, int wx,
+                                                 int lane, int wave) {
+#pragma unroll
+    for (int k = 0; k < LNB_PIX; ++k) {
+        const int i = s + LNB_SPLIT * (wave + LNB_WAVES * k);
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        R.x[k] = R.add[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        R.mu[k] = R.rs[k] = 0.f;
+        if (i < CFFM_WA && y < G.H0 && x < G.W0) {
+            const long pix = (long)y * G.W0 + x;
+            R.x[k] = *(const f32x4*)(xf + pix * CFFM_C + 4 * lane);
+            R.mu[k] = mean_f[pix];
+            R.rs[k] = rstd_f[pix];
+            if (ACC) R.add[k] = *(const f32x4*)(dxf + pix * CFFM_C + 4 * lane);
+        }
+    }
+}
+// one reference frame (NC cells per window, first cell g0 >= 1) of the workgroup's pixels, for all D blocks
+template <int NC, int D>
+__device__ __forceinline__ void ln_pool_bwd_ref_frame(const Geo& G, const RefRows& R, float* __restrict__ dxf,
+                                                      const float* sP, const float* sMm, float* sdM, const f32x4 (&gm)[D], const f32x4 (&bt)[D],
+                                                      f32x4 (&ag)[D], f32x4 (&ab)[D], int g0, int s, int wy, int wx, int lane, int wave) {
+#pragma unroll
+    for (int k = 0; k < LNB_PIX; ++k) {
+        const int i = s + LNB_SPLIT * (wave + LNB_WAVES * k);
+        if (i >= CFFM_WA) break;
+        const int y = 7 * wy + i / 7, x = 7 * wx + i % 7;
+        if (!((y < G.H0) && (x < G.W0))) continue;
+        const long pix = (long)y * G.W0 + x;
+        const float rs = R.rs[k];
+        const f32x4 xh = (R.x[k] - R.mu[k]) * rs;
+        f32x4 gz = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (the pooled-cell gradient rows are re-read from LDS for every pixel: hoisted out of the unrolled pixel loop they occupy 36
+        //  registers per block in the nine-cell frame -- 158 VGPRs at two blocks)
+        const float* sPk = sP + opaque_zero();
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const f32x4 z = xh * gm[d] + bt[d];
+            f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // cells in groups of (at most) three -- three LDS reads, three dot products, three overlapping wave reductions -- with the
+            // scheduler fenced between groups: left alone it issues every LDS read of the unrolled pixel body up front (159 VGPRs)
+#pragma unroll
+            for (int c0 = 0; c0 < NC; c0 += 3) {
+                float dm[3];
+#pragma unroll
+                for (int c = c0; c < c0 + 3 && c < NC; ++c) {
+                    const f32x4 dp = *(const f32x4*)(sPk + (d * 14 + g0 - 1 + c) * CFFM_C + 4 * lane);
+                    dz += sMm[(d * 14 + g0 - 1 + c) * CFFM_WA + i] * dp;
+                    dm[c - c0] = dot4(dp, z);
+                }
+#if !(LNPB_ABLATE & 1)
+#pragma unroll
+                for (int c = c0; c < c0 + 3 && c < NC; ++c) dm[c - c0] = wave_sum_hi(dm[c - c0]);   // independent chains: they overlap
+                if (lane == 63)
+#pragma unroll
+                    for (int c = c0; c < c0 + 3 && c < NC; ++c) sdM[(d * 14 + g0 - 1 + c) * CFFM_WA + i] = dm[c - c0];
+#endif
+                sched_fence();
+            }
+            ag[d] += dz * xh;
+            ab[d] += dz;
+            gz += dz * gm[d];
+        }
+#if LNPB_ABLATE & 2
+        const float m1 = gz[0], m2 = gz[1];
+#else
+        const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
+        const float m2 = wave_sum(dot4(gz, xh)) * (1.f / CFFM_C);
+#endif
+        const f32x4 dx = (gz - m1 - xh * m2) * rs + R.add[k];
+#if LNPB_ABLATE & 4
+        ag[0] += dx;
+#else
+        *(f32x4*)(dxf + pix * CFFM_C + 4 * lane) = dx;
+#endif
+    }
+}
+
+template <int D, bool ACC>
+__global__ void __launch_bounds__(LNB_THREADS) k_ln_pool_bwd_ref(Geo G, const float* __restrict__ x_ref, long ref_bs, CffaRefBlocks Bk,
+                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                 float* __restrict__ dx_ref, long dref_bs) {
+    CFFM_DYN_SMEM(smem);
+    float* sP = (float*)smem;                             // [D][14][256]
+    float* sMm = sP + D * 14 * CFFM_C;                    // [D][14][49]
+    float* red = (float*)smem;                            // [LNB_WAVES][D][2][256], reuses sP / sMm behind the pixel loops
+    constexpr int body = D * (14 * CFFM_C + 14 * CFFM_WA), redn = LNB_WAVES * D * 2 * CFFM_C;
+    float* sdM = (float*)smem + (body > redn ? body : redn);   // [D][14][49]
+    float* sbs = sdM + D * 14 * CFFM_WA;                  // [D][4]: pool-bias gradients of the three reference groups
+    const int s = blockIdx.x % LNB_SPLIT, wb = blockIdx.x / LNB_SPLIT;
+    const int w = wb % G.nW, b = wb / G.nW;
+    const int wy = w / G.gx, wx = w % G.gx;
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    for (int e = threadIdx.x; e < D * 14 * CFFM_WA; e += LNB_THREADS) {
+        const int d = e / (14 * CFFM_WA), r = e % (14 * CFFM_WA);
+        sMm[e] = Bk.M[d][CFFM_WA + r];
+        sdM[e] = 0.f;
+    }
+    // the 14 pooled-cell gradient rows of the window, per block (1 KiB rows, one wave per row)
+    for (int r = wave; r < D * 14; r += LNB_WAVES) {
+        const int d = r / 14, c = r % 14;
+        *(f32x4*)(sP + r * CFFM_C + 4 * lane) = *(const f32x4*)(Bk.dzall[d] + ((long)b * G.RC + cell_row(G, wy, wx, 1 + c)) * CFFM_C + 4 * lane);
+    }
+    f32x4 gm[D], bt[D], ag[D], ab[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        gm[d] = *(const f32x4*)(Bk.gamma[d] + 4 * lane);
+        bt[d] = *(const f32x4*)(Bk.beta[d] + 4 * lane);
+        ag[d] = ab[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (s == 0) {     // pool-bias gradients: sums over the group's cells and channels, counted once per window
+        for (int q = wave; q < 3 * D; q += LNB_WAVES) {
+            const int d = q / 3, grp = q % 3;
+            const int c0 = grp == 0 ? 0 : (grp == 1 ? 1 : 5), nc = grp == 0 ? 1 : (grp == 1 ? 4 : 9);
+            float t = 0.f;
+            for (int c = 0; c < nc; ++c) {
+                const f32x4 v = *(const f32x4*)(sP + (d * 14 + c0 + c) * CFFM_C + 4 * lane);
+                t += v[0] + v[1] + v[2] + v[3];
+            }
+            t = wave_sum(t);
+            if (lane == 0) sbs[d * 4 + grp] = t;
+        }
+    } else if (threadIdx.x < 4 * D) sbs[threadIdx.x] = 0.f;
+    const float* xb = x_ref + (long)b * ref_bs;
+    float* dxb = dx_ref + (long)b * dref_bs;
+    const long fr = (long)G.HW * CFFM_C;
+    const float* mb = mean_in + (long)b * 4 * G.HW;
+    const float* rb = rstd_in + (long)b * 4 * G.HW;
+    // the rows of frame f + 1 are requested before frame f is worked on
+    RefRows Ra, Rb;
+    ln_pool_ref_load<ACC>(Ra, G, xb, dxb, mb, rb, s, wy, wx, lane, wave);
+    ln_pool_ref_load<ACC>(Rb, G, xb + fr, dxb + fr, mb + G.HW, rb + G.HW, s, wy, wx, lane, wave);
+    ln_pool_bwd_ref_frame<1, D>(G, Ra, dxb, sP, sMm, sdM, gm, bt, ag, ab, 1, s, wy, wx, lane, wave);
+    ln_pool_ref_load<ACC>(Ra, G, xb + 2 * fr, dxb + 2 * fr, mb + 2 * G.HW, rb + 2 * G.HW, s, wy, wx, lane, wave);
+    ln_pool_bwd_ref_frame<4, D>(G, Rb, dxb + fr, sP, sMm, sdM, gm, bt, ag, ab, 2, s, wy, wx, lane, wave);
+    ln_pool_bwd_ref_frame<9, D>(G, Ra, dxb + 2 * fr, sP, sMm, sdM, gm, bt, ag, ab, 6, s, wy, wx, lane, wave);
+    __syncthreads();          // every wave is done with sP / sMm: red may overwrite them
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        *(f32x4*)(red + ((wave * D + d) * 2 + 0) * CFFM_C + 4 * lane) = ag[d];
+        *(f32x4*)(red + ((wave * D + d) * 2 + 1) * CFFM_C + 4 * lane) = ab[d];
+    }
+    __syncthreads();
+    for (int d = 0; d < D; ++d) {
+        float* r = Bk.rec[d] + (long)blockIdx.x * LNP_RSTRIDE;
+        for (int e = threadIdx.x; e < 2 * CFFM_C; e += LNB_THREADS) {
+            float t = red[(d * 2) * CFFM_C + e];
+#pragma unroll
+            for (int q = 1; q < LNB_WAVES; ++q) t += red[((q * D + d) * 2) * CFFM_C + e];
+            r[e] = t;
+        }
+        for (int e = threadIdx.x; e < LNP_TAIL_REF; e += LNB_THREADS)
+            r[2 * CFFM_C + e] = e < 14 * CFFM_WA ? sdM[d * 14 * CFFM_WA + e] : sbs[d * 4 + (e - 14 * CFFM_WA)];
+    }
+}

@@ -87,7 +87,10 @@ __device__ __forceinline__ float readlane_f32(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 #endif
-__device__ __forceinline__ float wave_sum(float v) {
+// the wave's sum, valid in lanes 48..63 ONLY (the other lanes hold partial sums): four DPP steps inside each 16-lane row, then row 0 / 2's
+// total goes to rows 1 / 3 (row_bcast:15) and the lower half's to the upper (row_bcast:31) -- six VALU instructions; the round 1-4 form
+// read the four row totals with v_readlane and added them (eleven)
+__device__ __forceinline__ float wave_sum_hi(float v) {
 #ifdef CFFM_EMU
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
@@ -96,7 +99,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
     v += dpp_f32<0x141>(v);   // row_half_mirror
     v += dpp_f32<0x140>(v);   // row_mirror
-    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+    // (spelled out: from the update_dpp builtin with a row mask hipcc makes v_mov 0 + v_mov_dpp + v_add, three instructions per step;
+    //  a DPP source written by the previous VALU instruction needs two wait states, which the hazard recognizer does not insert
+    //  inside inline assembly)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return v;
+#endif
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#ifdef CFFM_EMU
+    return wave_sum_hi(v);
+#else
+    return readlane_f32(wave_sum_hi(v), 63);
 #endif
 }
 // sum over each aligned group of 16 lanes (a DPP "row"), result in every lane of the group
@@ -469,6 +484,18 @@ __device__ __forceinline__ float fast_exp(float x) {
 #else
     return __expf(x);
 #endif
+}
+
+// A zero the compiler cannot see through: `p + opaque_zero()` is an address it must treat as new at this point, so loads through it are
+// not hoisted out of the surrounding (unrolled) loop and kept in registers -- used where re-reading LDS per iteration is cheaper than the
+// registers the hoisted values would occupy.  (Laundering the POINTER itself loses its LDS address space: hipcc then emits flat accesses
+// and an illegal V_CMP on src_shared_base.)
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+#ifndef CFFM_EMU
+    asm volatile("" : "+v"(z));
+#endif
+    return z;
 }
 
 // a value that is the same in every lane of the wave, handed to the compiler as such (an SGPR): buffer-instruction scalar

@@ -58,12 +58,12 @@ enum { ST_TRANSPOSE, ST_POOLMAT, ST_LN_POOL_FWD, ST_LN_POOL_BWD, ST_BIAS_ASM, ST
        ST_GEMM, ST_COLSUM, ST_RES_LN, ST_LN_BWD, ST_GELU, ST_GELU_BWD, ST_RES_OUT, ST_GTC_FWD, ST_GTC_BWD, ST_LN, ST_ADAMW, ST_NULL_PAIR,
        // per-kernel-family stages of the block (bench.py's `roofline_kernels`); the ST_GEMM / ST_ATTN_BWD totals above stay
        ST_G_QKV_FWD, ST_G_PROJ_FWD, ST_G_FC1_FWD, ST_G_FC2_FWD, ST_G_FC2_DX, ST_G_FC1_DX, ST_G_PROJ_DX, ST_G_QKV_DX, ST_G_DW,
-       ST_ATTN_BWD_Q, ST_ATTN_BWD_KV, ST_DKV_GATHER, ST_MLP_FWD, ST_MLP_BWD, ST_COUNT };
+       ST_ATTN_BWD_Q, ST_ATTN_BWD_KV, ST_DKV_GATHER, ST_MLP_FWD, ST_MLP_BWD, ST_LN_POOL_BWD_REF, ST_COUNT };
 static const char* const k_stage_names[ST_COUNT] = {"transpose", "pool_matrix", "ln_pool_fwd", "ln_pool_bwd", "bias_assemble",
     "bias_scatter", "cfm_attn_fwd", "cfm_attn_bwd", "linear_gemm", "colsum", "residual_ln", "ln_bwd", "bias_gelu", "gelu_bwd",
     "residual_out", "gtc_attn_fwd", "gtc_attn_bwd", "layernorm", "adamw", "event_pair_null",
     "gemm_qkv_fwd", "gemm_proj_fwd", "gemm_fc1_fwd", "gemm_fc2_fwd", "gemm_fc2_dx_gelu", "gemm_fc1_dx", "gemm_proj_dx", "gemm_qkv_dx",
-    "gemm_dw_group", "attn_bwd_fused", "attn_bwd_bias_sum", "attn_dkv_gather", "mlp_fwd_fused", "mlp_bwd_fused"};
+    "gemm_dw_group", "attn_bwd_fused", "attn_bwd_bias_sum", "attn_dkv_gather", "mlp_fwd_fused", "mlp_bwd_fused", "ln_pool_bwd_ref"};
 #ifndef CFFM_EMU
 #include <vector>
 struct ProfRec { int stage; hipEvent_t e0, e1; };
@@ -658,28 +658,166 @@ int cffm_ln_pool_fwd(const cffm_geom* g, const float* x_ref, long ref_bs, const 
     return ln_pool_fwd_impl(g, x_ref, ref_bs, x_tgt, tgt_bs, gamma, beta, M, pool_b, zall, mean, rstd, 0, stream);
 }
 
+// ---- CFFA backward (cffa_kernels.h): target frame per block, reference frames once per range of blocks ------------------------------
+static long cffa_rows(const cffm_geom* g) { return (long)g->B * g->nW * LNB_SPLIT; }     // records per kernel launch and block
+static int ln_pool_bwd_tgt(const cffm_geom* g, const float* x_tgt, long tgt_bs, const float* gamma, const float* beta, const float* M,
+                           const float* mean, const float* rstd, const float* dzall, const float* dres, float* dx_tgt, long dtgt_bs,
+                           float* rec, void* stream) {
+    PROF(ST_LN_POOL_BWD);
+    CFFM_LAUNCH(k_ln_pool_bwd_tgt, ((unsigned)cffa_rows(g)), (LNB_THREADS), 0, (hipStream_t)stream, to_geo(g), x_tgt, tgt_bs, gamma, beta, M, mean, rstd,
+                dzall, dres, dx_tgt, dtgt_bs, rec);
+    CHECK_LAUNCH("ln_pool_bwd_tgt");
+    return 0;
+}
+extern "C++" {
+template <int D>
+static int ln_pool_bwd_ref_d(const cffm_geom* g, const float* x_ref, long ref_bs, const CffaRefBlocks& Bk, const float* mean, const float* rstd,
+                             float* dx_ref, long dref_bs, int accum, hipStream_t st) {
+    constexpr int lds = cffa_ref_lds(D);
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted && lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k_ln_pool_bwd_ref<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_ln_pool_bwd_ref<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
+        granted = true;
+    }
+#endif
+    if (accum) CFFM_LAUNCH((k_ln_pool_bwd_ref<D, true>), ((unsigned)cffa_rows(g)), (LNB_THREADS), lds, st, to_geo(g), x_ref, ref_bs, Bk, mean, rstd, dx_ref, dref_bs);
+    else CFFM_LAUNCH((k_ln_pool_bwd_ref<D, false>), ((unsigned)cffa_rows(g)), (LNB_THREADS), lds, st, to_geo(g), x_ref, ref_bs, Bk, mean, rstd, dx_ref, dref_bs);
+    return 0;
+}
+}  // extern "C++"
+// the reference frames of Bk.n <= RB_MAXD blocks; accum: dx_ref already holds the share of blocks handled earlier
+static int ln_pool_bwd_ref(const cffm_geom* g, const float* x_ref, long ref_bs, const CffaRefBlocks& Bk, const float* mean, const float* rstd,
+                           float* dx_ref, long dref_bs, int accum, void* stream) {
+    PROF(ST_LN_POOL_BWD_REF);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = -1;
+    switch (Bk.n) {
+        case 1: rc = ln_pool_bwd_ref_d<1>(g, x_ref, ref_bs, Bk, mean, rstd, dx_ref, dref_bs, accum, st); break;
+        case 2: rc = ln_pool_bwd_ref_d<2>(g, x_ref, ref_bs, Bk, mean, rstd, dx_ref, dref_bs, accum, st); break;
+        case 3: rc = ln_pool_bwd_ref_d<3>(g, x_ref, ref_bs, Bk, mean, rstd, dx_ref, dref_bs, accum, st); break;
+        case 4: rc = ln_pool_bwd_ref_d<4>(g, x_ref, ref_bs, Bk, mean, rstd, dx_ref, dref_bs, accum, st); break;
+        default: break;
+    }
+    REQUIRE(!rc, "ln_pool_bwd_ref: bad block count %d or LDS grant failed", Bk.n);
+    CHECK_LAUNCH("ln_pool_bwd_ref");
+    return 0;
+}
+// The three record sums of one block (its target records in rec[0, rows), its reference records in rec[rows, 2 rows)): norm1's
+// dgamma | dbeta over both, the target tail (dM cell 0, pool bias 0), the reference tail (dM cells 1..14, pool biases 1..3) -- appended
+// to J (launched when it is full; the caller launches the rest with redq_launch).
+static void job_add(RedJobs& J, const float* part, int nblk, int stride, int total, const RedSegs& segs, hipStream_t st) {
+    if (J.njob == RED_MAXJOB) redq_launch(J, st);
+    const int j = J.njob++;
+    J.part[j] = part; J.nblk[j] = nblk; J.stride[j] = stride; J.total[j] = total; J.segs[j] = segs;
+    J.blk_end[j] = (j ? J.blk_end[j - 1] : 0) + (total + 63) / 64;
+}
+static void cffa_jobs(RedJobs& J, const float* rec, long rows, float* dgamma, float* dbeta, float* dM, float* const dpool_b[4], hipStream_t st) {
+    RedSegs a, b, c;
+    a.nseg = b.nseg = c.nseg = 0;
+    seg_add(a, 0, CFFM_C, dgamma, 0);
+    seg_add(a, CFFM_C, CFFM_C, dbeta, 0);
+    job_add(J, rec, (int)(2 * rows), LNP_RSTRIDE, 2 * CFFM_C, a, st);
+    seg_add(b, 0, CFFM_WA, dM, 0);
+    seg_add(b, CFFM_WA, 1, dpool_b[0], 0);
+    job_add(J, rec + 2 * CFFM_C, (int)rows, LNP_RSTRIDE, LNP_TAIL_TGT, b, st);
+    seg_add(c, 0, 14 * CFFM_WA, dM + CFFM_WA, 0);
+    for (int i = 1; i < 4; ++i) seg_add(c, 14 * CFFM_WA + i - 1, 1, dpool_b[i], 0);
+    job_add(J, rec + rows * LNP_RSTRIDE + 2 * CFFM_C, (int)rows, LNP_RSTRIDE, LNP_TAIL_REF, c, st);
+}
+
 int cffm_ln_pool_bwd(const cffm_geom* g, const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs,
                      const float* gamma, const float* beta, const float* M, const float* mean, const float* rstd,
                      const float* dzall, const float* dres, float* dx_ref, long dref_bs, int accum_ref,
                      float* dx_tgt, long dtgt_bs, float* dgamma, float* dbeta, float* dM, float* const dpool_b[4],
                      void* stream) {
-    PROF(ST_LN_POOL_BWD);
+    REQUIRE(g && x_ref && x_tgt && gamma && beta && M && mean && rstd && dzall && dx_ref && dx_tgt && dgamma && dbeta && dM && dpool_b, "ln_pool_bwd: null");
     hipStream_t st = (hipStream_t)stream;
-    PoolBG pb;
-    for (int i = 0; i < 4; ++i) pb.b[i] = dpool_b[i];
-    const int nblk = g->nW * 4 * g->B;
-    float* part = red_scratch((size_t)nblk * LNP_REC, st);
-    REQUIRE(part, "ln_pool_bwd: scratch allocation failed");
-    CFFM_LAUNCH(k_ln_pool_bwd, (g->nW, 4, g->B), (LNP_THREADS), 0, st, to_geo(g), x_ref, ref_bs, x_tgt, tgt_bs, gamma, beta, M, mean, rstd,
-                dzall, dres, dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, part);
-    RedSegs segs;
-    segs.nseg = 0;
-    seg_add(segs, 0, CFFM_C, dgamma, 0);
-    seg_add(segs, CFFM_C, CFFM_C, dbeta, 0);
-    seg_add(segs, 2 * CFFM_C, CFFM_NCELL * CFFM_WA, dM, 0);
-    for (int i = 0; i < 4; ++i) seg_add(segs, 2 * CFFM_C + CFFM_NCELL * CFFM_WA + i, 1, pb.b[i], 0);
-    reduce_records(part, nblk, LNP_REC, LNP_REC, segs, st);
+    const long rows = cffa_rows(g);
+    float* rec = red_scratch((size_t)2 * rows * LNP_RSTRIDE, st);
+    REQUIRE(rec, "ln_pool_bwd: scratch allocation failed");
+    TRY(ln_pool_bwd_tgt(g, x_tgt, tgt_bs, gamma, beta, M, mean, rstd, dzall, dres, dx_tgt, dtgt_bs, rec, stream));
+    CffaRefBlocks Bk;
+    Bk.n = 1;
+    for (int d = 0; d < RB_MAXD; ++d) { Bk.gamma[d] = gamma; Bk.beta[d] = beta; Bk.M[d] = M; Bk.dzall[d] = dzall; Bk.rec[d] = rec + rows * LNP_RSTRIDE; }
+    TRY(ln_pool_bwd_ref(g, x_ref, ref_bs, Bk, mean, rstd, dx_ref, dref_bs, accum_ref, stream));
+    RedJobs J;
+    J.njob = 0;
+    cffa_jobs(J, rec, rows, dgamma, dbeta, dM, dpool_b, st);
+    redq_launch(J, st);
     CHECK_LAUNCH("ln_pool_bwd");
+    return 0;
+}
+
+// Library-owned state of the CFFA backward, one SLOT per block of the layer: the block's token-row gradient dzall (written by the q|k|v
+// input-gradient GEMM, its pooled-cell rows are read again by the reference pass at the end of the range), the records of its target
+// and reference workgroups, its pooling-matrix gradient.
+static float* g_scr4 = nullptr;
+static size_t g_scr4_floats = 0;
+static float* lib_scratch4(size_t nfloats) {
+    if (nfloats <= g_scr4_floats) return g_scr4;
+#ifdef CFFM_EMU
+    free(g_scr4);
+    g_scr4 = (float*)malloc(nfloats * sizeof(float));
+#else
+    if (g_scr4) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr4); }
+    if (hipMalloc((void**)&g_scr4, nfloats * sizeof(float)) != hipSuccess) g_scr4 = nullptr;
+#endif
+    g_scr4_floats = g_scr4 ? nfloats : 0;
+    return g_scr4;
+}
+struct CffaSlot { float* dzall; float* rec; float* dM; };
+static int cffa_slot(const cffm_geom* g, int slot, int nslots, CffaSlot* o) {
+    const long a = up((long)g->B * g->RC * CFFM_C), b = up(2 * cffa_rows(g) * LNP_RSTRIDE), c = up(CFFM_NCELL * CFFM_WA);
+    float* base = lib_scratch4((size_t)(a + b + c) * nslots);
+    REQUIRE(base && slot >= 0 && slot < nslots, "cffa: scratch allocation failed");
+    float* p = base + (a + b + c) * slot;
+    o->dzall = p; o->rec = p + a; o->dM = p + a + b;
+    return 0;
+}
+// End of a range of block backwards (blocks first, first - 1, ..., last of a layer with `nslots` blocks; block i's parameters / gradients
+// at params[i] / grads[i], its workspace at ws0 + i * ws_stride): the reference frames of all of them in one pass (RB_MAXD blocks per
+// launch) -> dx_ref, then every CFFA parameter gradient of the range: norm1, the pooling matrix -> the pooling Linears, the pool biases.
+static int cffa_finish(const cffm_geom* g, int nslots, const cffm_block_params* params, const cffm_block_grads* grads, int first, int last,
+                       const float* ws0, long ws_stride, const float* x_ref, long ref_bs, float* dx_ref, long dref_bs, int accum, void* stream) {
+    cffm_block_ws L;
+    cffm_block_ws_layout(g, &L);
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = cffa_rows(g);
+    static_assert(PMB_MAXD == RB_MAXD, "one pooling-matrix launch per reference launch");
+    for (int hi = first; hi >= last; hi -= RB_MAXD) {
+        const int n = hi - last + 1 < RB_MAXD ? hi - last + 1 : RB_MAXD;
+        CffaRefBlocks Bk;
+        PoolWGN pw;
+        RedJobs J;
+        Bk.n = n; J.njob = 0;
+        for (int d = 0; d < RB_MAXD; ++d) {
+            const int i = hi - (d < n ? d : 0);
+            CffaSlot S;
+            TRY(cffa_slot(g, i, nslots, &S));
+            Bk.gamma[d] = params[i].norm1_w; Bk.beta[d] = params[i].norm1_b; Bk.M[d] = ws0 + i * ws_stride + L.M;
+            Bk.dzall[d] = S.dzall; Bk.rec[d] = S.rec + rows * LNP_RSTRIDE;
+            pw.dM[d] = S.dM;
+            for (int q = 0; q < 4; ++q) { pw.gw[d].w[q] = grads[i].pool_w[q]; pw.gw[d].b[q] = g_grad_pads ? grads[i].pool_b[q] : nullptr; }
+        }
+        // (the LayerNorm statistics of the reference frames are the same in every block: any block's saved copy serves)
+        const float* ws = ws0 + (long)hi * ws_stride;
+        TRY(ln_pool_bwd_ref(g, x_ref, ref_bs, Bk, ws + L.mean1, ws + L.rstd1, dx_ref, dref_bs, accum || hi != first, stream));
+        for (int d = 0; d < n; ++d) {
+            const int i = hi - d;
+            CffaSlot S;
+            TRY(cffa_slot(g, i, nslots, &S));
+            cffa_jobs(J, S.rec, rows, grads[i].norm1_w, grads[i].norm1_b, S.dM, grads[i].pool_b, st);
+        }
+        redq_launch(J, st);
+        CHECK_LAUNCH("cffa reductions");
+        {
+            PROF(ST_POOLMAT);
+            CFFM_LAUNCH(k_pool_matrix_bwd_n, (111, n), (64), 0, st, pw);
+            CHECK_LAUNCH("pool_matrix_bwd");
+        }
+    }
     return 0;
 }
 
@@ -1210,13 +1348,13 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                                const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
                                const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
-                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, void* stream);
+                               float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, int slot, int nslots, void* stream);
 // The parameter-gradient tail of a block backward (record reductions, pooling-matrix backward), LAUNCHED LATE: its fork point is the end
 // of ln_pool_bwd (event fork[3]), but the launches happen only after the chain's next kernel has been launched (tail_flush), so that
 // under stream capture the chain's kernel is ln_pool_bwd's FIRST dependant and keeps its place on the graph's first stream (the graph
 // executor hands every further dependant of a node the next stream, see side_fork_mark).
 #ifndef CFFM_EMU
-static struct { bool has, cs; RedJobs jobs; float* dM; const cffm_block_grads* gr; int parity; } g_tail = {false, false, {}, nullptr, nullptr, 0};
+static struct { bool has, cs; RedJobs jobs; int parity; } g_tail = {false, false, {}, 0};
 // on_main (end of a layer backward): the optimizer is what waits for these gradients, so they are the chain now -- launched on the
 // caller's stream itself, in front of everything else that follows the last ln_pool_bwd
 // `on` (fork_order bit 6): a side stream that is already ordered behind the ln_pool_bwd in question (the NEXT block's weight-gradient
@@ -1229,7 +1367,6 @@ static int tail_flush(hipStream_t st, bool on_main = false, hipStream_t on = nul
         g_tail.cs = false;
         redq_launch(g_tail.jobs, s3);
         CHECK_LAUNCH("block_backward reductions");
-        TRY(pool_matrix_bwd_impl(g_tail.dM, g_tail.gr->pool_w, g_grad_pads ? g_tail.gr->pool_b : nullptr, (void*)s3));
         side_record(s3, st, g_side.tail_done[g_tail.parity]);
         g_side.tail_pending[g_tail.parity] = true;
         return 0;
@@ -1242,7 +1379,6 @@ static int tail_flush(hipStream_t st, bool on_main = false, hipStream_t on = nul
     g_tail.cs = false;
     redq_launch(g_tail.jobs, s3);
     CHECK_LAUNCH("block_backward reductions");
-    TRY(pool_matrix_bwd_impl(g_tail.dM, g_tail.gr->pool_w, g_grad_pads ? g_tail.gr->pool_b : nullptr, (void*)s3));
     if (s3 != st) {
         side_record(s3, st, g_side.tail_done[g_tail.parity]);
         g_side.tail_pending[g_tail.parity] = true;
@@ -1267,8 +1403,10 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
                         const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
                         const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
                         float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, void* stream) {
-    return block_backward_impl(g, p, gr, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_ref, dref_bs, accum_ref,
-                               dx_tgt, dtgt_bs, scratch, 0, 0, stream);
+    REQUIRE(x_ref && dx_ref, "block_backward: null");
+    TRY(block_backward_impl(g, p, gr, x_ref, ref_bs, x_tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_tgt, dtgt_bs, scratch, 0, 0, 0, 1,
+                            stream));
+    return cffa_finish(g, 1, p, gr, 0, 0, ws, 0, x_ref, ref_bs, dx_ref, dref_bs, accum_ref, stream);
 }
 // `defer` (layer backward, round 3): the call returns with this block's parameter-gradient tail (partial-slab sums, record reductions,
 // pooling-matrix backward, bias-table scatter) still running on the side streams; the caller's stream has only waited for what reads
@@ -1278,7 +1416,7 @@ int cffm_block_backward(const cffm_geom* g, const cffm_block_params* p, const cf
 static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, const cffm_block_grads* gr,
                                const float* x_ref, long ref_bs, const float* x_tgt, long tgt_bs, const int* key_src,
                                const int* q_dst, const int* inv_ptr, const int* inv_idx, const float* ws, const float* dout,
-                               float* dx_ref, long dref_bs, int accum_ref, float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, void* stream) {
+                               float* dx_tgt, long dtgt_bs, float* scratch, int defer, int par, int slot, int nslots, void* stream) {
     REQUIRE(g && p && gr && ws && dout && scratch, "block_backward: null");
     {
         static int defer_env = -1;   // CFFM_DEFER_JOIN=0: every block ends fully joined (round-2 behaviour; A/B measurements)
@@ -1291,16 +1429,14 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
     par = (defer && par) ? 1 : 0;
     const long altb = S.alt, altact = altb + up(NP * CFFM_C), altqkv = altact + up(NP * CFFM_HID), altbias = altqkv + up(NR * 768);
-    const long altdM = altbias + up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD);
     float* dx1 = scratch + (par ? altb : S.b);
     float* dz2 = scratch + S.dz2;
     float* dao = scratch + S.dao;
     float* dact = scratch + (par ? altact : S.dact);
     float* dqkv = scratch + (par ? altqkv : S.dqkv);
-    float* dzall = scratch + S.dzall;
-    // (dM too: a block's record reductions + pooling-matrix backward may still run on the side stream when the NEXT block's run -- the last
-    //  block's even on the caller's stream; found by the depth-3 captured-step test at 14 x 14, where the kernels are short enough to collide)
-    float* dM = scratch + (par ? altdM : S.dM);
+    CffaSlot cffa;           // library-owned: this block's dzall lives until the reference pass at the end of the range (cffa_finish)
+    TRY(cffa_slot(g, slot, nslots, &cffa));
+    float* dzall = cffa.dzall;
     float* dbiasT = scratch + (par ? altbias : S.dbiasT);
     RedScope reductions((hipStream_t)stream);   // the four parameter-gradient reductions below run as one launch (finish())
     hipStream_t st = (hipStream_t)stream;
@@ -1470,10 +1606,11 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         g_side.dw_pending[par ^ 1] = false;
     }
 #endif
-    // CFFA
-    TRY(cffm_ln_pool_bwd(g, x_ref, ref_bs, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1,
-                         dx_ref, dref_bs, accum_ref, dx_tgt, dtgt_bs, gr->norm1_w, gr->norm1_b, dM, gr->pool_b, stream));
-    // the record reductions (every block-partial record of this backward is written by now) and the pooling-matrix backward:
+    // CFFA, target frame: dx_tgt for the next block + this block's target records.  The reference frames of every block of the range
+    // follow in ONE pass at its end (cffa_finish): they need this block's pooled-cell rows of dzall and nothing else.
+    TRY(ln_pool_bwd_tgt(g, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1, dx_tgt, dtgt_bs, cffa.rec,
+                        stream));
+    // the record reductions (every block-partial record of this backward except the CFFA's is written by now):
     // parameter gradients only -> side stream (branch 3); the caller's stream then waits for the side stream once
 #ifndef CFFM_EMU
     if (defer && sp && sb != st && s1 != st && g_side.on && (fork_order() & 32)) {
@@ -1481,7 +1618,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         side_fork_mark(st, 3);
         if (s1 != sb) side_order(s1, sb);
         (void)hipEventRecord(g_side.tail_order, sb);
-        g_tail.has = true; g_tail.jobs = g_rq.jobs; g_tail.dM = dM; g_tail.gr = gr; g_tail.parity = g_red_parity;
+        g_tail.has = true; g_tail.jobs = g_rq.jobs; g_tail.parity = g_red_parity;
         g_rq.jobs.njob = 0; g_rq.active = false;
         g_side.dw_pending[par] = true;
         g_side.dw_dout[par] = dout;
@@ -1495,7 +1632,6 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     if (sp && s1 != st && s3 != st && s1 != s3) side_order(s1, s3);   // (four side streams: branch 1 joins through branch 3)
     reductions.finish_on(s3);
     CHECK_LAUNCH("block_backward reductions");
-    TRY(pool_matrix_bwd_impl(dM, gr->pool_w, g_grad_pads ? gr->pool_b : nullptr, (void*)s3));
 #ifndef CFFM_EMU
     if (defer && sp && sb != st && s3 != st) {
         // (no wait for the weight-gradient GEMMs: the next block works in the other scratch set; whoever reuses THIS set, or writes
@@ -1935,9 +2071,11 @@ int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_par
         const long dtgt_bs = (i == 0) ? 4 * img : img;
         // the last block reads the caller's gradient directly
         const float* dout = (i == depth - 1) ? dy_rows : scratch + (((depth - 1 - i) & 1) ? S.a2 : S.a);
-        TRY(block_backward_impl(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dx_rows,
-                                4 * img, i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
+        TRY(block_backward_impl(g, &params[i], &grads[i], x_rows, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dout, dtgt, dtgt_bs,
+                                scratch, 1, (depth - 1 - i) & 1, i, depth, stream));
     }
+    // the reference frames of every block in one pass + the CFFA parameter gradients, then the last block's parameter-gradient tail
+    TRY(cffa_finish(g, depth, params, grads, depth - 1, 0, blk0, L.total, x_rows, 4 * img, dx_rows, 4 * img, 0, stream));
     TRY(tail_flush((hipStream_t)stream, tail_on_main()));
     side_join_all((hipStream_t)stream);
     return 0;
@@ -2043,9 +2181,14 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
         float* dcur = scratch + (((depth - 1 - i) & 1) ? S.a2 : S.a);
         float* dtgt = (i == 0) ? dxs + 3 * img : scratch + (((depth - i) & 1) ? S.a2 : S.a);
         const long dtgt_bs = (i == 0) ? 4 * img : img;
-        TRY(block_backward_impl(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dcur, dxs, 4 * img,
-                                i != depth - 1, dtgt, dtgt_bs, scratch, 1, (depth - 1 - i) & 1, stream));
+        TRY(block_backward_impl(g, &params[i], &grads[i], xs, 4 * img, tgt, tgt_bs, key_src, q_dst, inv_ptr, inv_idx, ws, dcur, dtgt, dtgt_bs, scratch,
+                                1, (depth - 1 - i) & 1, i, depth, stream));
     }
+    // The reference frames of every block of the range in ONE pass (they pass through the layer unchanged: one read of x_ref, one write
+    // of dx_ref per range instead of a read + read-modify-write per block) and the range's CFFA parameter gradients.  A caller that
+    // walks the layer block by block (data-parallel training, BlockwiseReducer) gets a pass per block, accumulating into dx_ref, so
+    // that every block's gradient slice is complete when its range returns.
+    TRY(cffa_finish(g, depth, params, grads, first_block, last_block, blk0, L.total, xs, 4 * img, dxs, 4 * img, first_block != depth - 1, stream));
     // (dy_full: the upstream gradient of the whole [B,4,C,H,W] output -- its pass-through frames 0..2 join dx in the same pass)
     if (last_block == 0) {
         // the last block's parameter-gradient tail stays on the caller's stream, in front of the output transpose: no fork behind the

@@ -286,31 +286,32 @@ struct RedSegs {
     int accumulate[RED_MAXSEG];
     float* out[RED_MAXSEG];
 };
-__global__ void __launch_bounds__(1024) k_reduce_records(const float* __restrict__ part, int nblk, int stride, int total, RedSegs segs) {
-    __shared__ float red[16][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;   // 16 waves: each sums every 16th record
-    const int c = blockIdx.x * 64 + cx;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < total) {
-        int b = ry;
-        for (; b + 112 < nblk; b += 128) {   // 8 independent loads in flight per lane
-            const float v0 = part[(long)b * stride + c], v1 = part[(long)(b + 16) * stride + c];
-            const float v2 = part[(long)(b + 32) * stride + c], v3 = part[(long)(b + 48) * stride + c];
-            const float v4 = part[(long)(b + 64) * stride + c], v5 = part[(long)(b + 80) * stride + c];
-            const float v6 = part[(long)(b + 96) * stride + c], v7 = part[(long)(b + 112) * stride + c];
-            s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+// One 64-column slab of one record set (round 5): a lane owns FOUR consecutive columns (16-byte loads; `part`, `stride` and the column
+// offsets of every caller are multiples of 4 floats, and rows are at least ceil4(total) long), a quarter-wave one record, so the 16
+// waves have 64 records in flight per step and four steps per lane in the air -- the round 1-4 form walked one column per lane, 16
+// records per step, and took 8-10 us for the ~1600 records of a CFFA backward.  Fixed summation order: deterministic.
+__device__ __forceinline__ void reduce_records_body(const float* __restrict__ part, int nblk, int stride, int total, const RedSegs& segs, int blk,
+                                                    float (*red)[64]) {
+    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c4 = blk * 64 + 4 * (lane & 15), slot = 4 * ry + (lane >> 4);
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (c4 < total) {
+        const float* p = part + c4;
+        int b = slot;
+        for (; b + 192 < nblk; b += 256) {
+            const f32x4 v0 = *(const f32x4*)(p + (long)b * stride), v1 = *(const f32x4*)(p + (long)(b + 64) * stride);
+            const f32x4 v2 = *(const f32x4*)(p + (long)(b + 128) * stride), v3 = *(const f32x4*)(p + (long)(b + 192) * stride);
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
         }
-        for (; b + 48 < nblk; b += 64) {
-            s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 16) * stride + c];
-            s2 += part[(long)(b + 32) * stride + c]; s3 += part[(long)(b + 48) * stride + c];
-        }
-        for (; b < nblk; b += 16) s0 += part[(long)b * stride + c];
+        for (; b < nblk; b += 64) s0 += *(const f32x4*)(p + (long)b * stride);
     }
-    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    *(f32x4*)(&red[slot][4 * (lane & 15)]) = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (ry == 0 && c < total) {
+    const int c = blk * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && c < total) {
         float v = 0.f;
-        for (int k = 0; k < 16; ++k) v += red[k][cx];
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) v += red[k][threadIdx.x];
         for (int k = 0; k < segs.nseg; ++k)
             if (c >= segs.off[k] && c < segs.off[k] + segs.width[k]) {
                 float* o = segs.out[k] + (c - segs.off[k]);
@@ -318,10 +319,15 @@ __global__ void __launch_bounds__(1024) k_reduce_records(const float* __restrict
             }
     }
 }
+__global__ void __launch_bounds__(1024) k_reduce_records(const float* __restrict__ part, int nblk, int stride, int total, RedSegs segs) {
+    __shared__ float red[64][64];
+    reduce_records_body(part, nblk, stride, total, segs, blockIdx.x, red);
+}
 
-// The same for up to RED_MAXJOB record sets in one launch: the block backward defers its four reductions (fc1 bias /
-// LN2 + fc2/proj bias / q|k|v bias / LN1 + pooling) to its end -- none of their results is read earlier.
-#define RED_MAXJOB 4
+// The same for up to RED_MAXJOB record sets in one launch: the block backward defers its reductions (fc1 bias / LN2 + fc2/proj bias /
+// q|k|v bias) to its end, the layer backward those of the CFFA (LN1 + pooling) to the end of the range -- none of their results is read
+// earlier.
+#define RED_MAXJOB 6
 struct RedJobs {
     int njob;
     int blk_end[RED_MAXJOB];        // exclusive prefix of 64-column workgroups per job
@@ -330,44 +336,13 @@ struct RedJobs {
     RedSegs segs[RED_MAXJOB];
 };
 __global__ void __launch_bounds__(1024) k_reduce_records_multi(RedJobs J) {
-    __shared__ float red[16][64];
+    __shared__ float red[64][64];
     int blk = blockIdx.x, j = 0;
 #pragma unroll
     for (int q = 0; q < RED_MAXJOB - 1; ++q)
         if (q + 1 < J.njob && blk >= J.blk_end[q]) j = q + 1;
     if (j > 0) blk -= J.blk_end[j - 1];
-    const float* __restrict__ part = J.part[j];
-    const int nblk = J.nblk[j], stride = J.stride[j], total = J.total[j];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blk * 64 + cx;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < total) {
-        int b = ry;
-        for (; b + 112 < nblk; b += 128) {   // 8 independent loads in flight per lane
-            const float v0 = part[(long)b * stride + c], v1 = part[(long)(b + 16) * stride + c];
-            const float v2 = part[(long)(b + 32) * stride + c], v3 = part[(long)(b + 48) * stride + c];
-            const float v4 = part[(long)(b + 64) * stride + c], v5 = part[(long)(b + 80) * stride + c];
-            const float v6 = part[(long)(b + 96) * stride + c], v7 = part[(long)(b + 112) * stride + c];
-            s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
-        }
-        for (; b + 48 < nblk; b += 64) {
-            s0 += part[(long)b * stride + c]; s1 += part[(long)(b + 16) * stride + c];
-            s2 += part[(long)(b + 32) * stride + c]; s3 += part[(long)(b + 48) * stride + c];
-        }
-        for (; b < nblk; b += 16) s0 += part[(long)b * stride + c];
-    }
-    red[ry][cx] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (ry == 0 && c < total) {
-        float v = 0.f;
-        for (int k = 0; k < 16; ++k) v += red[k][cx];
-        const RedSegs& segs = J.segs[j];
-        for (int k = 0; k < segs.nseg; ++k)
-            if (c >= segs.off[k] && c < segs.off[k] + segs.width[k]) {
-                float* o = segs.out[k] + (c - segs.off[k]);
-                *o = segs.accumulate[k] ? *o + v : v;
-            }
-    }
+    reduce_records_body(J.part[j], J.nblk[j], J.stride[j], J.total[j], J.segs[j], blk, red);
 }
 
 // --------------------------------------------------------------------------- act = gelu(hraw + b1)
