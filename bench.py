@@ -279,6 +279,86 @@ def head_step(dev, b, steps=10, multi=False, rank=0):
     return out
 
 
+def gtc_step(dev, b, ks=(8, 100), steps=20):
+    """BASELINE config 5 (CFFM++-B1 480x480 T=4 + K global-context prototype tokens): forward + backward of the prototype layer
+    `decoder_swin` (BasicLayer_cluster, pvt/swin_transformer_2d.py:1103-1148) on b clips x 60 x 60 target tokens against K prototypes,
+    K = 8 (the BASELINE config) and K = 100 (the reference's own default, cffm_head.py:217) -- `gtc_step` in the JSON line, a context
+    number like `head_step` (not `value`).  One library call per direction since round 5 (cffm_gtc_block_forward / _backward)."""
+    import ctypes as C
+    import vss_cffm_amd as V
+    from vss_cffm_amd import _lib
+    lib = _lib.get()
+    nst = lib.cffm_profile_stage_count()
+    names = [lib.cffm_profile_stage_name(i).decode() for i in range(nst)]
+    ms_buf, n_buf = (C.c_float * nst)(), (C.c_int * nst)()
+    out = {'workload': 'decoder_swin (BasicLayer_cluster, depth 1) forward + backward: %d clips x 3600 tokens x 256 channels against K prototypes per clip; '
+                       'median of %d steps, launched eagerly and replayed from one HIP graph (ms_per_step = the faster)' % (b, steps)}
+    torch.manual_seed(0)
+    m = V.BasicLayer_cluster(dim=256, depth=1, num_heads=8, window_size=7).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(b, GRID * GRID, 256, generator=gen) * 1.5).to(dev).requires_grad_(True)
+    gy = torch.randn(b, GRID * GRID, 256, generator=gen).to(dev)
+    for k in ks:
+        c = torch.randn(b, k, 256, generator=gen).to(dev).requires_grad_(True)
+
+        def step():
+            for p in m.parameters():
+                p.grad = None
+            x.grad = c.grad = None
+            y = m(x, GRID, GRID, c)[0]
+            y.backward(gy)
+
+        def timed(fn):
+            ts = []
+            for _ in range(steps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            return ts[len(ts) // 2]
+        for _ in range(3):
+            step()
+        eager_ms = timed(step)
+        graph_ms, note = None, None
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            for _ in range(3):
+                g.replay()
+            graph_ms = timed(g.replay)
+        except Exception as ex:   # noqa: BLE001  (information only: the eager number stands)
+            note = 'graph capture failed: %s' % str(ex).splitlines()[0][:160]
+            torch.cuda.synchronize(dev)
+        # per-stage HIP-event times of one eager step (each interval includes ~2-3 us of event-record cost)
+        lib.cffm_profile_enable(-1)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        lib.cffm_profile_enable(0)
+        lib.cffm_profile_collect(ms_buf, n_buf)
+        fam = ('layernorm', 'linear_gemm', 'gemm_dw_group', 'gtc_attn_fwd', 'gtc_attn_bwd', 'mlp_fwd_fused', 'mlp_bwd_fused', 'ln_bwd', 'colsum')
+        kern = {names[i]: round(1e3 * ms_buf[i] / 5, 1) for i in range(nst) if n_buf[i] and names[i] in fam}
+        ms = eager_ms if graph_ms is None else min(eager_ms, graph_ms)
+        flops = 4.0 * b * GRID * GRID * 8 * k * 32                      # QK^T + AV, SURVEY 8(d): 32.5 MFLOP per clip at K = 8
+        e = {'ms_per_step': round(ms, 4), 'clips_per_s': round(b * 1e3 / ms, 1), 'eager_ms': round(eager_ms, 4),
+             'graph_replay_ms': None if graph_ms is None else round(graph_ms, 4), 'attention_mflop_fwd': round(flops / 1e6, 1),
+             'stage_us_per_step': kern}
+        if note:
+            e['graph_note'] = note
+        out['K=%d' % k] = e
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -293,6 +373,7 @@ def main():
     ap.add_argument('--ddp', action='store_true', help='wrap in torch DistributedDataParallel instead of the one-buffer all-reduce')
     ap.add_argument('--spinup-steps', type=int, default=1000, help='untimed device spin-up steps before the warmup steps (~1 s)')
     ap.add_argument('--no-head-step', action='store_true', help='skip the whole-head training step reported as `head_step`')
+    ap.add_argument('--no-gtc-step', action='store_true', help='skip the CFFM++ prototype-layer step (BASELINE config 5) reported as `gtc_step`')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -699,6 +780,12 @@ def main():
         except Exception as e:   # noqa: BLE001  (context only: never costs the headline)
             hs_all = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
 
+    gs = None
+    if rank == 0 and not args.no_gtc_step:
+        try:
+            gs = gtc_step(dev, b)
+        except Exception as e:   # noqa: BLE001  (context only: never costs the headline)
+            gs = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
     if rank == 0:
         nw, hw = ((GRID + 6) // 7) ** 2, GRID * GRID
         stages = {}
@@ -764,7 +851,7 @@ def main():
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
                        'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'ranks_in_sync': ranks_in_sync, 'params_finite': params_finite, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else (nonlocal_note[-1] if nonlocal_note else 'graph(forward + backward of block 1) | all-reduce(block 1) overlapping graph(backward of block 0) | all-reduce(block 0) | graph(AdamW)')),
                        'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one asynchronous all-reduce per block of the flat gradient buffer, overlapped with the backward of the next block') if multi else 'none'},
-            'roofline': roof, 'roofline_kernels': rk, 'head_step': hs,
+            'roofline': roof, 'roofline_kernels': rk, 'head_step': hs, 'gtc_step': gs,
             'rccl': {'world': world, 'backend': (dist.get_backend() if multi else None)}, 'collective': collective,
             'tolerance': {'forward': 5e-4, 'gradients': 2e-3, 'contract': 1e-3,
                           'note': 'max|a-b|/max|b| vs the reference (tests/test_gpu_parity.py): forward measured 1.3-1.6e-4; gradients '

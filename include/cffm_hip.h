@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 6
+#define CFFM_ABI_VERSION 7
 
 typedef struct cffm_geom {
     int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
@@ -181,6 +181,28 @@ int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw,
 int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, const float* o,
                       const float* dout, const float* lse, float* dq_raw, float* dkv /* overwritten */, int B, int T, int K,
                       void* stream);
+
+/* The whole block of the CFFM++ prototype layer in one call per direction (round 5, ABI 7; replaces the ~33 stage launches a caller
+ * had to sequence): SwinTransformerBlock_cluster.forward, pvt/swin_transformer_2d.py:605-665, shift 0, with
+ * WindowAttention_cluster.forward :208-262 inside (only_use_cluster_center_as_context, :216: no in-window keys, no position bias, no mask
+ * -- window partition / padding are numerically no-ops, SURVEY.md A "GTC is window-independent").
+ *   x [B,T,256] tokens, centers [B,K,256] prototypes (1 <= K <= 256), out [B,T,256]; `ws`: cffm_gtc_ws_floats(B, T, K) floats, written
+ *   by the forward and read (and extended) by the backward of the same call pair.
+ * Parameter order = the reference's state_dict of `decoder_swin.blocks.0`: norm1, attn.qkv (only its first 256 rows / entries -- the q
+ * third -- are used and receive a gradient; the rest of the gradient is written as zeros), attn.qkv_cluster, attn.proj_cluster, norm2,
+ * mlp.fc1, mlp.fc2.  (attn.proj and attn.relative_position_bias_table exist in the reference module but receive no gradient: not here.) */
+typedef struct {
+    const float *norm1_w, *norm1_b, *qkv_w /* [768,256] */, *qkv_b /* [768] */, *kv_w /* [512,256] */, *kv_b /* [512] */, *proj_w, *proj_b,
+        *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} cffm_gtc_params;
+typedef struct {
+    float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *kv_w, *kv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} cffm_gtc_grads;
+long cffm_gtc_ws_floats(int B, int T, int K);
+int cffm_gtc_block_forward(const cffm_gtc_params* p, const float* x, const float* centers, float* out, float* ws, int B, int T, int K,
+                           void* stream);
+int cffm_gtc_block_backward(const cffm_gtc_params* p, const cffm_gtc_grads* g, const float* x, const float* centers, const float* dout,
+                            float* dx, float* dcenters, float* ws, int B, int T, int K, void* stream);
 
 /* ---- SegFormer embedding in front of the hot path, without the 1024-channel concat ----
  * Replaces cffm_head.py:102-119 (4 x `MLP` embed, 3 x bilinear resize to the 1/4 map, torch.cat, 1x1 `linear_fuse.conv`):

@@ -361,3 +361,11 @@ def test_training_trajectory_against_oracle():
     assert losses_ref[-1] < losses_ref[0]
     assert worst_loss < 1e-3, worst_loss
     assert drift < 0.02, drift
+
+
+@pytest.mark.parametrize('b,h,w,k', [(1, 5, 7, 1), (2, 9, 9, 6), (1, 10, 13, 130), (2, 60, 60, 100)])
+def test_gtc_block_vs_oracle_odd_prototype_counts_gpu(b, h, w, k):
+    """The fused CFFM++ block (cffm_gtc_block_forward / _backward) against the oracle: K = 1, K not a multiple of 4, K > 128 (32-token
+    chunks of the attention backward), and the reference's default K = 100 at the full 60 x 60 size."""
+    from tests.test_emu_kernels import run_gtc_vs_oracle
+    run_gtc_vs_oracle(dev(), b, h, w, k)

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, ci, cl, cd, cf = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
 
@@ -31,7 +31,14 @@ class BlockWs(C.Structure):
                                   'rstd2', 'z2', 'hraw', 'act', 'x2', 'w_split', 'w_frag', 'total')]
 
 
+class GtcPtrs(C.Structure):
+    """cffm_gtc_params / cffm_gtc_grads (same field order)."""
+    _fields_ = [(n, vp) for n in ('norm1_w', 'norm1_b', 'qkv_w', 'qkv_b', 'kv_w', 'kv_b', 'proj_w', 'proj_b', 'norm2_w', 'norm2_b',
+                                  'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')]
+
+
 GP, BP = C.POINTER(Geom), C.POINTER(BlockPtrs)
+GTP = C.POINTER(GtcPtrs)
 P4 = vp * 4
 
 SIGNATURES = {
@@ -87,6 +94,9 @@ SIGNATURES = {
     'cffm_layer_backward_full': (ci, [GP, ci, BP, BP, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
     'cffm_gtc_attn_fwd': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_gtc_attn_bwd': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    'cffm_gtc_ws_floats': (cl, [ci, ci, ci]),
+    'cffm_gtc_block_forward': (ci, [GTP, vp, vp, vp, vp, ci, ci, ci, vp]),
+    'cffm_gtc_block_backward': (ci, [GTP, GTP, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'cffm_segfuse_fwd': (ci, [vp, vp, vp * 3, ci * 3, ci * 3, ci, ci, ci, ci, vp]),
     'cffm_segfuse_bwd': (ci, [vp, vp * 3, ci * 3, ci * 3, ci, ci, ci, ci, vp]),
     'cffm_seg_counts': (ci, [vp, vp, cl, ci, ci, ci, vp, vp]),

@@ -1113,7 +1113,7 @@ int cffm_adamw_step_rows(const cffm_adamw_chunk2* chunks, int nchunks, const flo
 int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
                        long nrows, void* stream) {
     PROF(ST_LN);
-    CFFM_LAUNCH(k_layernorm, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, x, gamma, beta, z, mean, rstd, nrows);
+    CFFM_LAUNCH(k_layernorm, ((unsigned)((nrows + 3) / 4)), (256), 0, (hipStream_t)stream, x, gamma, beta, z, mean, rstd, nrows, 0);
     CHECK_LAUNCH("layernorm_fwd");
     return 0;
 }
@@ -1121,9 +1121,16 @@ int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, float* o, float* lse,
                       int B, int T, int K, void* stream) {
     PROF(ST_GTC_FWD);
-    REQUIRE(K >= 1 && K <= 512, "gtc_attn_fwd: K=%d outside 1..512", K);
-    CFFM_LAUNCH(k_gtc_attn_fwd, ((T + GTC_TOK - 1) / GTC_TOK, CFFM_HEADS, B), (256), (size_t)2 * K * CFFM_HD * sizeof(float),
-                (hipStream_t)stream, q_raw, q_b, kv_raw, kv_b, o, lse, T, K);
+    REQUIRE(K >= 1 && K <= 256, "gtc_attn_fwd: K=%d outside 1..256", K);
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted) {
+        REQUIRE(hipFuncSetAttribute((const void*)k_gtc_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, gtf_lds(256)) == hipSuccess, "gtc_attn_fwd: LDS grant failed");
+        granted = true;
+    }
+#endif
+    CFFM_LAUNCH(k_gtc_attn_fwd, ((T + GTC_TOK - 1) / GTC_TOK, CFFM_HEADS, B), (256), (size_t)gtf_lds(K), (hipStream_t)stream, q_raw, q_b, kv_raw, kv_b, o,
+                lse, T, K);
     CHECK_LAUNCH("gtc_attn_fwd");
     return 0;
 }
@@ -1132,10 +1139,19 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
                       const float* dout, const float* lse, float* dq_raw, float* dkv, int B, int T, int K, void* stream) {
     PROF(ST_GTC_BWD);
     hipStream_t st = (hipStream_t)stream;
-    REQUIRE(K >= 1 && K <= 256, "gtc_attn_bwd: K=%d outside 1..256", K);
-    hipMemsetAsync(dkv, 0, (size_t)B * K * 512 * sizeof(float), st);
-    CFFM_LAUNCH(k_gtc_attn_bwd, ((T + GTC_TOK - 1) / GTC_TOK, CFFM_HEADS, B), (256), (size_t)4 * K * CFFM_HD * sizeof(float), st, q_raw,
-                q_b, kv_raw, kv_b, o, dout, lse, dq_raw, dkv, T, K);
+    REQUIRE(K >= 1 && K <= 256 && B >= 1 && T >= 1, "gtc_attn_bwd: K=%d outside 1..256", K);
+    const int per = gtb_tok(K) * GTB_CHUNKS, nwg = (T + per - 1) / per;
+    float* rec = lib_scratch((size_t)B * CFFM_HEADS * nwg * K * 64);       // one [K][64] record per workgroup: k_gtc_dkv_sum adds them in order
+    REQUIRE(rec, "gtc_attn_bwd: scratch allocation failed");
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted) {
+        REQUIRE(hipFuncSetAttribute((const void*)k_gtc_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "gtc_attn_bwd: LDS grant failed");
+        granted = true;
+    }
+#endif
+    CFFM_LAUNCH(k_gtc_attn_bwd, (nwg, CFFM_HEADS, B), (256), (size_t)gtb_lds(K), st, q_raw, q_b, kv_raw, kv_b, o, dout, lse, dq_raw, rec, T, K);
+    CFFM_LAUNCH(k_gtc_dkv_sum, (K, CFFM_HEADS, B), (64), 0, st, (const float*)rec, nwg, K, dkv);
     CHECK_LAUNCH("gtc_attn_bwd");
     return 0;
 }
@@ -1256,6 +1272,150 @@ int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const fl
     seg_add(s2, 3 * CFFM_C, CFFM_C, dbp, 0);
     reduce_records(a.rec_ln, nrec, 1024, 1024, s2, st);
     CHECK_LAUNCH("mlp_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- CFFM++ (GTC) block, fused (round 5)
+// SwinTransformerBlock_cluster.forward (pvt/swin_transformer_2d.py:605-665) with shift 0 and only_use_cluster_center_as_context (:216):
+//   z = LN1(x), cn = LN1(centers) (:619-622);  q = (z Wq^T + bq) 32^-0.5, q third of `qkv` only (:219-226);  [Kc|Vc] = cn Wkv^T + bkv
+//   (:223-224);  o = softmax_K(q Kc^T) Vc (:232-257);  x1 = x + o Wpc^T + bpc (:258, :662);  x2 = x1 + fc2(GELU(fc1(LN2(x1)))) (:663).
+// Round 1-4 sequenced ~13 forward / ~20 backward stage launches from Python (vss_cffm_amd/ops.py).  Now ONE entry point per
+// direction, built from the base head's kernels: the q projection and its input gradient are row-panel GEMMs (k_panel_gemm), everything
+// from proj_cluster to the block output is the fused Mlp launch of the base block (k_mlp_fwd / k_mlp_bwd: same shapes), the four large
+// weight gradients are one grouped launch (k_gemm_group_tt), every bias / norm gradient is a record reduction in one launch.
+struct GtcWs {     // float offsets into the caller's workspace: what the forward keeps for the backward, then the backward's temporaries
+    long z, mean1, rstd1, cn, cmean, crstd, qraw, kvraw, ao, lse, x1, z2, mean2, rstd2, hraw, act, wf, wn, saved;
+    long dh, dx1, dao, dq, dz, dkv, dcn, total;
+};
+#define GTC_WFLOATS (2 * 256 * 256 + 2 * 1024 * 256)     // q third | proj_cluster | fc1 | fc2 in fragment order
+static GtcWs gtc_ws_layout(long nt, long nk) {
+    GtcWs w;
+    long p = 0;
+    w.z = p; p += up(nt * CFFM_C);
+    w.mean1 = p; p += up(nt); w.rstd1 = p; p += up(nt);
+    w.cn = p; p += up(nk * CFFM_C); w.cmean = p; p += up(nk); w.crstd = p; p += up(nk);
+    w.qraw = p; p += up(nt * CFFM_C); w.kvraw = p; p += up(nk * 512);
+    w.ao = p; p += up(nt * CFFM_C); w.lse = p; p += up(nt * CFFM_HEADS);
+    w.x1 = p; p += up(nt * CFFM_C); w.z2 = p; p += up(nt * CFFM_C); w.mean2 = p; p += up(nt); w.rstd2 = p; p += up(nt);
+    w.hraw = p; p += up(nt * CFFM_HID); w.act = p; p += up(nt * CFFM_HID);
+    w.wf = p; p += up(GTC_WFLOATS); w.wn = p; p += up(GTC_WFLOATS);
+    w.saved = p;
+    w.dh = p; p += up(nt * CFFM_HID);
+    w.dx1 = p; p += up(nt * CFFM_C); w.dao = p; p += up(nt * CFFM_C); w.dq = p; p += up(nt * CFFM_C); w.dz = p; p += up(nt * CFFM_C);
+    w.dkv = p; p += up(nk * 512); w.dcn = p; p += up(nk * CFFM_C);
+    w.total = p;
+    return w;
+}
+long cffm_gtc_ws_floats(int B, int T, int K) { return (B < 1 || T < 1 || K < 1) ? -1 : gtc_ws_layout((long)B * T, (long)B * K).total; }
+
+static int gtc_pack(const cffm_gtc_params* p, float* wfrag, int form, void* stream) {
+    PnlPackJobs J;
+    const float* w[4] = {p->qkv_w /* rows 0..255 of qkv.weight: the q third */, p->proj_w, p->fc1_w, p->fc2_w};
+    const int N[4] = {256, 256, CFFM_HID, 256}, K[4] = {256, 256, 256, CFFM_HID};
+    const long off[4] = {0, 256 * 256, 2 * 256 * 256, 2 * 256 * 256 + CFFM_HID * 256};
+    long end = 0;
+    for (int j = 0; j < 4; ++j) {
+        J.w[j] = w[j]; J.dst[j] = (f32x4*)(wfrag + off[j]); J.N[j] = N[j]; J.K[j] = K[j];
+        end += ((long)N[j] * K[j] / 8 + 255) / 256 * 256;       // whole workgroups per weight
+        J.end[j] = end;
+    }
+    J.n = 4; J.nn = form;
+    CFFM_LAUNCH(k_pnl_pack_weights, ((unsigned)(end / 256)), (256), 0, (hipStream_t)stream, J);
+    CHECK_LAUNCH("gtc weight pack");
+    return 0;
+}
+static int gtc_check(const cffm_gtc_params* p, const void* a, const void* b, const void* c, const void* ws, int B, int T, int K, const char* who) {
+    REQUIRE(p && a && b && c && ws && B >= 1 && T >= 1 && K >= 1 && K <= 256, "%s: bad arguments (1 <= K <= 256)", who);
+    REQUIRE(p->norm1_w && p->norm1_b && p->qkv_w && p->qkv_b && p->kv_w && p->kv_b && p->proj_w && p->proj_b && p->norm2_w && p->norm2_b &&
+            p->fc1_w && p->fc1_b && p->fc2_w && p->fc2_b, "%s: null parameter", who);
+    return 0;
+}
+int cffm_gtc_block_forward(const cffm_gtc_params* p, const float* x, const float* centers, float* out, float* ws, int B, int T, int K,
+                           void* stream) {
+    TRY(gtc_check(p, x, centers, out, ws, B, T, K, "gtc_block_forward"));
+    hipStream_t st = (hipStream_t)stream;
+    const long nt = (long)B * T, nk = (long)B * K;
+    const GtcWs W = gtc_ws_layout(nt, nk);
+    float* wf = ws + W.wf;
+    TRY(gtc_pack(p, wf, 0, stream));
+    {
+        PROF(ST_LN);
+        CFFM_LAUNCH(k_layernorm, ((unsigned)((nt + 3) / 4)), (256), 0, st, x, p->norm1_w, p->norm1_b, ws + W.z, ws + W.mean1, ws + W.rstd1, nt, 1);
+        CFFM_LAUNCH(k_layernorm, ((unsigned)((nk + 3) / 4)), (256), 0, st, centers, p->norm1_w, p->norm1_b, ws + W.cn, ws + W.cmean, ws + W.crstd, nk, 0);
+        CHECK_LAUNCH("gtc layernorm");
+    }
+    {
+        PROF(ST_GEMM);
+        const int rc = panel_mt(nt) == 3 ? panel_gemm_launch<3, 2, true, 0>(ws + W.z, 256, nt, 256, wf, ws + W.qraw, 256, nullptr, nullptr, st)
+                                         : panel_gemm_launch<2, 2, true, 0>(ws + W.z, 256, nt, 256, wf, ws + W.qraw, 256, nullptr, nullptr, st);
+        REQUIRE(!rc, "gtc_block_forward: q gemm failed");
+        REQUIRE(!gemm_nt(ws + W.cn, p->kv_w, ws + W.kvraw, nk, 512, 256, st), "gtc_block_forward: kv gemm failed");
+    }
+    TRY(cffm_gtc_attn_fwd(ws + W.qraw, p->qkv_b, ws + W.kvraw, p->kv_b, ws + W.ao, ws + W.lse, B, T, K, stream));
+    TRY(cffm_mlp_fwd(ws + W.ao, x, 0, (int)nt, wf + 256 * 256, wf + 2 * 256 * 256, wf + 2 * 256 * 256 + CFFM_HID * 256, p->proj_b, p->fc1_b, p->fc2_b,
+                     p->norm2_w, p->norm2_b, ws + W.x1, ws + W.z2, ws + W.mean2, ws + W.rstd2, ws + W.hraw, ws + W.act, out, nt, stream));
+    return 0;
+}
+
+// every gradient of cffm_gtc_grads is written (qkv_w / qkv_b: rows / entries >= 256 -- the unused k, v thirds, :216 -- are zeroed)
+int cffm_gtc_block_backward(const cffm_gtc_params* p, const cffm_gtc_grads* g, const float* x, const float* centers, const float* dout,
+                            float* dx, float* dcenters, float* ws, int B, int T, int K, void* stream) {
+    TRY(gtc_check(p, x, centers, dout, ws, B, T, K, "gtc_block_backward"));
+    REQUIRE(g && dx && dcenters && g->norm1_w && g->norm1_b && g->qkv_w && g->qkv_b && g->kv_w && g->kv_b && g->proj_w && g->proj_b && g->norm2_w &&
+            g->norm2_b && g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b, "gtc_block_backward: null gradient");
+    hipStream_t st = (hipStream_t)stream;
+    const long nt = (long)B * T, nk = (long)B * K;
+    const GtcWs W = gtc_ws_layout(nt, nk);
+    float* wn = ws + W.wn;
+    TRY(gtc_pack(p, wn, 1, stream));
+#ifdef CFFM_EMU
+    memset(g->qkv_w + 256 * 256, 0, sizeof(float) * 512 * 256);
+    memset(g->qkv_b + 256, 0, sizeof(float) * 512);
+#else
+    REQUIRE(hipMemsetAsync(g->qkv_w + 256 * 256, 0, sizeof(float) * 512 * 256, st) == hipSuccess &&
+            hipMemsetAsync(g->qkv_b + 256, 0, sizeof(float) * 512, st) == hipSuccess, "gtc_block_backward: memset failed");
+#endif
+    RedScope reductions(st);      // the bias / norm record reductions below run as ONE launch (finish())
+    // x2 = x1 + Mlp(LN2(x1)), x1 = x + o Wpc^T + bpc: the fused input-gradient chain of the base block
+    TRY(cffm_mlp_bwd(dout, ws + W.hraw, p->fc1_b, ws + W.x1, ws + W.mean2, ws + W.rstd2, p->norm2_w, wn + 2 * 256 * 256 + CFFM_HID * 256, wn + 2 * 256 * 256,
+                     wn + 256 * 256, ws + W.dh, ws + W.dx1, ws + W.dao, g->norm2_w, g->norm2_b, g->fc1_b, g->fc2_b, g->proj_b, nt, stream));
+    TRY(cffm_gtc_attn_bwd(ws + W.qraw, p->qkv_b, ws + W.kvraw, p->kv_b, ws + W.ao, ws + W.dao, ws + W.lse, ws + W.dq, ws + W.dkv, B, T, K, stream));
+    {
+        // dz = dq Wq (row panels; the q bias gradient = column sums of dq out of the staging registers)
+        PROF(ST_GEMM);
+        const int mt = panel_mt(nt);
+        const long nrec = (nt + 16 * mt - 1) / (16 * mt);
+        float* qrec = red_scratch((size_t)nrec * 256, st);
+        REQUIRE(qrec, "gtc_block_backward: scratch allocation failed");
+        const int rc = mt == 3 ? panel_gemm_launch<3, 2, false, 0>(ws + W.dq, 256, nt, 256, wn, ws + W.dz, 256, nullptr, nullptr, st, qrec)
+                               : panel_gemm_launch<2, 2, false, 0>(ws + W.dq, 256, nt, 256, wn, ws + W.dz, 256, nullptr, nullptr, st, qrec);
+        REQUIRE(!rc, "gtc_block_backward: q input-gradient gemm failed");
+        RedSegs segs;
+        segs.nseg = 0;
+        seg_add(segs, 0, 256, g->qkv_b, 0);
+        reduce_records(qrec, (int)nrec, 256, 256, segs, st);
+    }
+    {
+        // the four large weight gradients in one grouped launch (z, z2, act and dh are in split-4 storage)
+        PROF(ST_GEMM); PROF2(ST_G_DW);
+        const cffm_wgrad wg4[4] = {{ws + W.dq, ws + W.z, g->qkv_w, nt, 256, 256}, {ws + W.dh, ws + W.z2, g->fc1_w, nt, CFFM_HID, 256},
+                                   {dout, ws + W.act, g->fc2_w, nt, 256, CFFM_HID}, {ws + W.dx1, ws + W.ao, g->proj_w, nt, 256, 256}};
+        const GemmTNPre pre4[4] = {{0, 1, nullptr}, {1, 1, nullptr}, {0, 1, nullptr}, {0, 0, nullptr}};
+        REQUIRE(!gemm_tn_group((const GemmTN*)wg4, 4, st, pre4, lib_scratch, 480), "gtc_block_backward: weight-gradient gemm failed");
+    }
+    // the prototype side: [Kc|Vc] = cn Wkv^T + bkv on B*K rows
+    TRY(cffm_colsum(ws + W.dkv, nk, 512, g->kv_b, stream));
+    {
+        PROF(ST_GEMM);
+        REQUIRE(!gemm_tn(ws + W.dkv, ws + W.cn, g->kv_w, nk, 512, 256, st), "gtc_block_backward: kv weight-gradient gemm failed");
+        REQUIRE(!gemm_nn(ws + W.dkv, p->kv_w, ws + W.dcn, nk, 512, 256, st), "gtc_block_backward: kv input-gradient gemm failed");
+    }
+    // LN1 backward of the tokens (+ the residual path dx1), then of the prototypes: the same norm1 (:622), so the second ACCUMULATES
+    TRY(cffm_ln_bwd_residual(x, ws + W.mean1, ws + W.rstd1, p->norm1_w, ws + W.dz, ws + W.dx1, dx, g->norm1_w, g->norm1_b, nt, 1, nullptr, nullptr, stream));
+    reductions.finish();
+    TRY(cffm_ln_bwd_residual(centers, ws + W.cmean, ws + W.crstd, p->norm1_w, ws + W.dcn, nullptr, dcenters, g->norm1_w, g->norm1_b, nk, 0, nullptr, nullptr,
+                             stream));
+    CHECK_LAUNCH("gtc_block_backward");
     return 0;
 }
 

@@ -9,12 +9,13 @@
 #pragma once
 #include "cffm_common.h"
 
-#define GTC_TOK 32  // tokens per workgroup
+#define GTB_QS_ 36          // floats per row of the q / dO / o tiles in LDS (32 + 4: 16-byte aligned rows on different banks)
 
 // plain row LayerNorm: z = LN(x) (+ stats)
+// split: z in split-4 storage (cffm_common.h) -- the A operand of a row-panel GEMM
 __global__ void __launch_bounds__(256) k_layernorm(const float* __restrict__ x, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ z,
-                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, long nrows) {
+                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, long nrows, int split = 0) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -23,103 +24,242 @@ __global__ void __launch_bounds__(256) k_layernorm(const float* __restrict__ x, 
     const f32x4 d = v - mu;
     const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / CFFM_C);
     const float rs = 1.f / sqrtf(var + CFFM_LN_EPS);
-    *(f32x4*)(z + row * CFFM_C + 4 * lane) = d * rs * *(const f32x4*)(gamma + 4 * lane) + *(const f32x4*)(beta + 4 * lane);
+    const f32x4 zv = d * rs * *(const f32x4*)(gamma + 4 * lane) + *(const f32x4*)(beta + 4 * lane);
+    *(f32x4*)(z + row * CFFM_C + 4 * lane) = split ? split4_pack(zv) : zv;
     if (lane == 0) { mean_out[row] = mu; rstd_out[row] = rs; }
 }
 
-__device__ __forceinline__ float red8(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-    return v;
-}
-
-// grid (ceil(T/32), 8, B).  q_raw [B*T,qld] (q = (q_raw + bq) * scale), kv_raw [B*K,512], o [B*T,256], lse [B*T,8]
+// Forward (round 5 form): a LANE owns a token -- its q head slice (32 floats) and its output accumulator live in registers, the
+// prototype rows are broadcast LDS reads, so s = q . Kc[k] and o += p Vc[k] are 32 + 32 register FMAs per key with NO cross-lane
+// reduction; softmax is online (running maximum per lane).  The q / o rows travel through an LDS tile so that global accesses are
+// 16-byte pieces of whole 128-byte head slices (8 threads per token row).  Rounds 1-4: 8 lanes per token, three ds_bpermute per key.
+// grid (ceil(T/256), 8, B), 256 threads; dynamic LDS gtf_lds(K).  q_raw [B*T,256] (q = (q_raw + bq) * scale), kv_raw [B*K,512],
+// o [B*T,256], lse [B*T,8]
+#define GTC_TOK 256  // tokens per workgroup
+__host__ __device__ constexpr int gtf_lds(int K) { return 4 * (2 * K * CFFM_HD + GTC_TOK * GTB_QS_); }
 __global__ void __launch_bounds__(256) k_gtc_attn_fwd(const float* __restrict__ q_raw, const float* __restrict__ bq,
                                                        const float* __restrict__ kv_raw, const float* __restrict__ bkv,
                                                        float* __restrict__ o, float* __restrict__ lse, int T, int K) {
     CFFM_DYN_SMEM(smem);
     float* Kc = (float*)smem;       // [K][32]
     float* Vc = Kc + K * CFFM_HD;   // [K][32]
+    float* Qs = Vc + K * CFFM_HD;   // [256][GTB_QS_]: q rows in, o rows out
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int t0 = blockIdx.x * GTC_TOK;
+    const float scale = 0.17677669529663687f;
     for (int e = tid; e < K * CFFM_HD; e += 256) {
         const int k = e >> 5, d = e & 31;
         const float* row = kv_raw + ((long)b * K + k) * 512 + h * CFFM_HD + d;
         Kc[e] = row[0] + bkv[h * CFFM_HD + d];
         Vc[e] = row[256] + bkv[256 + h * CFFM_HD + d];
     }
+    for (int e = tid; e < GTC_TOK * 8; e += 256) {
+        const int tl = e >> 3, c = e & 7, t = t0 + tl;
+        f32x4 qv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t < T) qv = (*(const f32x4*)(q_raw + ((long)b * T + t) * CFFM_C + h * CFFM_HD + 4 * c) + *(const f32x4*)(bq + h * CFFM_HD + 4 * c)) * scale;
+        *(f32x4*)(Qs + tl * GTB_QS_ + 4 * c) = qv;
+    }
     __syncthreads();
-    const int t = blockIdx.x * GTC_TOK + (tid >> 3), c = tid & 7;
-    const bool live = t < T;
-    const long row = (long)b * T + (live ? t : 0);
-    const float scale = 0.17677669529663687f;
-    f32x4 q = (*(const f32x4*)(q_raw + row * CFFM_C + h * CFFM_HD + 4 * c) + *(const f32x4*)(bq + h * CFFM_HD + 4 * c)) * scale;
+    float q[32], acc[32];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        const f32x4 qv = *(const f32x4*)(Qs + tid * GTB_QS_ + 4 * d4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q[4 * d4 + e] = qv[e]; acc[4 * d4 + e] = 0.f; }
+    }
     float m = -INFINITY, l = 0.f;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K; ++k) {
-        const f32x4 kc = *(const f32x4*)(Kc + k * CFFM_HD + 4 * c);
-        const float s = red8(q[0] * kc[0] + q[1] * kc[1] + q[2] * kc[2] + q[3] * kc[3]);
+        f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};      // four independent partial sums: one 32-long FMA chain would run at the FMA latency
+#pragma unroll
+        for (int d4 = 0; d4 < 8; ++d4) {
+            const f32x4 kc = *(const f32x4*)(Kc + k * CFFM_HD + 4 * d4);      // (broadcast read)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] += q[4 * d4 + e] * kc[e];
+        }
+        const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         const float mn = fmaxf(m, s);
         const float alpha = expf(m - mn), p = expf(s - mn);
         l = l * alpha + p;
-        acc = acc * alpha + p * *(const f32x4*)(Vc + k * CFFM_HD + 4 * c);
+#pragma unroll
+        for (int d4 = 0; d4 < 8; ++d4) {
+            const f32x4 vc = *(const f32x4*)(Vc + k * CFFM_HD + 4 * d4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * d4 + e] = acc[4 * d4 + e] * alpha + p * vc[e];
+        }
         m = mn;
     }
-    if (live) {
-        *(f32x4*)(o + row * CFFM_C + h * CFFM_HD + 4 * c) = acc * (1.f / l);
-        if (c == 0) lse[row * CFFM_HEADS + h] = m + logf(l);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4)      // (a thread overwrites only its own row)
+        *(f32x4*)(Qs + tid * GTB_QS_ + 4 * d4) = (f32x4){acc[4 * d4] * inv, acc[4 * d4 + 1] * inv, acc[4 * d4 + 2] * inv, acc[4 * d4 + 3] * inv};
+    if (t0 + tid < T) lse[((long)b * T + t0 + tid) * CFFM_HEADS + h] = m + logf(l);
+    __syncthreads();
+    for (int e = tid; e < GTC_TOK * 8; e += 256) {
+        const int tl = e >> 3, c = e & 7, t = t0 + tl;
+        if (t < T) *(f32x4*)(o + ((long)b * T + t) * CFFM_C + h * CFFM_HD + 4 * c) = *(const f32x4*)(Qs + tl * GTB_QS_ + 4 * c);
     }
 }
 
-// dq_raw [B*T,256] (written), dkv [B*K,512] (atomics; pre-zeroed)
+// Backward (round 5).  dq is per token, but dKc / dVc contract over ALL tokens of a clip: rounds 1-4 did that with one LDS atomic
+// per (token, key, channel) plus global atomics -- 180 us at K = 8 and 2.1 ms at K = 100 for 2 x 3600 tokens, and not deterministic.
+// Now a workgroup = (clip b, head h, GTB_CHUNKS chunks of 64 tokens), two phases per chunk:
+//   1. a LANE owns a token (its q and dO head slices in registers, read from LDS tiles that were loaded coalesced), the four waves
+//      split the keys: s, dp by 32-term register dot products against the broadcast prototype rows -- no cross-lane reduction at all --
+//      then p = exp(s - lse), ds = p (dp - D); P and dS tiles go to LDS, the waves' partial dq rows are summed through LDS;
+//   2. the thread that owns a 4-key x 4-channel block of dKc (= dS^T q) or dVc (= P^T dO) accumulates it over the chunk's tokens
+//      from the tiles (two 16-byte LDS reads per 16 FMAs), in registers across the workgroup's chunks.
+// Every workgroup leaves one record [K][64] (dKc | dVc rows, unscaled); k_gtc_dkv_sum adds the records of a (clip, head) in a fixed
+// order: deterministic, no atomics.
+#define GTB_CHUNKS 2        // chunks per workgroup; a chunk = `tok` tokens, one per lane: 64, or 32 when the P / dS tiles of 64 would not fit the LDS (K > 128)
+#define GTB_QS GTB_QS_
+__host__ __device__ constexpr int gtb_kp(int K) { return (K + 3) / 4 * 4; }             // keys padded to whole 4-blocks
+__host__ __device__ constexpr int gtb_ps(int K) { return gtb_kp(K) + 4; }               // floats per row of the P / dS tiles
+__host__ __device__ constexpr int gtb_tok(int K) { return K > 128 ? 32 : 64; }
+__host__ __device__ constexpr int gtb_lds(int K) {
+    return 4 * (2 * gtb_kp(K) * CFFM_HD + 2 * gtb_tok(K) * GTB_QS + 2 * gtb_tok(K) * gtb_ps(K) + 4 * gtb_tok(K) * 33);
+}
+// grid (ceil(T / (gtb_tok(K) GTB_CHUNKS)), 8, B), 256 threads.  rec [B][8][gridDim.x][K][64]
 __global__ void __launch_bounds__(256) k_gtc_attn_bwd(const float* __restrict__ q_raw, const float* __restrict__ bq,
                                                        const float* __restrict__ kv_raw, const float* __restrict__ bkv,
                                                        const float* __restrict__ o, const float* __restrict__ dout,
                                                        const float* __restrict__ lse, float* __restrict__ dq_raw,
-                                                       float* __restrict__ dkv, int T, int K) {
+                                                       float* __restrict__ rec, int T, int K) {
     CFFM_DYN_SMEM(smem);
-    float* Kc = (float*)smem;
-    float* Vc = Kc + K * CFFM_HD;
-    float* dKc = Vc + K * CFFM_HD;
-    float* dVc = dKc + K * CFFM_HD;
-    const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    for (int e = tid; e < K * CFFM_HD; e += 256) {
-        const int k = e >> 5, d = e & 31;
-        const float* row = kv_raw + ((long)b * K + k) * 512 + h * CFFM_HD + d;
-        Kc[e] = row[0] + bkv[h * CFFM_HD + d];
-        Vc[e] = row[256] + bkv[256 + h * CFFM_HD + d];
-        dKc[e] = 0.f;
-        dVc[e] = 0.f;
-    }
-    __syncthreads();
-    const int t = blockIdx.x * GTC_TOK + (tid >> 3), c = tid & 7;
-    const bool live = t < T;
-    const long row = (long)b * T + (live ? t : 0);
+    const int KP = gtb_kp(K), PS = gtb_ps(K), GTB_TOK = gtb_tok(K);
+    float* Kc = (float*)smem;                 // [KP][32] (rows >= K zero)
+    float* Vc = Kc + KP * CFFM_HD;
+    float* Qs = Vc + KP * CFFM_HD;            // [64][GTB_QS]  q (scaled, with bias)
+    float* Gs = Qs + GTB_TOK * GTB_QS;        // [64][GTB_QS]  dO
+    float* Ps = Gs + GTB_TOK * GTB_QS;        // [64][PS]
+    float* Ds = Ps + GTB_TOK * PS;            // [64][PS]      dS
+    float* Rq = Ds + GTB_TOK * PS;            // [4 waves][64][33]  partial dq rows
+    const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float scale = 0.17677669529663687f;
-    const f32x4 q = (*(const f32x4*)(q_raw + row * CFFM_C + h * CFFM_HD + 4 * c) + *(const f32x4*)(bq + h * CFFM_HD + 4 * c)) * scale;
-    f32x4 dov = *(const f32x4*)(dout + row * CFFM_C + h * CFFM_HD + 4 * c);
-    const f32x4 ov = *(const f32x4*)(o + row * CFFM_C + h * CFFM_HD + 4 * c);
-    if (!live) dov = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float D = red8(dov[0] * ov[0] + dov[1] * ov[1] + dov[2] * ov[2] + dov[3] * ov[3]);
-    const float ls = lse[row * CFFM_HEADS + h];
-    f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < K; ++k) {
-        const f32x4 kc = *(const f32x4*)(Kc + k * CFFM_HD + 4 * c);
-        const f32x4 vc = *(const f32x4*)(Vc + k * CFFM_HD + 4 * c);
-        const float s = red8(q[0] * kc[0] + q[1] * kc[1] + q[2] * kc[2] + q[3] * kc[3]);
-        const float dp = red8(dov[0] * vc[0] + dov[1] * vc[1] + dov[2] * vc[2] + dov[3] * vc[3]);
-        const float p = live ? expf(s - ls) : 0.f;
-        const float ds = p * (dp - D);
-        dq += ds * kc;
-        for (int e = 0; e < 4; ++e) {
-            atomicAdd(dKc + k * CFFM_HD + 4 * c + e, ds * q[e]);
-            atomicAdd(dVc + k * CFFM_HD + 4 * c + e, p * dov[e]);
+    for (int e = tid; e < KP * CFFM_HD; e += 256) {
+        const int k = e >> 5, d = e & 31;
+        float kc = 0.f, vc = 0.f;
+        if (k < K) {
+            const float* row = kv_raw + ((long)b * K + k) * 512 + h * CFFM_HD + d;
+            kc = row[0] + bkv[h * CFFM_HD + d];
+            vc = row[256] + bkv[256 + h * CFFM_HD + d];
+        }
+        Kc[e] = kc; Vc[e] = vc;
+    }
+    // the 4 x 4 blocks of dKc (blocks [0, NB)) and dVc ([NB, 2 NB)) this thread owns: block = (key quad kq, channel quad dq4)
+    const int NB = (KP / 4) * 8;
+    f32x4 accb[4][4];                         // [owned block: K <= 256 gives at most 1024 blocks = 4 per thread][key in block] x 4 channels
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accb[j][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < GTB_CHUNKS; ++ch) {
+        const int t0 = (blockIdx.x * GTB_CHUNKS + ch) * GTB_TOK;
+        if (t0 >= T) break;                   // (uniform)
+        __syncthreads();                      // the previous chunk's phase 2 is done with the tiles
+        // ---- tiles: q, dO (16-byte pieces, 8 threads per token row) and D = sum_d dO * O
+        for (int e = tid; e < GTB_TOK * 8; e += 256) {
+            const int tl = e >> 3, c = e & 7, t = t0 + tl;
+            f32x4 qv = (f32x4){0.f, 0.f, 0.f, 0.f}, gv = qv;
+            if (t < T) {
+                const long row = (long)b * T + t;
+                qv = (*(const f32x4*)(q_raw + row * CFFM_C + h * CFFM_HD + 4 * c) + *(const f32x4*)(bq + h * CFFM_HD + 4 * c)) * scale;
+                gv = *(const f32x4*)(dout + row * CFFM_C + h * CFFM_HD + 4 * c);
+            }
+            *(f32x4*)(Qs + tl * GTB_QS + 4 * c) = qv;
+            *(f32x4*)(Gs + tl * GTB_QS + 4 * c) = gv;
+        }
+        __syncthreads();
+        // ---- phase 1: lane = token, wave = every fourth key
+        {
+            const int t = t0 + lane;
+            const bool live = t < T && lane < GTB_TOK;
+            const long row = (long)b * T + (live ? t : 0);
+            float q[32], g[32], dq[32];
+            float D = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 8; ++d4) {
+                const int lq = lane < GTB_TOK ? lane : 0;
+                const f32x4 qv = *(const f32x4*)(Qs + lq * GTB_QS + 4 * d4), gv = *(const f32x4*)(Gs + lq * GTB_QS + 4 * d4);
+                const f32x4 ov = live ? *(const f32x4*)(o + row * CFFM_C + h * CFFM_HD + 4 * d4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { q[4 * d4 + e] = qv[e]; g[4 * d4 + e] = gv[e]; dq[4 * d4 + e] = 0.f; D += gv[e] * ov[e]; }
+            }
+            const float ls = live ? lse[row * CFFM_HEADS + h] : 0.f;
+            const int ln = lane < GTB_TOK ? lane : 0;          // (tok = 32: the upper half of the wave idles)
+            for (int k = wave; k < KP; k += 4) {
+                f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f}, p4 = s4;      // (independent partial sums, as in the forward)
+#pragma unroll
+                for (int d4 = 0; d4 < 8; ++d4) {
+                    const f32x4 kc = *(const f32x4*)(Kc + k * CFFM_HD + 4 * d4), vc = *(const f32x4*)(Vc + k * CFFM_HD + 4 * d4);   // (broadcast reads)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s4[e] += q[4 * d4 + e] * kc[e]; p4[e] += g[4 * d4 + e] * vc[e]; }
+                }
+                const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]), dp = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+                const float p = (live && k < K) ? expf(s - ls) : 0.f;
+                const float ds = p * (dp - D);
+                if (lane < GTB_TOK) { Ps[ln * PS + k] = p; Ds[ln * PS + k] = ds; }
+#pragma unroll
+                for (int d4 = 0; d4 < 8; ++d4) {
+                    const f32x4 kc = *(const f32x4*)(Kc + k * CFFM_HD + 4 * d4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq[4 * d4 + e] += ds * kc[e];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 32; ++d)
+                if (lane < GTB_TOK) Rq[(wave * GTB_TOK + lane) * 33 + d] = dq[d];
+        }
+        __syncthreads();
+        // dq rows: the four waves' partial rows added, 16-byte stores (8 threads per token row)
+        for (int e = tid; e < GTB_TOK * 8; e += 256) {
+            const int tl = e >> 3, c = e & 7, t = t0 + tl;
+            if (t < T) {
+                f32x4 v;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    v[x] = (Rq[(0 * GTB_TOK + tl) * 33 + 4 * c + x] + Rq[(1 * GTB_TOK + tl) * 33 + 4 * c + x]) +
+                           (Rq[(2 * GTB_TOK + tl) * 33 + 4 * c + x] + Rq[(3 * GTB_TOK + tl) * 33 + 4 * c + x]);
+                *(f32x4*)(dq_raw + ((long)b * T + t) * CFFM_C + h * CFFM_HD + 4 * c) = v * scale;
+            }
+        }
+        // ---- phase 2: dKc += dS^T q, dVc += P^T dO over the chunk's 64 tokens, 4 x 4 register blocks
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int blk = tid + 256 * j;
+            if (blk >= 2 * NB) break;
+            const bool isv = blk >= NB;
+            const int bb = isv ? blk - NB : blk, kq = bb >> 3, d4 = bb & 7;
+            const float* A = (isv ? Ps : Ds) + 4 * kq;
+            const float* Bm = (isv ? Gs : Qs) + 4 * d4;
+#pragma unroll 4
+            for (int tl = 0; tl < GTB_TOK; ++tl) {
+                const f32x4 a = *(const f32x4*)(A + tl * PS), bv = *(const f32x4*)(Bm + tl * GTB_QS);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[j][r] += a[r] * bv;
+            }
         }
     }
-    if (live) *(f32x4*)(dq_raw + row * CFFM_C + h * CFFM_HD + 4 * c) = dq * scale;
-    __syncthreads();
-    for (int e = tid; e < K * CFFM_HD; e += 256) {
-        const int k = e >> 5, d = e & 31;
-        float* row2 = dkv + ((long)b * K + k) * 512 + h * CFFM_HD + d;
-        atomicAdd(row2, dKc[e]);
-        atomicAdd(row2 + 256, dVc[e]);
+    // the record of this workgroup: rows k < K, 64 floats each (dKc 32 | dVc 32)
+    float* out = rec + (((long)(b * CFFM_HEADS + h) * gridDim.x + blockIdx.x) * K) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int blk = tid + 256 * j;
+        if (blk >= 2 * NB) break;
+        const bool isv = blk >= NB;
+        const int bb = isv ? blk - NB : blk, kq = bb >> 3, d4 = bb & 7;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * kq + r < K) *(f32x4*)(out + (long)(4 * kq + r) * 64 + (isv ? 32 : 0) + 4 * d4) = accb[j][r];
     }
+}
+// dkv [B*K][512] (dKc at column h*32, dVc at 256 + h*32; dKc carries the q scale already) = the records of each (clip, head) added in
+// order.  grid (K, 8, B), 64 threads
+__global__ void __launch_bounds__(64) k_gtc_dkv_sum(const float* __restrict__ rec, int nrec, int K, float* __restrict__ dkv) {
+    const int k = blockIdx.x, h = blockIdx.y, b = blockIdx.z, e = threadIdx.x;
+    const float* p = rec + ((long)(b * CFFM_HEADS + h) * nrec * K + k) * 64 + e;
+    float s0 = 0.f, s1 = 0.f;
+    int r = 0;
+    for (; r + 1 < nrec; r += 2) { s0 += p[(long)r * K * 64]; s1 += p[(long)(r + 1) * K * 64]; }
+    if (r < nrec) s0 += p[(long)r * K * 64];
+    dkv[((long)b * K + k) * 512 + (e < 32 ? 0 : 256) + h * CFFM_HD + (e & 31)] = s0 + s1;
 }

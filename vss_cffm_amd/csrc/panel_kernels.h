@@ -58,6 +58,18 @@ __global__ void __launch_bounds__(256) k_pnl_pack_weight(const float* __restrict
     if (item < (long)N * K / 8) pnl_pack_weight(W, N, K, nn != 0, dst, item);
 }
 
+// up to four weights in one launch (the CFFM++ block packs q | proj_cluster | fc1 | fc2 per direction)
+struct PnlPackJobs { const float* w[4]; f32x4* dst[4]; int N[4], K[4]; long end[4]; int n, nn; };
+__global__ void __launch_bounds__(256) k_pnl_pack_weights(PnlPackJobs J) {
+    long item = (long)blockIdx.x * 256 + threadIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q + 1 < J.n && item >= J.end[q]) j = q + 1;
+    if (j > 0) item -= J.end[j - 1];
+    if (item < (long)J.N[j] * J.K[j] / 8) pnl_pack_weight(J.w[j], J.N[j], J.K[j], J.nn != 0, J.dst[j], item);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release / acquire of ALL memory: on gfx9 it waits vmcnt(0),
 // i.e. for every global store issued so far to be acknowledged AND for the whole B-fragment ring that is in flight -- measured on the
 // fused forward kernel: 44.6 us with __syncthreads(), of which 20 us were the (seven times drained) stores.
