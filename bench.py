@@ -98,7 +98,12 @@ def roofline_kernels(stages, b, nw, hw):
         # attention backward, fused (round 2): S and dP recomputed once, dQ, dK, dV = 5 products of 49 x 289 x 32 per (window, head)
         'attn_bwd_fused': ('mfma16', 5 * 2.0 * b * nw * 8 * 49 * 289 * 32),
         'attn_dkv_gather': ('hbm', 4.0 * (2 * nr * 512)),
-        'ln_pool_fwd': ('hbm', 4.0 * (b * 4 * hw * 256 + nr * 256)), 'ln_pool_bwd': ('hbm', 4.0 * (2 * b * 4 * hw * 256 + nr * 256)),
+        'ln_pool_fwd': ('hbm', 4.0 * (b * 4 * hw * 256 + nr * 256)),
+        # round 5: the CFFA backward is two kernels -- per block the target frame (reads x_tgt, the residual-path gradient and the target rows of
+        # dzall, writes dx_tgt), once per step the three reference frames of BOTH blocks (reads x_ref + the 14 pooled-cell rows per window and block,
+        # writes dx_ref)
+        'ln_pool_bwd': ('hbm', 4.0 * (3 * b * hw * 256 + b * 49 * nw * 256)),
+        'ln_pool_bwd_ref': ('hbm', 4.0 * (2 * b * 3 * hw * 256 + DEPTH * b * 14 * nw * 256)),
         'residual_ln': ('hbm', 4.0 * 4 * np_ * 256), 'ln_bwd': ('hbm', 4.0 * 4 * np_ * 256),
         'transpose': ('hbm', None),
     }

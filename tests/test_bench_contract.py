@@ -39,7 +39,7 @@ def test_bench_prints_one_contract_line():
         assert k in j, k
     assert j['rccl'] == {'world': 1, 'backend': None}
     rk = j['roofline_kernels']
-    for fam in ('gemm_qkv_fwd', 'mlp_fwd_fused', 'mlp_bwd_fused', 'gemm_dw_group', 'attn_bwd_fused', 'ln_pool_fwd', 'ln_pool_bwd'):
+    for fam in ('gemm_qkv_fwd', 'mlp_fwd_fused', 'mlp_bwd_fused', 'gemm_dw_group', 'attn_bwd_fused', 'ln_pool_fwd', 'ln_pool_bwd', 'ln_pool_bwd_ref'):
         assert fam in rk and 0.0 < rk[fam]['frac'] < 1.0, (fam, rk.get(fam))
     assert j['head_step'] and j['head_step'].get('ms_per_step', 0) > 0, j['head_step']
 

@@ -471,33 +471,33 @@ __device__ __forceinline__ void ln_pool_bwd_ref_frame(const Geo& G, const RefRow
         const float rs = R.rs[k];
         const f32x4 xh = (R.x[k] - R.mu[k]) * rs;
         f32x4 gz = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // (the pooled-cell gradient rows are re-read from LDS for every pixel: hoisted out of the unrolled pixel loop they occupy 36
-        //  registers per block in the nine-cell frame -- 158 VGPRs at two blocks)
-        const float* sPk = sP + opaque_zero();
+        // The cells that can see pixel (iy, ix): the composed pooling matrix is SPARSE in the strided frames.  A cell (u, v) pools the
+        // resized rows wsg u .. wsg u + wsg - 1, a resized row r taps pixel rows r and r + 1 (bil_tap), so pixel row iy reaches the cells
+        // u = r / wsg of r in {iy - 1, iy} ^ [0, 5]: one or two per dimension -- on average 1.65 of the 9 cells of frame t-3 and 1.3 of
+        // the 4 of frame t-6.  Everywhere else M[c][i] is an exact zero: no share in dz, and the dM entry is one that the pooling-matrix
+        // backward multiplies by a zero tap (k_pool_matrix_bwd) -- it stays 0.  (Round 5, second form: all NC cells per pixel cost
+        // 14 dot products + wave reductions per block and pixel triple, 48 us for the launch.)
+        constexpr int NCD = NC == 9 ? 3 : (NC == 4 ? 2 : 1), WSG = NC == 9 ? 2 : (NC == 4 ? 3 : 7);
+        const int iy = i / 7, ix = i % 7;
+        int u0 = 0, u1 = 0, v0 = 0, v1 = 0;
+        if (NC > 1) {
+            u0 = (iy > 0 ? iy - 1 : 0) / WSG; u1 = (iy < 5 ? iy : 5) / WSG;
+            v0 = (ix > 0 ? ix - 1 : 0) / WSG; v1 = (ix < 5 ? ix : 5) / WSG;
+        }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const f32x4 z = xh * gm[d] + bt[d];
             f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // cells in groups of (at most) three -- three LDS reads, three dot products, three overlapping wave reductions -- with the
-            // scheduler fenced between groups: left alone it issues every LDS read of the unrolled pixel body up front (159 VGPRs)
-#pragma unroll
-            for (int c0 = 0; c0 < NC; c0 += 3) {
-                float dm[3];
-#pragma unroll
-                for (int c = c0; c < c0 + 3 && c < NC; ++c) {
-                    const f32x4 dp = *(const f32x4*)(sPk + (d * 14 + g0 - 1 + c) * CFFM_C + 4 * lane);
-                    dz += sMm[(d * 14 + g0 - 1 + c) * CFFM_WA + i] * dp;
-                    dm[c - c0] = dot4(dp, z);
-                }
+            for (int u = u0; u <= u1; ++u)          // (wave-uniform bounds)
+                for (int v = v0; v <= v1; ++v) {
+                    const int c = d * 14 + g0 - 1 + u * NCD + v;
+                    const f32x4 dp = *(const f32x4*)(sP + c * CFFM_C + 4 * lane);
+                    dz += sMm[c * CFFM_WA + i] * dp;
 #if !(LNPB_ABLATE & 1)
-#pragma unroll
-                for (int c = c0; c < c0 + 3 && c < NC; ++c) dm[c - c0] = wave_sum_hi(dm[c - c0]);   // independent chains: they overlap
-                if (lane == 63)
-#pragma unroll
-                    for (int c = c0; c < c0 + 3 && c < NC; ++c) sdM[(d * 14 + g0 - 1 + c) * CFFM_WA + i] = dm[c - c0];
+                    const float dm = wave_sum_hi(dot4(dp, z));
+                    if (lane == 63) sdM[c * CFFM_WA + i] = dm;
 #endif
-                sched_fence();
-            }
+                }
             ag[d] += dz * xh;
             ab[d] += dz;
             gz += dz * gm[d];
