@@ -133,6 +133,12 @@ int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, i
 /* n <= 4 independent weight gradients (dw_i[N_i,K_i] = dy_i[M_i,N_i]^T x_i[M_i,K_i]) in one launch: the four Linear layers of a
  * block (qkv / proj / fc1 / fc2 .weight.grad, cffm_transformer.py:374, :381, :18-19), none of which feeds the backward chain */
 typedef struct { const float* dy; const float* x; float* dw; long M; int N; int K; } cffm_wgrad;
+/* Weight gradient with both operands in split-4 storage (16 bytes = {bf16 hi x4 | bf16 lo x4} of four consecutive floats of a row: what the
+ * block's producers write for GEMM-only tensors): tiles go global -> LDS by DMA, no staging arithmetic (csrc/dw_kernels.h).  N, K multiples
+ * of 128.  cffm_split4 makes such a copy of a plain fp32 array (n floats, n % 4 == 0). */
+int cffm_split4(const float* src, float* dst, long n, void* stream);
+int cffm_linear_bwd_weight_split(const float* dy_s, const float* x_s, float* dw, long M, int N, int K, void* stream);
+int cffm_linear_bwd_weight_split_group(const cffm_wgrad* problems, int n /* <= 3 */, void* stream);   /* one launch, one common k-slice length */
 int cffm_linear_bwd_weight_group(const cffm_wgrad* problems /* host */, int n, void* stream);
 /* fused Mlp halves: hraw = x w^T (raw, kept for backward), act = gelu(hraw + b)  |  out = res + x w^T + b */
 int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K,

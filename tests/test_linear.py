@@ -137,3 +137,29 @@ def test_conv1x1_emulated():
 @pytest.mark.gpu
 def test_conv1x1_gpu():
     run_conv1x1_checks(torch.device('cuda:0'))
+
+
+def run_dw_split_checks(lib, device, shapes):
+    """cffm_linear_bwd_weight_split (the LDS-DMA weight-gradient kernel, csrc/dw_kernels.h): operands in split-4 storage made by
+    cffm_split4, against fp64; ragged contraction lengths (last K-tile partly past the array: the DMA's bounds check supplies zeros),
+    one K-tile, fewer K-tiles than LDS stages, several k-slices."""
+    gen = torch.Generator().manual_seed(9)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
+    for (M, N, K) in shapes:
+        dy, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+        dyd, xd = dy.to(device), x.to(device)
+        dys, xs, dw = torch.empty_like(dyd), torch.empty_like(xd), torch.full((N, K), 7., device=device)
+        assert lib.cffm_split4(P(dyd), P(dys), M * N, stream) == 0 and lib.cffm_split4(P(xd), P(xs), M * K, stream) == 0
+        assert lib.cffm_linear_bwd_weight_split(P(dys), P(xs), P(dw), M, N, K, stream) == 0, lib.cffm_last_error()
+        assert rel(dw, dy.double().T @ x.double()) < TOL, (M, N, K)
+    assert lib.cffm_linear_bwd_weight_split(P(dys), P(xs), P(dw), 10, 96, 128, stream) != 0      # N not a multiple of 128: refused
+
+
+def test_dw_split_emulated():
+    run_dw_split_checks(emu.lib(), torch.device('cpu'), [(7, 128, 128), (32, 128, 256), (100, 256, 128), (333, 128, 128)])
+
+
+@pytest.mark.gpu
+def test_dw_split_gpu():
+    run_dw_split_checks(_lib.get(), torch.device('cuda'), [(7, 128, 128), (32, 128, 256), (100, 256, 128), (1000, 128, 128), (10368, 768, 256), (7200, 1024, 256),
+                                                           (7200, 256, 1024), (7201, 256, 256)])

@@ -72,6 +72,9 @@ SIGNATURES = {
     'cffm_linear_bwd_input': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight_group': (ci, [vp, ci, vp]),
+    'cffm_split4': (ci, [vp, vp, cl, vp]),
+    'cffm_linear_bwd_weight_split': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_bwd_weight_split_group': (ci, [vp, ci, vp]),
     'cffm_linear_gelu_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_residual_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_colsum': (ci, [vp, cl, ci, vp, vp]),

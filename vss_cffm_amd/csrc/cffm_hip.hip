@@ -951,6 +951,38 @@ int cffm_linear_bwd_weight_group(const cffm_wgrad* problems, int n, void* stream
     return 0;
 }
 
+// plain fp32 -> split-4 storage (16 bytes = {bf16 hi x4 | bf16 lo x4} of four consecutive floats, cffm_common.h): what the operands of
+// cffm_linear_bwd_weight_split are stored as.  n: floats, a multiple of 4
+int cffm_split4(const float* src, float* dst, long n, void* stream) {
+    REQUIRE(src && dst && n >= 0 && n % 4 == 0, "split4: n must be a multiple of 4");
+    if (!n) return 0;
+    CFFM_LAUNCH(k_split4, (ew_grid(n / 4)), (256), 0, (hipStream_t)stream, src, dst, n / 4);
+    CHECK_LAUNCH("split4");
+    return 0;
+}
+// dw[N,K] = dy[M,N]^T x[M,K] with dy and x in split-4 storage: the LDS-DMA weight-gradient kernel of the block backward (dw_kernels.h) as
+// a stage.  N, K multiples of 128
+int cffm_linear_bwd_weight_split_group(const cffm_wgrad* problems, int n, void* stream) {
+    REQUIRE(problems && n >= 1 && n <= DWD_MAX, "linear_bwd_weight_split_group: 1..%d problems", DWD_MAX);
+    for (int i = 0; i < n; ++i)
+        REQUIRE(problems[i].dy && problems[i].x && problems[i].dw && problems[i].M >= 1 && problems[i].N % 128 == 0 && problems[i].K % 128 == 0 &&
+                problems[i].N >= 128 && problems[i].K >= 128, "linear_bwd_weight_split_group: N, K must be multiples of 128");
+    PROF(ST_GEMM);
+    int klen;
+    static int wgs = -1;      // tuning aid (experiment builds): CFFM_DWD_WGS
+    if (wgs < 0) { const char* e = cffm_tune("CFFM_DWD_WGS"); wgs = e ? atoi(e) : 480; if (wgs < 1) wgs = 480; }
+    const size_t need = dw_dma_partial_floats((const GemmTN*)problems, n, wgs, &klen);
+    float* part = need ? lib_scratch(need) : nullptr;
+    REQUIRE(!need || part, "linear_bwd_weight_split_group: scratch allocation failed");
+    REQUIRE(!dw_group_dma((const GemmTN*)problems, n, (hipStream_t)stream, part, wgs), "linear_bwd_weight_split_group: launch failed");
+    CHECK_LAUNCH("linear_bwd_weight_split_group");
+    return 0;
+}
+int cffm_linear_bwd_weight_split(const float* dy_s, const float* x_s, float* dw, long M, int N, int K, void* stream) {
+    const cffm_wgrad pr = {dy_s, x_s, dw, M, N, K};
+    return cffm_linear_bwd_weight_split_group(&pr, 1, stream);
+}
+
 // q|k|v Linear feeding the CFM kernels: qkv16[M,768] (f16) = x w^T + b, q third times 32^-0.5 (cffm_transformer.py:374, :528)
 int cffm_linear_qkv_fwd(const float* x, const float* w, const float* b, void* qkv16, long M, void* stream) {
     REQUIRE(x && w && b && qkv16, "linear_qkv_fwd: null");

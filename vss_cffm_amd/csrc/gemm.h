@@ -5,6 +5,7 @@
 #pragma once
 #include <stdlib.h>
 #include "gemm_kernels.h"
+#include "dw_kernels.h"
 
 // ---- hand-written split-bf16 MFMA path (default) -------------------------------------------------------------
 float* lib_scratch(size_t nfloats);   // cffm_hip.hip: library-owned device scratch (grows on demand)
@@ -222,6 +223,66 @@ static int gemm_tn_group_split(const GemmTN* pr, int n, hipStream_t st, const Ge
     static int lds_pad = -1;
     if (lds_pad < 0) { const char* e = cffm_tune("CFFM_DW_LDS_PAD"); lds_pad = e ? atoi(e) : 8192; if (lds_pad < 0 || lds_pad > 16384) lds_pad = 8192; }
     CFFM_LAUNCH(k_gemm_group_tt, ((unsigned)wg), (256), GEMM_LDS(128, 128, 32) + lds_pad, st, G);
+    if (after_gemm) after_gemm(st);
+    if (nsum) {
+        Sg.cnt = nsum;
+        for (int q = nsum; q < 4; ++q) { Sg.part[q] = nullptr; Sg.out[q] = nullptr; Sg.n[q] = 0; Sg.nsplit[q] = 0; Sg.blk_end[q] = blk; }
+        CFFM_LAUNCH(k_sum_splits_group, ((unsigned)blk), (256), 0, st, Sg);
+    }
+    return 0;
+}
+
+// ---- weight gradients with both operands in split-4 storage: the LDS-DMA kernel (dw_kernels.h), up to DWD_MAX problems per launch ----
+static size_t dw_dma_partial_floats(const GemmTN* pr, int n, int target_wgs, int* klen_out) {
+    long units = 0;
+    for (int p = 0; p < n; ++p) units += (long)(pr[p].N / 128) * (pr[p].K / 128) * ((pr[p].M + 31) / 32);
+    long ksteps = (units + target_wgs - 1) / target_wgs;
+    if (ksteps < 4) ksteps = 4;
+    const long klen = ksteps * 32;
+    size_t part = 0;
+    for (int p = 0; p < n; ++p) {
+        const long ks = (pr[p].M + klen - 1) / klen;
+        if (ks > 1) part += (size_t)ks * pr[p].N * pr[p].K;
+    }
+    *klen_out = (int)klen;
+    return part;
+}
+// `part`: dw_dma_partial_floats(...) floats of slab scratch (or NULL when that is 0)
+static int dw_group_dma(const GemmTN* pr, int n, hipStream_t st, float* part, int target_wgs, void (*after_gemm)(hipStream_t) = nullptr) {
+    if (n < 1 || n > DWD_MAX) return -1;
+    for (int p = 0; p < n; ++p)
+        if (pr[p].N % 128 || pr[p].K % 128 || pr[p].M < 1 || (long)pr[p].M * pr[p].N * 4 >= (1L << 32) || (long)pr[p].M * pr[p].K * 4 >= (1L << 32)) return -1;
+    int klen;
+    const size_t need = dw_dma_partial_floats(pr, n, target_wgs, &klen);
+    if (need && !part) return -1;
+    DwGroup G;
+    SumGroup Sg;
+    int wg = 0, blk = 0, nsum = 0;
+    for (int p = 0; p < n; ++p) {
+        const int ks = (int)((pr[p].M + klen - 1) / klen);
+        G.A[p] = pr[p].dy; G.B[p] = pr[p].x; G.N[p] = pr[p].N; G.K[p] = pr[p].K; G.M[p] = (int)pr[p].M;
+        G.C[p] = pr[p].dw;
+        if (ks > 1) {
+            G.C[p] = part;
+            Sg.part[nsum] = part; Sg.out[nsum] = pr[p].dw; Sg.n[nsum] = (long)pr[p].N * pr[p].K; Sg.nsplit[nsum] = ks;
+            blk += (int)((Sg.n[nsum] / 4 + 255) / 256);
+            Sg.blk_end[nsum] = blk;
+            ++nsum;
+            part += (size_t)ks * pr[p].N * pr[p].K;
+        }
+        wg += (pr[p].N / 128) * (pr[p].K / 128) * ks;
+        G.wg_end[p] = wg;
+    }
+    for (int p = n; p < DWD_MAX; ++p) { G.A[p] = G.B[p] = nullptr; G.C[p] = nullptr; G.N[p] = G.K[p] = 128; G.M[p] = 0; G.wg_end[p] = wg; }
+    G.klen = klen; G.n = n;
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void*)k_dw_dma, hipFuncAttributeMaxDynamicSharedMemorySize, DWD_LDS) != hipSuccess) return -1;
+        granted = true;
+    }
+#endif
+    CFFM_LAUNCH(k_dw_dma, ((unsigned)wg), (256), DWD_LDS, st, G);
     if (after_gemm) after_gemm(st);
     if (nsum) {
         Sg.cnt = nsum;

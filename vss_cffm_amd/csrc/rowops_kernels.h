@@ -345,6 +345,11 @@ __global__ void __launch_bounds__(1024) k_reduce_records_multi(RedJobs J) {
     reduce_records_body(J.part[j], J.nblk[j], J.stride[j], J.total[j], J.segs[j], blk, red);
 }
 
+// dst = src in split-4 storage; n4 groups of 4 floats
+__global__ void __launch_bounds__(256) k_split4(const float* __restrict__ src, float* __restrict__ dst, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) ((f32x4*)dst)[i] = split4_pack(((const f32x4*)src)[i]);
+}
+
 // --------------------------------------------------------------------------- act = gelu(hraw + b1)
 __global__ void __launch_bounds__(256) k_bias_gelu(const float* __restrict__ hraw, const float* __restrict__ b1,
                                                     float* __restrict__ act, long n4, int ncol4) {
