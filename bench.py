@@ -122,6 +122,18 @@ def roofline_kernels(stages, b, nw, hw):
             out[name] = {'bound': 'mfma', 'flops': int(work), 'avg_us': us, 'achieved_tflops': round(ach, 1), 'peak_tflops': round(peak, 1),
                          'frac': round(ach / peak, 4)}
         out[name]['ms_per_step'] = st['ms_per_step']
+        if name in ('mlp_fwd_fused', 'mlp_bwd_fused'):
+            # the bound that binds a fused row-panel kernel is not the matrix pipe.  Every workgroup (one per CU, 32 rows)
+            # streams ALL fragment-ordered weights of the stage from L2 (proj 256 KiB + fc1 1 MiB + fc2 1 MiB) at the measured 45 B/clk/CU
+            # (profiles/r03_l2stream.log), and the stage's stores drain at ~4.2 TB/s of pure writes (profiles/r03_store_bench.log), and the two
+            # ADD; the MFMA time is the three-pass work at the 2.5 PF peak.
+            wbytes = (256 * 256 + 2 * 1024 * 256) * 4
+            stored = np_ * 4.0 * ((256 + 256 + 1024 + 1024 + 256) if name == 'mlp_fwd_fused' else (1024 + 256 + 256))   # x1 z2 hraw act x2 | dh dx1 dao
+            t_stream = wbytes / (45.0 * 2.1e9) * 1e6          # us per workgroup at 45 B/clk, ~2.1 GHz under load
+            t_store = stored / 4.2e12 * 1e6
+            t_mfma = work / (gemm_peak * 1e12) * 1e6
+            out[name].update({'l2_stream_bytes_per_cu': wbytes, 'stored_bytes': int(stored), 'bound_us': {'weight_stream': round(t_stream, 1), 'store_drain': round(t_store, 1), 'mfma_3pass': round(t_mfma, 1)},
+                              'frac_of_binding_bound': round(max(t_stream, t_store, t_mfma) / us, 4), 'frac_of_stream_plus_store': round((t_stream + t_store) / us, 4)})
         if name == 'attn_bwd_fused':   # also HBM-side: reads f16 q/k/v + O + dO, writes dQ + f16 dK/dV partial rows + bias-gradient tiles
             rd = b * (nr // b * 768 * 2 + 2 * hw * 256 * 4)
             per = -(-(b * nw) // min(32, b * nw))        # window groups of the launch: cffm_hip.hip, attn_bwd_groups

@@ -779,8 +779,11 @@ static int cffa_slot(const cffm_geom* g, int slot, int nslots, CffaSlot* o) {
 // End of a range of block backwards (blocks first, first - 1, ..., last of a layer with `nslots` blocks; block i's parameters / gradients
 // at params[i] / grads[i], its workspace at ws0 + i * ws_stride): the reference frames of all of them in one pass (RB_MAXD blocks per
 // launch) -> dx_ref, then every CFFA parameter gradient of the range: norm1, the pooling matrix -> the pooling Linears, the pool biases.
+// `extra` (or NULL): record reductions of the caller that are due at this point of the stream anyway (the last block's parameter-gradient
+// tail): they join the final reduction launch instead of taking one of their own.
 static int cffa_finish(const cffm_geom* g, int nslots, const cffm_block_params* params, const cffm_block_grads* grads, int first, int last,
-                       const float* ws0, long ws_stride, const float* x_ref, long ref_bs, float* dx_ref, long dref_bs, int accum, void* stream) {
+                       const float* ws0, long ws_stride, const float* x_ref, long ref_bs, float* dx_ref, long dref_bs, int accum, void* stream,
+                       RedJobs* extra = nullptr) {
     cffm_block_ws L;
     cffm_block_ws_layout(g, &L);
     hipStream_t st = (hipStream_t)stream;
@@ -809,6 +812,10 @@ static int cffa_finish(const cffm_geom* g, int nslots, const cffm_block_params* 
             CffaSlot S;
             TRY(cffa_slot(g, i, nslots, &S));
             cffa_jobs(J, S.rec, rows, grads[i].norm1_w, grads[i].norm1_b, S.dM, grads[i].pool_b, st);
+        }
+        if (extra && hi - RB_MAXD < last) {        // (the range's last launch)
+            for (int j = 0; j < extra->njob; ++j) job_add(J, extra->part[j], extra->nblk[j], extra->stride[j], extra->total[j], extra->segs[j], st);
+            extra->njob = 0;
         }
         redq_launch(J, st);
         CHECK_LAUNCH("cffa reductions");
@@ -2267,7 +2274,15 @@ int cffm_layer_backward_rows(const cffm_geom* g, int depth, const cffm_block_par
                                 scratch, 1, (depth - 1 - i) & 1, i, depth, stream));
     }
     // the reference frames of every block in one pass + the CFFA parameter gradients, then the last block's parameter-gradient tail
-    TRY(cffa_finish(g, depth, params, grads, depth - 1, 0, blk0, L.total, x_rows, 4 * img, dx_rows, 4 * img, 0, stream));
+    RedJobs* tail_jobs = nullptr;
+#ifndef CFFM_EMU
+    if (tail_on_main() && g_tail.has) {
+        if (g_tail.cs) (void)hipStreamWaitEvent((hipStream_t)stream, g_side.cs_order, 0);
+        g_tail.has = g_tail.cs = false;
+        tail_jobs = &g_tail.jobs;
+    }
+#endif
+    TRY(cffa_finish(g, depth, params, grads, depth - 1, 0, blk0, L.total, x_rows, 4 * img, dx_rows, 4 * img, 0, stream, tail_jobs));
     TRY(tail_flush((hipStream_t)stream, tail_on_main()));
     side_join_all((hipStream_t)stream);
     return 0;
@@ -2380,7 +2395,15 @@ static int layer_backward_impl(const cffm_geom* g, int depth, const cffm_block_p
     // of dx_ref per range instead of a read + read-modify-write per block) and the range's CFFA parameter gradients.  A caller that
     // walks the layer block by block (data-parallel training, BlockwiseReducer) gets a pass per block, accumulating into dx_ref, so
     // that every block's gradient slice is complete when its range returns.
-    TRY(cffa_finish(g, depth, params, grads, first_block, last_block, blk0, L.total, xs, 4 * img, dxs, 4 * img, first_block != depth - 1, stream));
+    RedJobs* tail_jobs = nullptr;
+#ifndef CFFM_EMU
+    if (last_block == 0 && tail_on_main() && g_tail.has) {     // the last block's record reductions ride in the CFFA's final reduction launch
+        if (g_tail.cs) (void)hipStreamWaitEvent((hipStream_t)stream, g_side.cs_order, 0);
+        g_tail.has = g_tail.cs = false;
+        tail_jobs = &g_tail.jobs;
+    }
+#endif
+    TRY(cffa_finish(g, depth, params, grads, first_block, last_block, blk0, L.total, xs, 4 * img, dxs, 4 * img, first_block != depth - 1, stream, tail_jobs));
     // (dy_full: the upstream gradient of the whole [B,4,C,H,W] output -- its pass-through frames 0..2 join dx in the same pass)
     if (last_block == 0) {
         // the last block's parameter-gradient tail stays on the caller's stream, in front of the output transpose: no fork behind the

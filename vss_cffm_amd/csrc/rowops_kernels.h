@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(1024) k_reduce_records(const float* __restrict
 // The same for up to RED_MAXJOB record sets in one launch: the block backward defers its reductions (fc1 bias / LN2 + fc2/proj bias /
 // q|k|v bias) to its end, the layer backward those of the CFFA (LN1 + pooling) to the end of the range -- none of their results is read
 // earlier.
-#define RED_MAXJOB 6
+#define RED_MAXJOB 10
 struct RedJobs {
     int njob;
     int blk_end[RED_MAXJOB];        // exclusive prefix of 64-column workgroups per job
