@@ -769,6 +769,12 @@ def main():
         collective = {'allreduce_bytes_per_step': coll_info['allreduce_bytes_per_step'], 'allreduce_calls_per_step': coll_info['allreduce_calls_per_step'],
                       'first_call_bytes': coll_info['first_call_bytes'], 'capture_form': (nonlocal_note[-1] if nonlocal_note else 'three graphs + host-issued all-reduces'),
                       'exposed_wait_ms_per_step': round(waits[len(waits) // 2], 4), 'exposed_wait_note': 'median over %d steps of the interval around BlockwiseReducer.finish() in the three-graph form, rank 0' % n_probe}
+        # what a ring all-reduce of the LAST call's bytes (the one nothing is left to hide behind) costs on xGMI by arithmetic alone: 2 (N - 1) steps
+        # of bytes / N over one ~153 GB/s link each, plus ~2.5 us per step -- the number to hold the measured exposed wait against
+        last_bytes = coll_info['allreduce_bytes_per_step'] - coll_info['first_call_bytes'] if coll_info['allreduce_calls_per_step'] > 1 else coll_info['allreduce_bytes_per_step']
+        if world > 1:
+            collective['ring_estimate_us_last_call'] = round(2 * (world - 1) * (last_bytes / world / 153e9 * 1e6 + 2.5), 1)
+            collective['ring_estimate_note'] = 'arithmetic, not a measurement: 2 (N - 1) ring steps of bytes / N at ~153 GB/s per xGMI link + ~2.5 us per step, for the %d bytes of the last all-reduce of a step' % last_bytes
     with torch.no_grad():
         params_finite = bool(all(torch.isfinite(p).all().item() for p in params_list))
     ranks_in_sync = None

@@ -297,6 +297,50 @@ def test_gtc_block_vs_oracle_odd_prototype_counts(b, h, w, k):
         run_gtc_vs_oracle(torch.device('cpu'), b, h, w, k)
 
 
+def run_blockwise_backward_equals_whole(device, depth=3, h=8, w=9):
+    """The layer backward walked block by block (what data-parallel training does: cffm_layer_backward_range per block, a hook after each)
+    runs the CFFA reference pass once per RANGE, accumulating into dx of the reference frames; called whole it runs ONE pass over all
+    blocks.  Same gradients either way (summation order of the reference frames' dx differs: 1e-5)."""
+    import vss_cffm_amd as V
+    from vss_cffm_amd import ops
+    st = R.layer_state(depth, seed=41)
+    x = R.synth_input('x', (1, 4, 256, h, w), seed=42)
+    gy = R.synth_input('g', (1, 4, 256, h, w), seed=43, scale=1.0)
+    res = []
+    for hook in (None, lambda blk, flat, d: seen.append(blk)):
+        seen = []
+        m = V.BasicLayer3d3(dim=256, depth=depth, num_heads=8, window_size=7, expand_size=3, pool_method='fc', focal_level=2, focal_window=5,
+                            focal_l_clips=[1, 2, 3], focal_kernel_clips=[7, 5, 3])
+        m.load_state_dict(st, strict=False)
+        m.to(device)
+        xg = x.clone().to(device).requires_grad_(True)
+        was, ops.block_grad_hook = ops.block_grad_hook, hook
+        try:
+            (m(xg) * gy.to(device)).sum().backward()
+        finally:
+            ops.block_grad_hook = was
+        if hook is not None:
+            assert seen == list(range(depth - 1, -1, -1))
+        res.append((xg.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (dx0, g0), (dx1, g1) = res
+    assert H.rel_err(dx1, dx0) < 1e-5
+    for k in g0:
+        if g0[k].numel() == 1:
+            assert abs(float(g1[k]) - float(g0[k])) < 1e-4 * max(1.0, abs(float(g0[k]))), k
+        else:
+            assert H.rel_err(g1[k], g0[k]) < 1e-5, k
+
+
+def test_blockwise_backward_equals_whole_emulated():
+    with emu.active():
+        run_blockwise_backward_equals_whole(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_blockwise_backward_equals_whole_gpu():
+    run_blockwise_backward_equals_whole(torch.device('cuda'), depth=3, h=30, w=23)
+
+
 def test_upstream_gradient_slice_is_taken_with_its_stride():
     """backward(gradient on the whole [B,4,256,H,W] output) hands the last-frame slice over with its batch stride (no copy):
     same results as the dense gradient the sliced-loss form produces."""

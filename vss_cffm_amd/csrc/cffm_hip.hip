@@ -1202,7 +1202,9 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
 // 0.8914 vs 0.8843 ms per step without / with the stored activation, means of three alternating runs -- storing is the default)
 CFFM_SWITCH(store_act, "CFFM_STORE_ACT", 1)
 CFFM_SWITCH(panel_on, "CFFM_PANEL", 1)
+#ifndef MLP_MT
 #define MLP_MT 2
+#endif
 #define MLP_D 4
 static int mlp_lds_grant() {
 #ifndef CFFM_EMU
