@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 7
+#define CFFM_ABI_VERSION 8
 
 typedef struct cffm_geom {
     int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
@@ -355,12 +355,30 @@ int cffm_clip_format(const unsigned char* frames, const unsigned char* labels, f
                      float pad_val, int seg_pad_val, int reduce_zero_label, void* stream);
 /* the same with PhotoMetricDistortion_clips' brightness / contrast (mmseg/datasets/pipelines/transforms.py:2028-2150, convert() :2057)
  * between flip and normalisation, per frame: brightness_beta[t] / contrast_alpha[t] (HOST arrays of T floats, or NULL) -- NaN = branch
- * not taken for that frame; v = u8(clip(v + beta)), then v = u8(clip(v * alpha)) in float32 as numpy does.  The saturation / hue
- * branches (cv2 8-bit HSV) are not provided. */
+ * not taken for that frame; v = u8(clip(v + beta)), then v = u8(clip(v * alpha)) in float32 as numpy does.  (No saturation / hue:
+ * cffm_clip_format_hsv.) */
 int cffm_clip_format_photo(const unsigned char* frames, const unsigned char* labels, float* out_img, long long* out_lab, int T, int H,
                            int W, int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3],
                            int to_rgb, float pad_val, int seg_pad_val, int reduce_zero_label, const float* brightness_beta,
                            const float* contrast_alpha, void* stream);
+/* ABI 8: the whole of PhotoMetricDistortion_clips.__call__ (transforms.py:2112-2139) per frame: brightness, contrast when
+ * contrast_first[t] (the reference's mode == 1), saturation (:2082-2091: S of mmcv.bgr2hsv = cv2 COLOR_BGR2HSV scaled by saturation[t],
+ * convert()-style, back through COLOR_HSV2BGR), hue (:2093-2102: H + hue_shift[t] mod 180, its own round trip), contrast when
+ * !contrast_first[t].  HOST arrays of T entries or NULL; NaN = branch not taken; hue_shift holds integers.  The two colour conversions
+ * restate OpenCV's 8-bit arithmetic (color_hsv.cpp RGB2HSV_b: integer with the 12-bit division tables, hue range 180; HSV2RGB_b: float32
+ * through HSV2RGB_native, * 255, cvRound) -- OpenCV is not available where this library is built or tested, so that restatement is checked
+ * against oracle/cv_oracle.py only (parity unpinned). */
+int cffm_clip_format_hsv(const unsigned char* frames, const unsigned char* labels, float* out_img, long long* out_lab, int T, int H, int W,
+                         int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3], int to_rgb,
+                         float pad_val, int seg_pad_val, int reduce_zero_label, const float* brightness_beta, const float* contrast_alpha,
+                         const int* contrast_first, const float* saturation, const float* hue_shift, void* stream);
+/* ABI 8: cv2.resize of a clip, as mmcv.imrescale / imresize call it from Resize (transforms.py:475, config vspw_repeat2.py:10) and
+ * AlignedResize_clips (:236, config :27): frames [T,H,W,3] uint8 -> out_frames [T,Ho,Wo,3] with INTER_LINEAR (OpenCV's 8-bit path:
+ * 11-bit fixed-point weights, horizontal then vertical pass, the 2x2 -> 1 case as INTER_AREA's box mean), labels [T,H,W] uint8 ->
+ * out_labels [T,Ho,Wo] with INTER_NEAREST; either pair may be NULL.  The target size is the caller's (vss_cffm_amd/data.py applies
+ * mmcv.rescale_size and the size_divisor alignment).  Restated from resize.cpp; parity unpinned like cffm_clip_format_hsv. */
+int cffm_clip_resize(const unsigned char* frames, const unsigned char* labels, int T, int H, int W, unsigned char* out_frames,
+                     unsigned char* out_labels, int Ho, int Wo, void* stream);
 
 /* ---- parameter update of the training step (the reference trains the head with AdamW, lr 6e-5, betas (0.9, 0.999),
  * weight decay 0.01: local_configs/cffm/B1/cffm.b1.480x480.vspw2.160k.py:35) ----

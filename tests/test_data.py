@@ -61,14 +61,14 @@ def run_clip_cases(device):
         assert torch.equal(gt.cpu(), torch.from_numpy(g['photo/%d/gt' % clip_seed]))
         torch.testing.assert_close(img.cpu(), torch.from_numpy(g['photo/%d/img' % clip_seed]), rtol=0, atol=1e-6)
         assert any(v == v for v in params['photo']['beta'] + params['photo']['alpha'])       # (something was actually distorted)
-    # a stream that draws saturation / hue: those two steps are left out with ONE warning per instance by default, silently with
-    # on_hsv='skip', refused with on_hsv='raise'
+    # a stream that draws saturation / hue (applied by default since round 5: tests/test_data_cv.py): the policies that leave the two
+    # steps out -- ONE warning per instance with on_hsv='warn', silently with on_hsv='skip', refused with on_hsv='raise'
     np.random.seed(3)
     with pytest.raises(_lib.CffmError):
         for _ in range(8):
             D.PhotoMetricDistortionClips(on_hsv='raise').draw(4)
     np.random.seed(3)
-    dflt = D.PhotoMetricDistortionClips()
+    dflt = D.PhotoMetricDistortionClips(on_hsv='warn')
     with pytest.warns(RuntimeWarning, match='saturation / hue'):
         for _ in range(8):
             dflt.draw(4)

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp, ci, cl, cd, cf = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
 
@@ -118,6 +118,8 @@ SIGNATURES = {
     'cffm_rows_resize_bwd': (ci, [vp, cl, vp, cl, ci, ci, ci, ci, ci, ci, vp]),
     'cffm_clip_format': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.c_float * 3, C.c_float * 3, ci, C.c_float, ci, ci, vp]),
     'cffm_clip_format_photo': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.c_float * 3, C.c_float * 3, ci, C.c_float, ci, ci, vp, vp, vp]),
+    'cffm_clip_format_hsv': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.c_float * 3, C.c_float * 3, ci, C.c_float, ci, ci, vp, vp, vp, vp, vp, vp]),
+    'cffm_clip_resize': (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp]),
     'cffm_upce_blocks': (cl, [ci, ci, ci]),
     'cffm_upce_fwd': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     'cffm_upce_bwd': (ci, [vp, vp, vp, vp, C.c_float, vp, ci, ci, ci, ci, ci, ci, ci, vp]),

@@ -2175,8 +2175,16 @@ int cffm_clip_format_photo(const unsigned char* frames, const unsigned char* lab
                            int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3], int to_rgb,
                            float pad_val, int seg_pad_val, int reduce_zero_label, const float* brightness_beta, const float* contrast_alpha,
                            void* stream) {
+    return cffm_clip_format_hsv(frames, labels, out_img, out_lab, T, H, W, y1, x1, ch, cw, flip, Ho, Wo, mean, std, to_rgb, pad_val, seg_pad_val,
+                                reduce_zero_label, brightness_beta, contrast_alpha, nullptr, nullptr, nullptr, stream);
+}
+int cffm_clip_format_hsv(const unsigned char* frames, const unsigned char* labels, float* out_img, long long* out_lab, int T, int H, int W,
+                         int y1, int x1, int ch, int cw, int flip, int Ho, int Wo, const float mean[3], const float std[3], int to_rgb,
+                         float pad_val, int seg_pad_val, int reduce_zero_label, const float* brightness_beta, const float* contrast_alpha,
+                         const int* contrast_first, const float* saturation, const float* hue_shift, void* stream) {
     REQUIRE(T >= 0 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1, "clip_format: bad sizes");
-    REQUIRE(!(brightness_beta || contrast_alpha) || T <= CLIP_MAXT, "clip_format: at most %d frames with photometric parameters", CLIP_MAXT);
+    const bool any_photo = brightness_beta || contrast_alpha || saturation || hue_shift;
+    REQUIRE(!any_photo || T <= CLIP_MAXT, "clip_format: at most %d frames with photometric parameters", CLIP_MAXT);
     REQUIRE(y1 >= 0 && x1 >= 0 && ch >= 0 && cw >= 0 && y1 + ch <= H && x1 + cw <= W && ch <= Ho && cw <= Wo,
             "clip_format: crop box %d+%d x %d+%d does not fit a %dx%d frame / %dx%d output", y1, ch, x1, cw, H, W, Ho, Wo);
     if (!T) return 0;
@@ -2184,11 +2192,16 @@ int cffm_clip_format_photo(const unsigned char* frames, const unsigned char* lab
     ClipFmt P;
     P.T = T; P.H = H; P.W = W; P.y1 = y1; P.x1 = x1; P.ch = ch; P.cw = cw; P.flip = flip ? 1 : 0; P.Ho = Ho; P.Wo = Wo;
     P.to_rgb = to_rgb ? 1 : 0; P.reduce_zero_label = reduce_zero_label ? 1 : 0; P.seg_pad = seg_pad_val; P.pad_val = pad_val;
-    P.photo = (brightness_beta || contrast_alpha) ? 1 : 0;
+    P.photo = any_photo ? 1 : 0;
     for (int t = 0; t < CLIP_MAXT; ++t) {   // NaN = "not taken" (the reference draws a parameter only when the branch is taken)
         const float bt = (brightness_beta && t < T) ? brightness_beta[t] : NAN, al = (contrast_alpha && t < T) ? contrast_alpha[t] : NAN;
-        P.has_b[t] = bt == bt; P.has_c[t] = al == al;
+        const float sa = (saturation && t < T) ? saturation[t] : NAN, hu = (hue_shift && t < T) ? hue_shift[t] : NAN;
+        P.has_b[t] = bt == bt; P.has_c[t] = al == al; P.has_s[t] = sa == sa; P.has_h[t] = hu == hu;
         P.beta[t] = P.has_b[t] ? bt : 0.f; P.alpha[t] = P.has_c[t] ? al : 1.f;
+        P.sat[t] = P.has_s[t] ? sa : 1.f;
+        REQUIRE(!P.has_h[t] || (hu == (float)(int)hu && hu > -100000.f && hu < 100000.f), "clip_format: the hue shift of frame %d is not an integer", t);
+        P.hue[t] = P.has_h[t] ? (int)hu : 0;
+        P.c_first[t] = (contrast_first && t < T && contrast_first[t]) ? 1 : 0;
     }
     for (int c = 0; c < 3; ++c) {
         REQUIRE(std[c] != 0.f, "clip_format: zero std");
@@ -2198,6 +2211,21 @@ int cffm_clip_format_photo(const unsigned char* frames, const unsigned char* lab
     const long n = (long)T * Ho * Wo, want = (n + 255) / 256;
     CFFM_LAUNCH(k_clip_format, ((unsigned)(want < 8192 ? want : 8192)), (256), 0, (hipStream_t)stream, frames, labels, out_img, out_lab, P);
     CHECK_LAUNCH("clip_format");
+    return 0;
+}
+int cffm_clip_resize(const unsigned char* frames, const unsigned char* labels, int T, int H, int W, unsigned char* out_frames,
+                     unsigned char* out_labels, int Ho, int Wo, void* stream) {
+    REQUIRE(T >= 0 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1 && H < (1 << 15) && W < (1 << 15) && Ho < (1 << 15) && Wo < (1 << 15), "clip_resize: bad sizes");
+    if (!T) return 0;
+    REQUIRE((frames || labels) && (!frames || out_frames) && (!labels || out_labels), "clip_resize: null");
+    ClipResize P;
+    P.T = T; P.H = H; P.W = W; P.Ho = Ho; P.Wo = Wo;
+    P.scale_x = 1.0 / ((double)Wo / (double)W);          // scale_x = 1. / inv_scale_x, as cv::resize computes it
+    P.scale_y = 1.0 / ((double)Ho / (double)H);
+    P.half = (W == 2 * Wo && H == 2 * Ho) ? 1 : 0;
+    const long n = (long)T * Ho * Wo, want = (n + 255) / 256;
+    CFFM_LAUNCH(k_clip_resize, ((unsigned)(want < 8192 ? want : 8192)), (256), 0, (hipStream_t)stream, frames, labels, out_frames, out_labels, P);
+    CHECK_LAUNCH("clip_resize");
     return 0;
 }
 

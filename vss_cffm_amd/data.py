@@ -58,28 +58,26 @@ class PhotoMetricDistortionClips:
     """The random decisions of ``PhotoMetricDistortion_clips`` (pipelines/transforms.py:2028-2150), drawn per FRAME in the reference's
     order: ``randint(2)`` brightness (+ ``uniform(-delta, delta)``), ``randint(2)`` mode, [mode 1: ``randint(2)`` contrast (+ ``uniform``)],
     ``randint(2)`` saturation (+ ``uniform``), ``randint(2)`` hue (+ ``randint(-delta, delta)``), [mode 0: contrast] -- so a seeded run stays in
-    step with the reference's stream.  Brightness and contrast are applied by the clip kernel (``convert()``, :2057-2061, in float32 as
-    numpy does).  Saturation and hue go through cv2's 8-bit BGR<->HSV conversion (mmcv.bgr2hsv / hsv2bgr), whose rounding cannot be
-    pinned without cv2: a frame that draws them has just those two steps left out -- a documented deviation, never an approximation of
-    the colour conversion -- with one RuntimeWarning per instance (``on_hsv='warn'``, the default: each step is taken with probability
-    1/2 per frame, so a policy that refuses them refuses 15 of 16 four-frame clips), silently (``'skip'``), or raises (``'raise'``:
-    for runs that must match the reference's augmentation bit for bit or not run at all).  ``draw()`` returns the drawn saturation
-    factors and hue shifts per frame in every mode, so a caller whose host has cv2 can see which frames the reference would have
-    distorted further (the two steps sit BETWEEN brightness / first contrast and the late contrast of `convert()` mode 0, so they cannot
-    simply be applied to the frames before or after this class)."""
+    step with the reference's stream.  The clip kernel applies all of them (``cffm_clip_format_hsv``): brightness and contrast as
+    ``convert()`` does (:2057-2061, float32 like numpy), saturation and hue through OpenCV's 8-bit BGR <-> HSV arithmetic
+    (mmcv.bgr2hsv / hsv2bgr = ``cv2.cvtColor``), restated from OpenCV's published source because neither mmcv nor cv2 exists in the
+    boxes this was built and tested in: those two steps are checked against ``oracle/cv_oracle.py`` only (parity unpinned).
+    ``on_hsv``: ``'apply'`` (default); ``'skip'`` leaves the two HSV steps out silently, ``'warn'`` with one RuntimeWarning per instance,
+    ``'raise'`` refuses a clip that draws them (for runs that accept nothing unpinned).  ``draw()`` returns every decision in all modes."""
 
-    def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, on_hsv='warn',
+    def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, on_hsv='apply',
                  np_random=np.random):
-        if on_hsv not in ('raise', 'skip', 'warn'):
-            raise ValueError("on_hsv must be 'warn', 'skip' or 'raise'")
+        if on_hsv not in ('apply', 'raise', 'skip', 'warn'):
+            raise ValueError("on_hsv must be 'apply', 'warn', 'skip' or 'raise'")
         self._warned = False
         self.brightness_delta, self.contrast_range = brightness_delta, tuple(contrast_range)
         self.saturation_range, self.hue_delta, self.on_hsv, self.rng = tuple(saturation_range), hue_delta, on_hsv, np_random
 
     def draw(self, n_frames):
-        """-> dict(beta [T], alpha [T] (NaN = not taken), saturation [T], hue [T] (None = not taken))."""
+        """-> dict(beta [T], alpha [T] (NaN = not taken), contrast_first [T] (the reference's mode == 1), saturation [T], hue [T]
+        (None = not taken), apply_hsv)."""
         r = self.rng
-        beta, alpha, sat, hue = [], [], [], []
+        beta, alpha, first, sat, hue = [], [], [], [], []
         for _ in range(n_frames):
             b = float(r.uniform(-self.brightness_delta, self.brightness_delta)) if r.randint(2) else float('nan')
             mode = int(r.randint(2))
@@ -90,16 +88,116 @@ class PhotoMetricDistortionClips:
             h_ = int(r.randint(-self.hue_delta, self.hue_delta)) if r.randint(2) else None
             if mode == 0 and r.randint(2):
                 a = float(r.uniform(*self.contrast_range))
-            beta.append(b); alpha.append(a); sat.append(s_); hue.append(h_)
-        if self.on_hsv == 'raise' and any(v is not None for v in sat + hue):
-            raise _lib.CffmError('PhotoMetricDistortionClips: a frame drew the saturation / hue distortion, which needs cv2\'s 8-bit HSV '
-                                 'conversion (not available here; on_hsv=\'skip\' leaves those two steps out)')
-        if self.on_hsv == 'warn' and not self._warned and any(v is not None for v in sat + hue):
+            beta.append(b); alpha.append(a); first.append(mode == 1); sat.append(s_); hue.append(h_)
+        drew_hsv = any(v is not None for v in sat + hue)
+        if self.on_hsv == 'raise' and drew_hsv:
+            raise _lib.CffmError('PhotoMetricDistortionClips: a frame drew the saturation / hue distortion, whose OpenCV arithmetic is '
+                                 'restated here without a cv2 to pin it against (on_hsv=\'apply\' applies it, \'skip\' leaves the two steps out)')
+        if self.on_hsv == 'warn' and not self._warned and drew_hsv:
             import warnings
             warnings.warn('PhotoMetricDistortionClips: the saturation / hue steps (cv2 8-bit HSV arithmetic) are left out; brightness and '
-                          'contrast are applied as the reference does (on_hsv=\'raise\' refuses such frames instead)', RuntimeWarning, stacklevel=2)
+                          'contrast are applied as the reference does (on_hsv=\'apply\' applies them too)', RuntimeWarning, stacklevel=2)
             self._warned = True
-        return dict(beta=beta, alpha=alpha, saturation=sat, hue=hue)
+        return dict(beta=beta, alpha=alpha, contrast_first=first, saturation=sat, hue=hue, apply_hsv=self.on_hsv == 'apply')
+
+
+def _imrescale_size(w, h, scale):
+    """mmcv.rescale_size((w, h), scale): a (long edge, short edge) bound -> (new_w, new_h), ``int(x * factor + 0.5)``."""
+    f = min(max(scale) / max(h, w), min(scale) / min(h, w))
+    return int(w * float(f) + 0.5), int(h * float(f) + 0.5)
+
+
+def resize_clip(frames, labels, size):
+    """``cv2.resize`` of a clip on the device: frames [T,H,W,3] uint8 -> [T,h,w,3] (INTER_LINEAR), labels [T,H,W] uint8 -> [T,h,w]
+    (INTER_NEAREST); ``size = (w, h)`` as mmcv / cv2 take it; either input may be None."""
+    lib = _lib.get()
+    ref = frames if frames is not None else labels
+    for t, what in ((frames, 'frames'), (labels, 'labels')):
+        if t is None:
+            continue
+        if t.dtype != torch.uint8:
+            raise _lib.CffmError('resize_clip: %s must be uint8, got %s' % (what, t.dtype))
+        if _lib._override is None and not t.is_cuda:
+            raise _lib.CffmError('resize_clip: %s are on %s; the kernel runs only on the GPU (no CPU fallback)' % (what, t.device))
+    if frames is not None and (frames.dim() != 4 or frames.shape[3] != 3) or (labels is not None and labels.dim() != 3) or \
+            (frames is not None and labels is not None and labels.shape != frames.shape[:3]):
+        raise _lib.CffmError('resize_clip: frames [T,H,W,3] and labels [T,H,W] expected')
+    t, h, w = ref.shape[:3]
+    nw, nh = int(size[0]), int(size[1])
+    frames = frames.contiguous() if frames is not None else None
+    labels = labels.contiguous() if labels is not None else None
+    out_f = torch.empty(t, nh, nw, 3, dtype=torch.uint8, device=ref.device) if frames is not None else None
+    out_l = torch.empty(t, nh, nw, dtype=torch.uint8, device=ref.device) if labels is not None else None
+    stream = C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream) if ref.is_cuda else C.c_void_p(0)
+    ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
+    _lib.check(lib.cffm_clip_resize(ptr(frames), ptr(labels), t, h, w, ptr(out_f), ptr(out_l), nh, nw, stream), lib)
+    return out_f, out_l
+
+
+class ResizeClips:
+    """``Resize(img_scale=(853, 480), ratio_range=(0.5, 2.0), process_clips=True)`` of the training pipeline
+    (local_configs/_base_/datasets/vspw_repeat2.py:10; mmseg/datasets/pipelines/transforms.py:475-760): one ratio per clip
+    (``np.random.random_sample() * (max - min) + min``, ``scale = (int(853 r), int(480 r))``, :625-637), every frame through
+    ``mmcv.imrescale(keep_ratio)`` -- bilinear for the frames, nearest for the label maps.  ``draw()`` makes the random decision in the
+    reference's order, ``apply()`` runs the kernel (``cffm_clip_resize``: OpenCV's 8-bit resize arithmetic restated, parity unpinned)."""
+
+    def __init__(self, img_scale=(853, 480), ratio_range=(0.5, 2.0), keep_ratio=True, np_random=np.random):
+        if isinstance(img_scale, list):
+            if len(img_scale) != 1:
+                raise NotImplementedError('ResizeClips: one img_scale (modes 3 / 4 of the reference, several scales, are not used by any CFFM config)')
+            img_scale = img_scale[0]
+        self.img_scale = tuple(img_scale) if img_scale is not None else None
+        self.ratio_range = tuple(ratio_range) if ratio_range is not None else None
+        self.keep_ratio, self.rng = keep_ratio, np_random
+
+    def draw(self, shape):
+        """-> the ``scale`` tuple of the reference's ``results['scale']`` for a clip of frame shape (H, W)."""
+        if self.ratio_range is None:
+            if self.img_scale is None:
+                raise _lib.CffmError('ResizeClips: neither img_scale nor ratio_range')
+            return self.img_scale
+        base = self.img_scale if self.img_scale is not None else (shape[1], shape[0])
+        lo, hi = self.ratio_range
+        ratio = self.rng.random_sample() * (hi - lo) + lo
+        return int(base[0] * ratio), int(base[1] * ratio)
+
+    def size_for(self, shape, scale):
+        h, w = shape
+        return _imrescale_size(w, h, scale) if self.keep_ratio else (int(scale[0]), int(scale[1]))
+
+    def apply(self, frames, labels, scale):
+        ref = frames if frames is not None else labels
+        return resize_clip(frames, labels, self.size_for(tuple(ref.shape[1:3]), scale))
+
+    def __call__(self, frames, labels=None):
+        ref = frames if frames is not None else labels
+        scale = self.draw(tuple(ref.shape[1:3]))
+        return self.apply(frames, labels, scale) + (scale,)
+
+
+class AlignedResizeClips(ResizeClips):
+    """``AlignedResize_clips(keep_ratio=True, size_divisor=32)`` of the test pipeline (vspw_repeat2.py:27; transforms.py:236-470): the
+    frames through ``mmcv.imrescale`` to ``img_scale`` (``MultiScaleFlipAug`` supplies (853, 480)), then ``_align`` (:394-401): a second
+    ``mmcv.imresize`` to the next multiples of ``size_divisor`` -- two resizes, as the reference does them (the intermediate image is
+    rounded to uint8 in between)."""
+
+    def __init__(self, img_scale=(853, 480), ratio_range=None, keep_ratio=True, size_divisor=32, np_random=np.random):
+        super().__init__(img_scale, ratio_range, keep_ratio, np_random)
+        self.size_divisor = size_divisor
+
+    def apply(self, frames, labels, scale):
+        ref = frames if frames is not None else labels
+        d = self.size_divisor
+        if not self.keep_ratio:
+            nw, nh = int(scale[0]), int(scale[1])
+            if nh % d or nw % d:
+                raise _lib.CffmError('AlignedResizeClips: img size not align. h:%d w:%d' % (nh, nw))     # the reference's assert (:430)
+            return resize_clip(frames, labels, (nw, nh))
+        f, l = resize_clip(frames, labels, self.size_for(tuple(ref.shape[1:3]), scale))
+        ref = f if f is not None else l
+        h, w = ref.shape[1:3]
+        ah, aw = -(-h // d) * d, -(-w // d) * d
+        return resize_clip(f, l, (aw, ah))       # (same size: the kernel copies, as cv2.resize does)
 
 
 class ClipFormatter:
@@ -171,10 +269,16 @@ class ClipFormatter:
             raise _lib.CffmError('ClipFormatter: photometric parameters for %d frames, clip has %d' % (len(ph['beta']), t))
         beta = (C.c_float * t)(*ph['beta']) if ph is not None else None
         alpha = (C.c_float * t)(*ph['alpha']) if ph is not None else None
-        _lib.check(lib.cffm_clip_format_photo(ptr(frames), ptr(labels), ptr(img), ptr(lab), t, h, w, params['y1'], params['x1'], params['ch'],
-                                              params['cw'], int(params['flip']), ho, wo, (C.c_float * 3)(*self.mean),
-                                              (C.c_float * 3)(*self.std), int(self.to_rgb), float(self.pad_val), int(self.seg_pad_val),
-                                              int(self.rzl), beta, alpha, stream), lib)
+        first = sat = hue = None
+        if ph is not None and ph.get('apply_hsv'):
+            nan = float('nan')
+            first = (C.c_int * t)(*[int(bool(v)) for v in ph['contrast_first']])
+            sat = (C.c_float * t)(*[nan if v is None else float(v) for v in ph['saturation']])
+            hue = (C.c_float * t)(*[nan if v is None else float(int(v)) for v in ph['hue']])
+        _lib.check(lib.cffm_clip_format_hsv(ptr(frames), ptr(labels), ptr(img), ptr(lab), t, h, w, params['y1'], params['x1'], params['ch'],
+                                            params['cw'], int(params['flip']), ho, wo, (C.c_float * 3)(*self.mean),
+                                            (C.c_float * 3)(*self.std), int(self.to_rgb), float(self.pad_val), int(self.seg_pad_val),
+                                            int(self.rzl), beta, alpha, first, sat, hue, stream), lib)
         return img, lab
 
     def __call__(self, frames, labels, last_label_host=None):
