@@ -183,6 +183,34 @@ def run_photo_hsv_cases(device):
     assert D.PhotoMetricDistortionClips().draw(2)['apply_hsv']
 
 
+def test_load_clip_decodes_like_the_reference_loaders(tmp_path):
+    """LoadAnnotations decodes with Pillow ('unchanged', squeeze, uint8): the same call, bit for bit; lossless frames come back exactly, in
+    BGR order; clips whose frames differ in size or that carry an EXIF rotation are refused."""
+    from PIL import Image
+    frames, labels = _clip(60, 3, 20, 28)
+    ips, mps = [], []
+    for i in range(3):
+        ips.append(str(tmp_path / ('%08d.png' % i))); mps.append(str(tmp_path / ('m%08d.png' % i)))
+        Image.fromarray(frames[i][:, :, ::-1]).save(ips[-1])          # the file holds RGB; the loader hands back BGR as cv2 would
+        Image.fromarray(labels[i], mode='L').save(mps[-1])
+    f, l = D.load_clip(ips, mps)
+    assert f.dtype == torch.uint8 and np.array_equal(f.numpy(), frames) and np.array_equal(l.numpy(), labels)
+    f, l = D.load_clip(ips[:2])
+    assert l is None and f.shape == (2, 20, 28, 3)
+    pal = Image.fromarray(labels[0], mode='P'); pal.putpalette([i % 256 for i in range(768)]); pal.save(mps[0])     # palette PNGs (VSPW masks): indices, not colours
+    assert np.array_equal(D.load_clip(ips[:1], mps[:1])[1].numpy()[0], labels[0])
+    jp = str(tmp_path / 'a.jpg')
+    Image.fromarray(frames[0][:, :, ::-1]).save(jp, quality=90)
+    fj, _ = D.load_clip([jp])
+    assert fj.shape == (1, 20, 28, 3) and np.abs(fj.numpy()[0].astype(int) - frames[0]).mean() < 12           # lossy, BGR order kept
+    Image.fromarray(frames[0][:10, :, ::-1]).save(ips[1])
+    with pytest.raises(_lib.CffmError):
+        D.load_clip(ips)
+    ex = Image.fromarray(frames[0][:, :, ::-1]); exif = ex.getexif(); exif[0x0112] = 6; ex.save(jp, exif=exif)
+    with pytest.raises(_lib.CffmError):
+        D.load_clip([jp])
+
+
 def test_clip_resize_emulated():
     with emu.active():
         run_resize_cases(torch.device('cpu'))

@@ -289,6 +289,35 @@ class ClipFormatter:
         return self.apply(frames, labels, params) + (params,)
 
 
+def load_clip(img_paths, mask_paths=None, device=None):
+    """``LoadImageFromFile`` + ``LoadAnnotations`` (mmseg/datasets/pipelines/loading.py:10-88, :91-155) for the frames of one clip:
+    -> (frames [T,H,W,3] uint8 BGR, labels [T,H,W] uint8 or None) on ``device``.
+
+    The reference decodes label maps with Pillow (``imdecode_backend='pillow'``, flag ``'unchanged'``, ``squeeze().astype(uint8)``: :133-135)
+    -- done the same way here, bit for bit (PNG is lossless) -- and images with ``cv2.imdecode`` (colour, BGR).  cv2 is not available
+    here, so images are decoded with Pillow and flipped to BGR: identical for lossless formats; for JPEG both sit on libjpeg(-turbo)'s
+    default decoder, whose output is build-dependent in the last bit for the reference too.  (cv2 also honours an EXIF orientation tag;
+    VSPW frames carry none, and a file that does is refused rather than silently left unrotated.)"""
+    from PIL import Image
+    frames, labels = [], []
+    for p_ in img_paths:
+        with Image.open(p_) as im:
+            if im.getexif().get(0x0112, 1) not in (0, 1):
+                raise _lib.CffmError('load_clip: %s carries an EXIF orientation, which cv2.imdecode would apply' % p_)
+            frames.append(np.asarray(im.convert('RGB'))[:, :, ::-1])
+    for p_ in (mask_paths or []):
+        with Image.open(p_) as im:
+            labels.append(np.asarray(im).squeeze().astype(np.uint8))
+    shapes = {f.shape[:2] for f in frames} | {l.shape[:2] for l in labels}
+    if len(shapes) != 1 or (labels and len(labels) != len(frames)) or any(l.ndim != 2 for l in labels):
+        raise _lib.CffmError('load_clip: the frames / label maps of a clip must share one size (got %s)' % sorted(shapes))
+    f = torch.from_numpy(np.ascontiguousarray(np.stack(frames)))
+    l = torch.from_numpy(np.ascontiguousarray(np.stack(labels))) if labels else None
+    if device is not None:
+        f, l = f.to(device), (l.to(device) if l is not None else None)
+    return f, l
+
+
 class ClipLister:
     """The video / frame lists of ``CustomDataset_video2`` (mmseg/datasets/custom.py:1959-2100) and the clips it serves.
 
