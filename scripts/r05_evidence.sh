@@ -10,6 +10,7 @@
 #   r05_gtc_step.json, r05_gtc_kernel_stats.csv, r05_gtc_fused_vs_unfused.txt   the CFFM++ prototype layer (BASELINE config 5)
 #   r05_dw_dma_bench.txt           the LDS-DMA weight-gradient kernel against the register-staged group
 #   r05_gpu_suite.txt              tail of pytest -m gpu
+
 cd "$(dirname "$0")/.." && R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out/pmc
 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; tail -2 gpurun_out/r05_bench.err
 (cd /tmp && rm -rf /tmp/bp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp -o x -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-head-step --no-gtc-step --spinup-steps 100 > $R/gpurun_out/r05_bench_prof.json 2>/dev/null)
