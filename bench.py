@@ -546,12 +546,27 @@ def main():
                 for p_, g_ in zip(ordered, lp.grads):
                     p_.grad = g_
                 gy_last = gy[:, -1]
+                # Gradient exchange at N > 1 (CFFM_BENCH_EXCHANGE):
+                #   'whole' (default since round 5): the whole backward as ONE library call, then ONE all-reduce of the flat gradient buffer.
+                #     Round 5 made the CFFA backward's reference-frame pass a once-per-RANGE kernel (one read of x_ref, one write of dx_ref per
+                #     step); a backward cut between the blocks pays that pass per block and loses the chain layout of the whole-layer call --
+                #     with ONE rank (no data moving) the cut form measured 0.80-0.89 ms per step against 0.69 for the whole layer, i.e. it costs
+                #     more than the ~0.08 ms an exposed 6.8 MB ring all-reduce is estimated at;
+                #   'blockwise': backward of blocks depth-1..1 | all-reduce(their slices) || backward of block 0 | all-reduce(block 0's slice).
+                blockwise = os.environ.get('CFFM_BENCH_EXCHANGE', 'whole') == 'blockwise' and DEPTH > 1
+                avg_ok = dist.get_backend() == 'nccl' and hasattr(dist.ReduceOp, 'AVG')
+
+                def exchange_whole():
+                    w_ = dist.all_reduce(lp.flat, op=dist.ReduceOp.AVG if avg_ok else dist.ReduceOp.SUM, async_op=True)
+                    w_.wait()
+                    if not avg_ok:
+                        lp.flat.div_(dist.get_world_size())
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
                     lp.forward()
-                    lp.backward(gy_last, DEPTH - 1, min(1, DEPTH - 1))
+                    lp.backward(gy_last, DEPTH - 1, min(1, DEPTH - 1) if blockwise else 0)
                 ga2 = None
-                if DEPTH > 1:
+                if blockwise:
                     ga2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(ga2, pool=ga.pool()):
                         lp.backward(gy_last, 0, 0)
@@ -563,27 +578,33 @@ def main():
                 lib.cffm_profile_sample_every(1)
                 lib.cffm_profile_collect(ms_buf, n_buf)
             red = V.distributed.BlockwiseReducer(single_rank_too=force1)
-            upper = lp.flat[lp.per_block:] if DEPTH > 1 else lp.flat
+            upper = lp.flat[lp.per_block:] if blockwise else lp.flat
+            form_graphs = ('graph(forward + backward of block 1) | all-reduce(block 1) overlapping graph(backward of block 0) | all-reduce(block 0) | graph(AdamW)'
+                           if blockwise else 'graph(forward + backward) | ONE all-reduce of the flat gradient buffer | graph(AdamW)')
 
-            def replay_step(ev=None):       # the three-graph form: graphs + host-issued all-reduces
+            def replay_step(ev=None):       # graphs + host-issued all-reduce(s)
                 ga.replay()
-                red.start(DEPTH - 1, upper)
-                if ga2 is not None:
+                if blockwise:
+                    red.start(DEPTH - 1, upper)
                     ga2.replay()
                     red.start(0, lp.block_slice(0))
-                if ev is not None:
-                    ev[0].record()
-                red.finish()              # the compute stream waits here for whatever part of the exchange the backward did not cover
+                    if ev is not None:
+                        ev[0].record()
+                    red.finish()          # the compute stream waits here for whatever part of the exchange the backward did not cover
+                else:
+                    if ev is not None:
+                        ev[0].record()
+                    exchange_whole()      # (nothing to hide behind: the whole exchange is exposed)
                 if ev is not None:
                     ev[1].record()
                 gb.replay()
-            coll_info.update(allreduce_bytes_per_step=int(lp.flat.numel() * 4), allreduce_calls_per_step=2 if DEPTH > 1 else 1,
-                             first_call_bytes=int(upper.numel() * 4), probe=replay_step)
+            coll_info.update(allreduce_bytes_per_step=int(lp.flat.numel() * 4), allreduce_calls_per_step=2 if blockwise else 1,
+                             first_call_bytes=int(upper.numel() * 4), probe=replay_step, form=form_graphs, blockwise=blockwise)
             if try_coll:
-                # default at N > 1: the whole step INCLUDING the RCCL all-reduces as ONE graph -- one graph launch
-                # instead of three + two host-issued collectives (~0.06 ms per step with one rank).  A capture that fails on ANY rank
-                # sends EVERY rank back to the three-graph form above: the ranks agree on the outcome with an (eager) all-reduce, so
-                # nobody replays a graph whose peers are missing.  CFFM_BENCH_GRAPH_COLLECTIVES=0 skips the attempt.
+                # default at N > 1: the whole step INCLUDING the RCCL all-reduce(s) as ONE graph -- one graph launch
+                # instead of two or three + host-issued collectives.  A capture that fails on ANY rank sends EVERY rank back to the
+                # several-graph form above: the ranks agree on the outcome with an (eager) all-reduce, so nobody replays a graph whose
+                # peers are missing.  CFFM_BENCH_GRAPH_COLLECTIVES=0 skips the attempt.
                 ok, g1 = 1, None
                 if with_events:
                     lib.cffm_profile_collect_graph(ms_buf, n_buf, 1)
@@ -593,17 +614,20 @@ def main():
                     g1 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, pool=ga.pool()):
                         lp.forward()
-                        lp.backward(gy_last, DEPTH - 1, min(1, DEPTH - 1))
-                        works = [dist.all_reduce(upper, op=dist.ReduceOp.AVG, async_op=True)]
-                        if DEPTH > 1:
+                        if blockwise:
+                            lp.backward(gy_last, DEPTH - 1, 1)
+                            works = [dist.all_reduce(upper, op=dist.ReduceOp.AVG, async_op=True)]
                             lp.backward(gy_last, 0, 0)
                             works.append(dist.all_reduce(lp.block_slice(0), op=dist.ReduceOp.AVG, async_op=True))
-                        for w_ in works:
-                            w_.wait()
+                            for w_ in works:
+                                w_.wait()
+                        else:
+                            lp.backward(gy_last, DEPTH - 1, 0)
+                            exchange_whole()
                         opt.step()
                 except Exception as e:   # noqa: BLE001
                     ok = 0
-                    sys.stderr.write('bench.py: rank %d: capturing the collectives failed (%s); every rank falls back to three graphs\n' % (rank, str(e).splitlines()[0][:120] if str(e) else type(e).__name__))
+                    sys.stderr.write('bench.py: rank %d: capturing the collectives failed (%s); every rank falls back to separate graphs\n' % (rank, str(e).splitlines()[0][:120] if str(e) else type(e).__name__))
                     torch.cuda.synchronize(dev)
                 finally:
                     lib.cffm_profile_enable(0)
@@ -612,9 +636,10 @@ def main():
                 agree = torch.tensor([ok], device=dev, dtype=torch.int32)
                 dist.all_reduce(agree, op=dist.ReduceOp.MIN)
                 if int(agree.item()) == 1:
-                    nonlocal_note.append('ONE graph per step with the RCCL all-reduces captured inside (every rank captured it; CFFM_BENCH_GRAPH_COLLECTIVES=0 selects three graphs + host-issued all-reduces)')
+                    nonlocal_note.append('ONE graph per step with the RCCL all-reduce%s captured inside: %s (every rank captured it; CFFM_BENCH_GRAPH_COLLECTIVES=0 selects separate graphs + host-issued all-reduces)'
+                                         % ('s' if blockwise else '', 'forward, backward of block 1, all-reduce, backward of block 0, all-reduce, AdamW' if blockwise else 'forward, backward, ONE all-reduce of the flat gradient buffer, AdamW'))
                     return g1.replay
-                nonlocal_note.append('three graphs + host-issued all-reduces (the one-graph capture with RCCL inside failed on at least one rank)')
+                nonlocal_note.append(form_graphs + ' (the one-graph capture with RCCL inside failed on at least one rank)')
 
             return replay_step
 
@@ -767,8 +792,8 @@ def main():
         torch.cuda.synchronize(dev)
         waits = sorted(a.elapsed_time(b_) for a, b_ in evs)
         collective = {'allreduce_bytes_per_step': coll_info['allreduce_bytes_per_step'], 'allreduce_calls_per_step': coll_info['allreduce_calls_per_step'],
-                      'first_call_bytes': coll_info['first_call_bytes'], 'capture_form': (nonlocal_note[-1] if nonlocal_note else 'three graphs + host-issued all-reduces'),
-                      'exposed_wait_ms_per_step': round(waits[len(waits) // 2], 4), 'exposed_wait_note': 'median over %d steps of the interval around BlockwiseReducer.finish() in the three-graph form, rank 0' % n_probe}
+                      'first_call_bytes': coll_info['first_call_bytes'], 'capture_form': (nonlocal_note[-1] if nonlocal_note else coll_info.get('form')),
+                      'exposed_wait_ms_per_step': round(waits[len(waits) // 2], 4), 'exposed_wait_note': ('median over %d steps of the interval around BlockwiseReducer.finish() in the several-graph form, rank 0' if coll_info.get('blockwise') else 'median over %d steps of the interval around the ONE all-reduce (issue + wait: all of it is exposed) in the separate-graphs form, rank 0') % n_probe}
         # what a ring all-reduce of the LAST call's bytes (the one nothing is left to hide behind) costs on xGMI by arithmetic alone: 2 (N - 1) steps
         # of bytes / N over one ~153 GB/s link each, plus ~2.5 us per step -- the number to hold the measured exposed wait against
         last_bytes = coll_info['allreduce_bytes_per_step'] - coll_info['first_call_bytes'] if coll_info['allreduce_calls_per_step'] > 1 else coll_info['allreduce_bytes_per_step']
@@ -872,8 +897,8 @@ def main():
             'data_note': ('every step consumes the SAME resident synthetic clip batch (29.5 MB at B = 2) and upstream gradient: they stay in the 256 MB MALL '
                           'between steps, so a step does not pay the first-touch HBM read a fresh batch would (~7 us at ~4 TB/s, ~1 % of the step)'),
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
-                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'ranks_in_sync': ranks_in_sync, 'params_finite': params_finite, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else (nonlocal_note[-1] if nonlocal_note else 'graph(forward + backward of block 1) | all-reduce(block 1) overlapping graph(backward of block 0) | all-reduce(block 0) | graph(AdamW)')),
-                       'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else 'RCCL, one asynchronous all-reduce per block of the flat gradient buffer, overlapped with the backward of the next block') if multi else 'none'},
+                       'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'ranks_in_sync': ranks_in_sync, 'params_finite': params_finite, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else (nonlocal_note[-1] if nonlocal_note else coll_info.get('form'))),
+                       'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else ('RCCL, one asynchronous all-reduce per block of the flat gradient buffer, overlapped with the backward of the next block' if coll_info.get('blockwise') else 'RCCL, ONE all-reduce of the flat gradient buffer (6.8 MB) behind the backward; CFFM_BENCH_EXCHANGE=blockwise selects the per-block overlapped form')) if multi else 'none'},
             'roofline': roof, 'roofline_kernels': rk, 'head_step': hs, 'gtc_step': gs,
             'rccl': {'world': world, 'backend': (dist.get_backend() if multi else None)}, 'collective': collective,
             'tolerance': {'forward': 5e-4, 'gradients': 2e-3, 'contract': 1e-3,

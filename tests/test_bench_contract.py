@@ -71,20 +71,24 @@ def test_bench_self_launches_two_ranks():
 
 
 @pytest.mark.gpu
-def test_bench_single_rank_over_rccl_takes_the_one_graph_form():
-    """The default N > 1 path -- ONE graph per step with the RCCL all-reduces captured inside -- cannot be run with real peers on a
+@pytest.mark.parametrize('exchange', ['whole', 'blockwise'])
+def test_bench_single_rank_over_rccl_takes_the_one_graph_form(exchange):
+    """The default N > 1 path -- ONE graph per step with the RCCL all-reduce captured inside -- cannot be run with real peers on a
     one-GPU box; with CFFM_BENCH_FORCE_DIST the same code runs as a one-rank RCCL group: the capture must be the form taken, the
-    parameters stay finite and in sync, and the line carries what the exchange moves and how long the compute stream waits for it."""
-    env = dict(os.environ, PYTHONPATH=ROOT, CFFM_BENCH_FORCE_DIST='1')
+    parameters stay finite and in sync, and the line carries what the exchange moves and how long the compute stream waits for it.
+    Both forms of the exchange: ONE all-reduce of the flat gradient buffer behind the whole backward (default since round 5) and the
+    per-block overlapped form (CFFM_BENCH_EXCHANGE=blockwise)."""
+    env = dict(os.environ, PYTHONPATH=ROOT, CFFM_BENCH_FORCE_DIST='1', CFFM_BENCH_EXCHANGE=exchange)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--spinup-steps', '10',
-                        '--no-cpu-baseline', '--no-head-step'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--no-head-step', '--no-gtc-step'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     assert j['rccl'] == {'world': 1, 'backend': 'nccl'}
     assert j['config']['ranks_in_sync'] is True and j['config']['params_finite'] is True
-    assert j['config']['hip_graph'] is True and j['config']['hip_graph_note'].startswith('ONE graph per step with the RCCL all-reduces captured inside')
+    assert j['config']['hip_graph'] is True and j['config']['hip_graph_note'].startswith('ONE graph per step with the RCCL all-reduce')
     c = j['collective']
-    assert c['allreduce_calls_per_step'] == 2 and c['allreduce_bytes_per_step'] > 6_000_000 and c['capture_form'] == j['config']['hip_graph_note']
+    assert c['allreduce_calls_per_step'] == (1 if exchange == 'whole' else 2) and c['allreduce_bytes_per_step'] > 6_000_000
+    assert c['capture_form'] == j['config']['hip_graph_note'] and ('ONE all-reduce' in c['capture_form']) == (exchange == 'whole')
     assert 0.0 <= c['exposed_wait_ms_per_step'] < j['ms_per_step']
