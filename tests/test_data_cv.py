@@ -211,6 +211,55 @@ def test_load_clip_decodes_like_the_reference_loaders(tmp_path):
         D.load_clip([jp])
 
 
+def run_train_pipeline(device, seed, t, h, w, img_scale, crop):
+    """The training pipeline of vspw_repeat2.py:8-19 from decoded frames on: Resize(ratio_range) -> RandomCrop_clips -> RandomFlip_clips ->
+    PhotoMetricDistortion_clips -> Normalize_clips -> Pad_clips -> DefaultFormatBundle_clips, the random numbers drawn in that order from one
+    stream, against the same chain composed from the oracle's pieces."""
+    frames, labels = _clip(seed, t, h, w)
+    f_t, l_t = torch.from_numpy(frames).to(device), torch.from_numpy(labels).to(device)
+    np.random.seed(seed)
+    rs = D.ResizeClips(img_scale=img_scale, ratio_range=(0.5, 2.0))
+    fmt = D.ClipFormatter(crop_size=crop, cat_max_ratio=0.75, flip_prob=0.5, photo=D.PhotoMetricDistortionClips())
+    fr, lr, scale = rs(f_t, l_t)
+    img, gt, params = fmt(fr, lr, last_label_host=lr[-1].cpu().numpy())
+    # the oracle's chain with the decisions the host classes drew
+    nw, nh = CV.rescale_size(w, h, scale)
+    rf = np.stack([CV.resize_linear_u8(x, nw, nh) for x in frames])
+    rl = np.stack([CV.resize_nearest(x, nw, nh) for x in labels])
+    assert np.array_equal(fr.cpu().numpy(), rf) and np.array_equal(lr.cpu().numpy(), rl)
+    y1, x1, ch, cw, ph = params['y1'], params['x1'], params['ch'], params['cw'], params['photo']
+    mean, stdinv = np.float32(fmt.mean), (1 / np.float64(fmt.std)).astype(np.float32)
+    ho, wo = max(crop[0], ch), max(crop[1], cw)
+    want_img = np.zeros((t, 3, ho, wo), np.float32)
+    want_gt = np.full((t, 1, ho, wo), 255, np.int64)
+    for i in range(t):
+        c_, l_ = rf[i, y1:y1 + ch, x1:x1 + cw], D.reduce_zero_label(rl[i, y1:y1 + ch, x1:x1 + cw])
+        if params['flip']:
+            c_, l_ = c_[:, ::-1], l_[:, ::-1]
+        beta = None if ph['beta'][i] != ph['beta'][i] else ph['beta'][i]
+        alpha = None if ph['alpha'][i] != ph['alpha'][i] else ph['alpha'][i]
+        out = CV.photometric_frame(c_, beta, alpha, ph['contrast_first'][i], ph['saturation'][i], ph['hue'][i])
+        want_img[i, :, :ch, :cw] = (((out[:, :, ::-1].astype(np.float32) - mean) * stdinv).astype(np.float32)).transpose(2, 0, 1)
+        want_gt[i, 0, :ch, :cw] = l_
+    assert np.array_equal(img.cpu().numpy(), want_img) and np.array_equal(gt.cpu().numpy(), want_gt), (seed, scale, params['flip'])
+    return scale
+
+
+def test_train_pipeline_emulated():
+    with emu.active():
+        scales = [run_train_pipeline(torch.device('cpu'), seed, 3, 30, 53, (53, 30), (32, 40)) for seed in (71, 72, 73)]
+    assert len(set(scales)) == 3
+
+
+@pytest.mark.gpu
+def test_train_pipeline_gpu():
+    """VSPW geometry at a quarter of the linear size (120 x 213 frames, (213, 120) scale, 120 x 120 crops) over several random streams,
+    and once at full size (480 x 854, (853, 480), 480 x 480)."""
+    for seed in (81, 82, 83, 84):
+        run_train_pipeline(torch.device('cuda:0'), seed, 4, 120, 213, (213, 120), (120, 120))
+    run_train_pipeline(torch.device('cuda:0'), 85, 4, 480, 854, (853, 480), (480, 480))
+
+
 def test_clip_resize_emulated():
     with emu.active():
         run_resize_cases(torch.device('cpu'))
