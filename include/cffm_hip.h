@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 8
+#define CFFM_ABI_VERSION 9
 
 typedef struct cffm_geom {
     int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
@@ -59,7 +59,7 @@ typedef struct cffm_block_grads {
 
 /* float offsets of the activations one block saves for its backward (inside its slice of `saved`) */
 typedef struct cffm_block_ws {
-    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, w_split, w_frag, total;
+    long mean1, rstd1, M, zall, qkv, bias, biasT, lse, ao, x1, mean2, rstd2, z2, hraw, act, x2, w_split, w_frag, ao_t, zall_t /* ABI 9 */, total;
 } cffm_block_ws;
 
 int cffm_abi_version(void);
@@ -140,6 +140,20 @@ int cffm_split4(const float* src, float* dst, long n, void* stream);
 int cffm_linear_bwd_weight_split(const float* dy_s, const float* x_s, float* dw, long M, int N, int K, void* stream);
 int cffm_linear_bwd_weight_split_group(const cffm_wgrad* problems, int n /* <= 3 */, void* stream);   /* one launch, one common k-slice length */
 int cffm_linear_bwd_weight_group(const cffm_wgrad* problems /* host */, int n, void* stream);
+/* ABI 9: weight gradient with both operands in "T-frag" storage (csrc/dws_kernels.h): MFMA fragments along the contraction -- unit (ks, jt, h)
+ * = 64 lanes x 16 B at 16-byte word ((ks * C/16 + jt) * 2 + h) * 64, lane (l15, g) holding x[32 ks + 8 g + e][16 jt + l15], e = 0..7, as bf16
+ * hi (h = 0) / lo (h = 1), rows past M zero -- streamed straight into registers: no LDS staging, no barrier in the contraction loop.  The
+ * block's row-panel kernels leave z2 / act / dh / dx1 / ao / dout (and the q|k|v panel GEMMs zall / dqkv) in this order for the block's four
+ * weight gradients (qkv / proj / fc1 / fc2 .weight.grad, cffm_transformer.py:374, :381, :18-19); cffm_tfrag_pack makes such a copy of a plain
+ * row-major fp32 array (dst: cffm_tfrag_floats(R, C) floats).  N a multiple of 64, K of 128. */
+long cffm_tfrag_floats(long R, int C);
+/* Which form the block's four weight gradients take (process-wide; returns the previous setting, on < 0 only asks): 1 = the streaming kernel on
+ * T-frag operands the row-panel kernels leave behind, 0 = the LDS-staged grouped kernel on split-4 / fp32 operands.  A block forward stores its
+ * operands in the form the backward will read, so the setting must not change between a forward and its backward. */
+int cffm_dw_stream(int on);
+int cffm_tfrag_pack(const float* x, float* dst, long R, int C /* % 16 == 0 */, void* stream);
+int cffm_linear_bwd_weight_tfrag(const float* dy_t, const float* x_t, float* dw, long M, int N, int K, void* stream);
+int cffm_linear_bwd_weight_tfrag_group(const cffm_wgrad* problems /* host; dy / x in T-frag storage */, int n /* <= 4 */, void* stream);
 /* fused Mlp halves: hraw = x w^T (raw, kept for backward), act = gelu(hraw + b)  |  out = res + x w^T + b */
 int cffm_linear_gelu_fwd(const float* x, const float* w, const float* b, float* hraw, float* act, long M, int N, int K,
                          void* stream);
@@ -162,6 +176,16 @@ int cffm_mlp_fwd(const float* ao, const float* xt, long xt_bs, int rows_per_batc
 int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const float* x1, const float* mean2,
                  const float* rstd2, const float* g2, const float* w2_n, const float* w1_n, const float* wp_n, float* dhs,
                  float* dx1, float* dao, float* dg2, float* dbe2, float* db1, float* db2, float* dbp, long NP, void* stream);
+/* ABI 9: the same two kernels also leaving T-frag copies (cffm_tfrag_floats(NP, 256 | 1024) floats; see cffm_linear_bwd_weight_tfrag) of the
+ * operands of the block's weight gradients: ao, z2, act (forward), dout, dh, dx1 (backward).  Every split-4 / T-frag output may be NULL. */
+int cffm_mlp_fwd_tfrag(const float* ao, const float* xt, long xt_bs, int rows_per_batch, const float* wp_f, const float* w1_f,
+                       const float* w2_f, const float* bp, const float* b1, const float* b2, const float* g2, const float* be2,
+                       float* x1, float* z2s, float* mean2, float* rstd2, float* hraw, float* acts, float* x2, float* ao_t, float* z2_t,
+                       float* act_t, long NP, void* stream);
+int cffm_mlp_bwd_tfrag(const float* dout, const float* hraw, const float* b1, const float* x1, const float* mean2,
+                       const float* rstd2, const float* g2, const float* w2_n, const float* w1_n, const float* wp_n, float* dhs,
+                       float* dx1, float* dao, float* dg2, float* dbe2, float* db1, float* db2, float* dbp, float* dout_t, float* dh_t,
+                       float* dx1_t, long NP, void* stream);
 int cffm_colsum(const float* a, long rows, int cols /* multiple of 4 */, float* out /* overwritten */, void* stream);
 int cffm_residual_ln(const float* xt, long xt_bs, int rows_per_batch, const float* yraw, const float* bproj,
                      const float* gamma, const float* beta, float* x1, float* z2, float* mean, float* rstd,

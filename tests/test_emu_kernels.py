@@ -27,8 +27,18 @@ def flat_params(st, depth):
     return [st['blocks.%d.%s' % (i, k)].clone().requires_grad_(True) for i in range(depth) for k, _, _ in ops.BLOCK_PARAM_KEYS]
 
 
+@pytest.fixture(params=['staged', 'stream'])
+def dw_form(request):
+    """Both forms of the block's weight gradients (include/cffm_hip.h cffm_dw_stream): the LDS-staged group on split-4 / fp32 operands and
+    the streaming kernel on the T-frag copies the row-panel kernels leave behind."""
+    lib = emu.lib()
+    was = lib.cffm_dw_stream(1 if request.param == 'stream' else 0)
+    yield request.param
+    lib.cffm_dw_stream(was)
+
+
 @pytest.mark.parametrize('case', ['layer_b1_8x8_d1', 'layer_b2_8x8_d2', 'layer_b1_14x21_d2', 'layer_b1_13x30_d1'])
-def test_layer_against_reference_golden(case):
+def test_layer_against_reference_golden(case, dw_form):
     g = H.load_golden(case)
     b, h, w, depth, st, x, gy = H.layer_case_inputs(g)
     params = flat_params(st, depth)
@@ -54,7 +64,7 @@ def test_layer_golden_with_the_eager_form_of_the_weight_gradient_groups():
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider', os.path.abspath(__file__), '-k',
                         'test_layer_against_reference_golden and layer_b2_8x8_d2'], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and '2 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def run_nan_poisoned_backward(device):

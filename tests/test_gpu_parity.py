@@ -39,8 +39,19 @@ def test_native_library_is_the_one_loaded():
     assert lib._name.endswith('libcffm_hip.so')
 
 
+@pytest.fixture(params=['staged', 'stream'])
+def dw_form(request):
+    """Both forms of the block's weight gradients (include/cffm_hip.h cffm_dw_stream): the LDS-staged group on split-4 / fp32 operands and
+    the streaming kernel on the T-frag copies the row-panel kernels leave behind."""
+    from vss_cffm_amd import _lib
+    lib = _lib.get()
+    was = lib.cffm_dw_stream(1 if request.param == 'stream' else 0)
+    yield request.param
+    lib.cffm_dw_stream(was)
+
+
 @pytest.mark.parametrize('case', H.LAYER_CASES)
-def test_layer_against_reference_golden(case):
+def test_layer_against_reference_golden(case, dw_form):
     g = H.load_golden(case)
     b, h, w, depth, st, x, gy = H.layer_case_inputs(g)
     m = build_layer(depth, st)
@@ -159,7 +170,7 @@ def test_config5_gtc_8_prototypes_full_size():
     assert H.rel_err(xg.grad, xo.grad) < 1e-4 and H.rel_err(cg.grad, co.grad) < 1e-4
 
 
-def test_backward_is_deterministic():
+def test_backward_is_deterministic(dw_form):
     """Every gradient -- dK/dV (owner-side reduction), dX, the weight gradients and the position-bias tables (per-group tiles
     summed in a fixed order) -- is bit-reproducible run to run: the backward has no atomics on shared data."""
     st = R.layer_state(1, seed=21)
@@ -178,7 +189,7 @@ def test_backward_is_deterministic():
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 
 
-def test_replayed_graph_equals_eager_at_full_size():
+def test_replayed_graph_equals_eager_at_full_size(dw_form):
     """The layer's forward + backward at BASELINE's size (B = 2, 60 x 60, depth 2) captured in a HIP graph and replayed: output,
     input gradient and every parameter gradient are BIT-identical to the eager launches -- the graph executor runs the library's side
     work on other streams and in another interleaving than the eager path does (four capture streams, two scratch sets, tails launched
@@ -295,7 +306,7 @@ def test_layer_goldens_with_either_form_of_the_weight_gradient_groups_gpu(form):
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider', '-m', 'gpu', os.path.abspath(__file__), '-k',
                         'test_layer_against_reference_golden'], env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and '5 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and '10 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_training_trajectory_against_oracle():

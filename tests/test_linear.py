@@ -163,3 +163,47 @@ def test_dw_split_emulated():
 def test_dw_split_gpu():
     run_dw_split_checks(_lib.get(), torch.device('cuda'), [(7, 128, 128), (32, 128, 256), (100, 256, 128), (1000, 128, 128), (10368, 768, 256), (7200, 1024, 256),
                                                            (7200, 256, 1024), (7201, 256, 256)])
+
+
+def run_dw_tfrag_checks(lib, device, shapes, group=None):
+    """cffm_linear_bwd_weight_tfrag (the streaming weight-gradient kernel, csrc/dws_kernels.h): operands in T-frag storage made by
+    cffm_tfrag_pack, against fp64; contraction lengths that are not multiples of 32 (the last k-step zero-padded), fewer k-steps than waves
+    (waves with nothing to do), several k-slices (slabs), N = 64; then several problems as one group."""
+    gen = torch.Generator().manual_seed(11)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
+    lib.cffm_tfrag_floats.restype = C.c_long
+    made = []
+    for (M, N, K) in shapes:
+        dy, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+        dyd, xd = dy.to(device), x.to(device)
+        dyt = torch.full((lib.cffm_tfrag_floats(M, N),), float('nan'), device=device)
+        xt = torch.full((lib.cffm_tfrag_floats(M, K),), float('nan'), device=device)
+        dw = torch.full((N, K), 7., device=device)
+        assert lib.cffm_tfrag_pack(P(dyd), P(dyt), M, N, stream) == 0 and lib.cffm_tfrag_pack(P(xd), P(xt), M, K, stream) == 0
+        assert lib.cffm_linear_bwd_weight_tfrag(P(dyt), P(xt), P(dw), M, N, K, stream) == 0, lib.cffm_last_error()
+        ref = dy.double().T @ x.double()
+        assert rel(dw, ref) < TOL, (M, N, K)
+        made.append((dyt, xt, M, N, K, ref))
+    assert lib.cffm_linear_bwd_weight_tfrag(P(dyt), P(xt), P(dw), 10, 96, 128, stream) != 0      # N not a multiple of 64: refused
+    assert lib.cffm_linear_bwd_weight_tfrag(P(dyt), P(xt), P(dw), 10, 128, 64, stream) != 0      # K not a multiple of 128: refused
+    if group:
+        class WGrad(C.Structure):
+            _fields_ = [('dy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('M', C.c_long), ('N', C.c_int), ('K', C.c_int)]
+        sel = [made[i] for i in group]
+        outs = [torch.full((m[3], m[4]), 3., device=device) for m in sel]
+        prob = (WGrad * len(sel))(*[WGrad(m[0].data_ptr(), m[1].data_ptr(), o.data_ptr(), m[2], m[3], m[4]) for m, o in zip(sel, outs)])
+        assert lib.cffm_linear_bwd_weight_tfrag_group(prob, len(sel), stream) == 0, lib.cffm_last_error()
+        again = [o.clone() for o in outs]
+        assert lib.cffm_linear_bwd_weight_tfrag_group(prob, len(sel), stream) == 0
+        for m, o, a in zip(sel, outs, again):
+            assert rel(o, m[5]) < TOL and torch.equal(o, a), m[2:5]       # (and bit-identical from call to call: fixed summation order)
+
+
+def test_dw_tfrag_emulated():
+    run_dw_tfrag_checks(emu.lib(), torch.device('cpu'), [(7, 64, 128), (70, 128, 128), (333, 64, 256), (600, 128, 128)], group=(1, 2, 3))
+
+
+@pytest.mark.gpu
+def test_dw_tfrag_gpu():
+    run_dw_tfrag_checks(_lib.get(), torch.device('cuda'), [(7, 64, 128), (100, 256, 128), (1000, 128, 128), (7201, 256, 256), (10368, 768, 256),
+                                                           (7200, 1024, 256), (7200, 256, 1024), (7200, 256, 256)], group=(4, 5, 6, 7))

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 vp, ci, cl, cd, cf = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
 
@@ -28,7 +28,7 @@ class BlockPtrs(C.Structure):
 
 class BlockWs(C.Structure):
     _fields_ = [(n, cl) for n in ('mean1', 'rstd1', 'M', 'zall', 'qkv', 'bias', 'biasT', 'lse', 'ao', 'x1', 'mean2',
-                                  'rstd2', 'z2', 'hraw', 'act', 'x2', 'w_split', 'w_frag', 'total')]
+                                  'rstd2', 'z2', 'hraw', 'act', 'x2', 'w_split', 'w_frag', 'ao_t', 'zall_t', 'total')]
 
 
 class GtcPtrs(C.Structure):
@@ -75,6 +75,11 @@ SIGNATURES = {
     'cffm_split4': (ci, [vp, vp, cl, vp]),
     'cffm_linear_bwd_weight_split': (ci, [vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_bwd_weight_split_group': (ci, [vp, ci, vp]),
+    'cffm_tfrag_floats': (cl, [cl, ci]),
+    'cffm_dw_stream': (ci, [ci]),
+    'cffm_tfrag_pack': (ci, [vp, vp, cl, ci, vp]),
+    'cffm_linear_bwd_weight_tfrag': (ci, [vp, vp, vp, cl, ci, ci, vp]),
+    'cffm_linear_bwd_weight_tfrag_group': (ci, [vp, ci, vp]),
     'cffm_linear_gelu_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_linear_residual_fwd': (ci, [vp, vp, vp, vp, vp, cl, ci, ci, vp]),
     'cffm_colsum': (ci, [vp, cl, ci, vp, vp]),
@@ -82,6 +87,8 @@ SIGNATURES = {
     'cffm_mlp_records': (cl, [cl]),
     'cffm_mlp_fwd': (ci, [vp, vp, cl, ci] + [vp] * 15 + [cl, vp]),
     'cffm_mlp_bwd': (ci, [vp] * 18 + [cl, vp]),
+    'cffm_mlp_fwd_tfrag': (ci, [vp, vp, cl, ci] + [vp] * 18 + [cl, vp]),
+    'cffm_mlp_bwd_tfrag': (ci, [vp] * 21 + [cl, vp]),
     'cffm_residual_ln': (ci, [vp, cl, ci, vp, vp, vp, vp, vp, vp, vp, vp, cl, vp]),
     'cffm_ln_bwd_residual': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp, vp, vp]),
     'cffm_layernorm_fwd': (ci, [vp, vp, vp, vp, vp, vp, cl, vp]),

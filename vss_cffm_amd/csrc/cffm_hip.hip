@@ -243,12 +243,15 @@ int cffm_block_ws_layout(const cffm_geom* g, cffm_block_ws* o) {
     o->x1 = p; p += up(B * HW * CFFM_C);
     o->mean2 = p; p += up(B * HW);
     o->rstd2 = p; p += up(B * HW);
-    o->z2 = p; p += up(B * HW * CFFM_C);
+    const long NP32 = (B * HW + 31) / 32 * 32, NR32 = (B * RC + 31) / 32 * 32;   // T-frag storage pads the token rows to whole k-steps of 32
+    o->z2 = p; p += up(NP32 * CFFM_C);
     o->hraw = p; p += up(B * HW * CFFM_HID);
-    o->act = p; p += up(B * HW * CFFM_HID);
+    o->act = p; p += up(NP32 * CFFM_HID);
     o->x2 = p; p += up(B * HW * CFFM_C);
     o->w_split = p; p += up(PREP_WFLOATS);   // qkv | proj | fc1 | fc2 weights in split-4 storage (k_param_prep)
     o->w_frag = p; p += up(2 * PREP_WFLOATS); // the same in MFMA-fragment order: forward forms, then input-gradient forms (row-panel kernels)
+    o->ao_t = p; p += up(NP32 * CFFM_C);      // T-frag copies of ao and zall: operands of the streaming weight gradients (dws_kernels.h; ABI 9)
+    o->zall_t = p; p += up(NR32 * CFFM_C);
     o->total = p;
     return 0;
 }
@@ -260,7 +263,7 @@ long cffm_layer_saved_floats(const cffm_geom* g, int depth) {
 }
 
 // scratch carve (floats): fwd uses [0, BHW*C); bwd uses all of it
-struct Scratch { long a, a2, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, dkvp, alt, total; };
+struct Scratch { long a, a2, b, dz2, dao, dact, dqkv, dzall, dM, dbiasT, dxs, dkvp, alt, tf, tf_stride, total; };
 static Scratch scratch_layout(const cffm_geom* g) {
     const long B = g->B, HW = g->HW, RC = g->RC;
     Scratch s;
@@ -270,7 +273,8 @@ static Scratch scratch_layout(const cffm_geom* g) {
     s.b = p; p += up(B * HW * CFFM_C);
     s.dz2 = p; p += up(B * HW * CFFM_C);
     s.dao = p; p += up(B * HW * CFFM_C);
-    s.dact = p; p += up(B * HW * CFFM_HID);
+    const long NP32 = (B * HW + 31) / 32 * 32, NR32 = (B * RC + 31) / 32 * 32;   // T-frag storage pads the token rows to whole k-steps of 32
+    s.dact = p; p += up(NP32 * CFFM_HID);
     s.dqkv = p; p += up(B * RC * 768);
     s.dzall = p; p += up(B * RC * CFFM_C);
     s.dM = p; p += up(CFFM_NCELL * CFFM_WA);
@@ -281,7 +285,11 @@ static Scratch scratch_layout(const cffm_geom* g) {
     // moved on to the next block: blocks alternate between the two sets (block_backward_impl `par`), so the next block's chain never
     // waits for the side streams.  Offsets relative to `alt`: b | dact | dqkv | dbiasT | dM
     s.alt = p;
-    p += up(B * HW * CFFM_C) + up(B * HW * CFFM_HID) + up(B * RC * 768) + up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD) + up(CFFM_NCELL * CFFM_WA);
+    p += up(B * HW * CFFM_C) + up(NP32 * CFFM_HID) + up(B * RC * 768) + up((long)CFFM_HEADS * CFFM_NQ_PAD * CFFM_NKEY_PAD) + up(CFFM_NCELL * CFFM_WA);
+    // T-frag copies of dout | dx1 | dqkv for the streaming weight gradients, one set per parity (the side stream reads them after the chain has moved on)
+    s.tf = p;
+    s.tf_stride = 2 * up(NP32 * CFFM_C) + up(NR32 * 768);
+    p += 2 * s.tf_stride;
     s.total = p;
     return s;
 }
@@ -990,6 +998,36 @@ int cffm_linear_bwd_weight_split(const float* dy_s, const float* x_s, float* dw,
     return cffm_linear_bwd_weight_split_group(&pr, 1, stream);
 }
 
+// row-major fp32 x[R][C] -> T-frag storage (dws_kernels.h: MFMA fragments along the contraction, bf16 hi | lo, rows padded to a multiple of
+// 32 with zeros): what the operands of cffm_linear_bwd_weight_tfrag are stored as.  dst: cffm_tfrag_floats(R, C) floats.  A utility: inside
+// the block the row-panel kernels leave their operands in this order themselves.
+long cffm_tfrag_floats(long R, int C) { return R < 0 || C < 16 ? 0 : ((R + 31) / 32) * 32 * (long)C; }
+int cffm_tfrag_pack(const float* x, float* dst, long R, int C, void* stream) {
+    REQUIRE(x && dst && R >= 1 && C >= 16 && C % 16 == 0, "tfrag_pack: C must be a multiple of 16");
+    const long items = ((R + 31) / 32) * (C / 16) * 64;
+    CFFM_LAUNCH(k_tfrag_pack, ((unsigned)((items + 255) / 256)), (256), 0, (hipStream_t)stream, x, R, C, 0, (f32x4*)dst, items);
+    CHECK_LAUNCH("tfrag_pack");
+    return 0;
+}
+// dw[N,K] = dy[M,N]^T x[M,K] with dy and x in T-frag storage: the streaming weight-gradient kernel of the block backward (dws_kernels.h) as
+// a stage.  N a multiple of 64, K a multiple of 128
+int cffm_linear_bwd_weight_tfrag_group(const cffm_wgrad* problems, int n, void* stream) {
+    REQUIRE(problems && n >= 1 && n <= DWS_MAX, "linear_bwd_weight_tfrag_group: 1..%d problems", DWS_MAX);
+    for (int i = 0; i < n; ++i) REQUIRE(problems[i].dy && problems[i].x && problems[i].dw, "linear_bwd_weight_tfrag_group: null operand");
+    PROF(ST_GEMM);
+    DwsPlan P;
+    REQUIRE(dw_stream_plan((const GemmTN*)problems, n, dw_stream_target(), &P), "linear_bwd_weight_tfrag_group: N must be a multiple of 64, K of 128, operands under 4 GB");
+    float* part = P.part_floats ? lib_scratch(P.part_floats) : nullptr;
+    REQUIRE(!P.part_floats || part, "linear_bwd_weight_tfrag_group: scratch allocation failed");
+    REQUIRE(!dw_group_stream((const GemmTN*)problems, n, (hipStream_t)stream, part, dw_stream_target()), "linear_bwd_weight_tfrag_group: launch failed");
+    CHECK_LAUNCH("linear_bwd_weight_tfrag_group");
+    return 0;
+}
+int cffm_linear_bwd_weight_tfrag(const float* dy_t, const float* x_t, float* dw, long M, int N, int K, void* stream) {
+    const cffm_wgrad pr = {dy_t, x_t, dw, M, N, K};
+    return cffm_linear_bwd_weight_tfrag_group(&pr, 1, stream);
+}
+
 // q|k|v Linear feeding the CFM kernels: qkv16[M,768] (f16) = x w^T + b, q third times 32^-0.5 (cffm_transformer.py:374, :528)
 int cffm_linear_qkv_fwd(const float* x, const float* w, const float* b, void* qkv16, long M, void* stream) {
     REQUIRE(x && w && b && qkv16, "linear_qkv_fwd: null");
@@ -1227,7 +1265,7 @@ static int panel_mt(long M) {
 extern "C++" {
 template <int MT, int NTW, bool A_PRE, int EPI>
 static int panel_gemm_launch(const float* A, int lda, long M, int K, const float* wf, float* Cout, int ldc, const float* bias, void* aux,
-                             hipStream_t st, float* colrec = nullptr) {
+                             hipStream_t st, float* colrec = nullptr, float* a_t = nullptr) {
     auto kern = k_panel_gemm<MT, NTW, 2, 4, A_PRE, EPI>;
 #ifndef CFFM_EMU
     static bool granted = false;
@@ -1236,25 +1274,37 @@ static int panel_gemm_launch(const float* A, int lda, long M, int K, const float
         granted = true;
     }
 #endif
-    CFFM_LAUNCH(kern, ((unsigned)((M + 16 * MT - 1) / (16 * MT))), (PNL_THREADS), PNL_LDS(MT), st, A, lda, (int)M, K, (const f32x4*)wf, Cout, ldc, bias, aux, colrec);
+    CFFM_LAUNCH(kern, ((unsigned)((M + 16 * MT - 1) / (16 * MT))), (PNL_THREADS), PNL_LDS(MT), st, A, lda, (int)M, K, (const f32x4*)wf, Cout, ldc, bias, aux, colrec, (f32x4*)a_t);
     return 0;
 }
 }  // extern "C++"
 // qkv16[M][768] (f16) = f16((x W^T + b) [q third * 32^-0.5]), x in split-4 storage, W fragment-ordered (forward form)
-static int panel_qkv_fwd(const float* x_s, const float* wf, const float* b, h16* qkv16, long M, hipStream_t st) {
-    return panel_mt(M) == 3 ? panel_gemm_launch<3, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st)
-                            : panel_gemm_launch<2, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st);
+// x_t (or NULL): T-frag copy of x for the streaming weight gradient
+static int panel_qkv_fwd(const float* x_s, const float* wf, const float* b, h16* qkv16, long M, hipStream_t st, float* x_t = nullptr) {
+    return panel_mt(M) == 3 ? panel_gemm_launch<3, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st, nullptr, x_t)
+                            : panel_gemm_launch<2, 6, true, 3>(x_s, 256, M, 256, wf, nullptr, 768, b, qkv16, st, nullptr, x_t);
 }
 // dx[M][256] = dqkv[M][768] W, W fragment-ordered (input-gradient form); colrec (or NULL): panel_qkv_records(M) records of 768
 // column sums of dqkv (the q|k|v bias gradient before its reduction)
 static long panel_qkv_records(long M) { return (M + 16 * panel_mt(M) - 1) / (16 * panel_mt(M)); }
-static int panel_qkv_dx(const float* dqkv, const float* wfn, float* dx, long M, hipStream_t st, float* colrec = nullptr) {
-    return panel_mt(M) == 3 ? panel_gemm_launch<3, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st, colrec)
-                            : panel_gemm_launch<2, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st, colrec);
+// dqkv_t (or NULL): T-frag copy of dqkv for the streaming weight gradient
+static int panel_qkv_dx(const float* dqkv, const float* wfn, float* dx, long M, hipStream_t st, float* colrec = nullptr, float* dqkv_t = nullptr) {
+    return panel_mt(M) == 3 ? panel_gemm_launch<3, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st, colrec, dqkv_t)
+                            : panel_gemm_launch<2, 2, false, 0>(dqkv, 768, M, 768, wfn, dx, 256, nullptr, nullptr, st, colrec, dqkv_t);
 }
 // CFFM_PANEL_QKV=0: the q|k|v Linear keeps the tiled GEMMs (A/B: 0.8843 tiled vs 0.8729 ms per step as row panels, means of three
 // alternating runs with the activation stored)
 CFFM_SWITCH(qkv_colrec_on, "CFFM_QKV_COLREC", 1)
+// The block's four weight gradients by the streaming kernel (dws_kernels.h): their operands in T-frag storage, written by the row-panel
+// kernels that have them in LDS anyway.  CFFM_DW_STREAM=0 (experiment builds): the LDS-staged group on split-4 / fp32 operands, as before.
+#ifndef CFFM_DW_STREAM_DEFAULT
+#define CFFM_DW_STREAM_DEFAULT 0
+#endif
+static int g_dw_stream = CFFM_DW_STREAM_DEFAULT;
+static int dw_stream_sw() { return g_dw_stream; }
+// Process-wide choice between the two forms of the block's weight gradients (both tested): 1 = streaming kernel on T-frag operands, 0 = the
+// LDS-staged group.  The forward leaves the operands in the form the backward will read: do not change it between a forward and its backward.
+int cffm_dw_stream(int on) { const int was = g_dw_stream; if (on >= 0) g_dw_stream = on != 0; return was; }
 CFFM_SWITCH(panel_qkv_sw, "CFFM_PANEL_QKV", 1)
 static constexpr_or_not int panel_qkv_on() { return panel_qkv_sw() && panel_on(); }
 
@@ -1267,12 +1317,14 @@ int cffm_panel_pack_weight(const float* w, int N, int K, int form, float* w_frag
     return 0;
 }
 
-int cffm_mlp_fwd(const float* ao, const float* xt, long xt_bs, int rows_per_batch, const float* wp_f, const float* w1_f, const float* w2_f,
-                 const float* bp, const float* b1, const float* b2, const float* g2, const float* be2, float* x1, float* z2s, float* mean2,
-                 float* rstd2, float* hraw, float* acts, float* x2, long NP, void* stream) {
+// z2s / acts: split-4 copies (what the LDS-staged weight-gradient kernels read), ao_t / z2_t / act_t: T-frag copies (what the streaming one
+// reads, cffm_tfrag_floats(NP, 256 | 256 | 1024) floats each); every one of the five may be NULL
+int cffm_mlp_fwd_tfrag(const float* ao, const float* xt, long xt_bs, int rows_per_batch, const float* wp_f, const float* w1_f, const float* w2_f,
+                       const float* bp, const float* b1, const float* b2, const float* g2, const float* be2, float* x1, float* z2s, float* mean2,
+                       float* rstd2, float* hraw, float* acts, float* x2, float* ao_t, float* z2_t, float* act_t, long NP, void* stream) {
     REQUIRE(NP >= 0 && NP < (1L << 21) && rows_per_batch >= 1, "mlp_fwd: bad sizes");
     if (!NP) return 0;
-    REQUIRE(ao && xt && wp_f && w1_f && w2_f && bp && b1 && b2 && g2 && be2 && x1 && z2s && mean2 && rstd2 && hraw && x2, "mlp_fwd: null");   // (acts may be NULL: not stored)
+    REQUIRE(ao && xt && wp_f && w1_f && w2_f && bp && b1 && b2 && g2 && be2 && x1 && mean2 && rstd2 && hraw && x2, "mlp_fwd: null");
     REQUIRE(!mlp_lds_grant(), "mlp_fwd: LDS grant failed");
     PROF2(ST_MLP_FWD);
     MlpFwdArgs a;
@@ -1280,17 +1332,26 @@ int cffm_mlp_fwd(const float* ao, const float* xt, long xt_bs, int rows_per_batc
     a.wp = (const f32x4*)wp_f; a.w1 = (const f32x4*)w1_f; a.w2 = (const f32x4*)w2_f;
     a.bp = bp; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2;
     a.x1 = x1; a.z2s = z2s; a.mean2 = mean2; a.rstd2 = rstd2; a.hraw = hraw; a.acts = acts; a.x2 = x2; a.NP = (int)NP;
+    a.ao_t = (f32x4*)ao_t; a.z2_t = (f32x4*)z2_t; a.act_t = (f32x4*)act_t;
     CFFM_LAUNCH((k_mlp_fwd<MLP_MT, MLP_D>), ((unsigned)cffm_mlp_records(NP)), (PNL_THREADS), PNL_FUSED_LDS(MLP_MT), (hipStream_t)stream, a);
     CHECK_LAUNCH("mlp_fwd");
     return 0;
 }
+int cffm_mlp_fwd(const float* ao, const float* xt, long xt_bs, int rows_per_batch, const float* wp_f, const float* w1_f, const float* w2_f,
+                 const float* bp, const float* b1, const float* b2, const float* g2, const float* be2, float* x1, float* z2s, float* mean2,
+                 float* rstd2, float* hraw, float* acts, float* x2, long NP, void* stream) {
+    REQUIRE(z2s || !NP, "mlp_fwd: null");   // (acts may be NULL: not stored)
+    return cffm_mlp_fwd_tfrag(ao, xt, xt_bs, rows_per_batch, wp_f, w1_f, w2_f, bp, b1, b2, g2, be2, x1, z2s, mean2, rstd2, hraw, acts, x2, nullptr, nullptr,
+                              nullptr, NP, stream);
+}
 
-int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const float* x1, const float* mean2, const float* rstd2,
-                 const float* g2, const float* w2_n, const float* w1_n, const float* wp_n, float* dhs, float* dx1, float* dao, float* dg2,
-                 float* dbe2, float* db1, float* db2, float* dbp, long NP, void* stream) {
+// dhs: split-4 copy of dh; dout_t / dh_t / dx1_t: T-frag copies of dout, dh, dx1 (cffm_tfrag_floats(NP, 256 | 1024 | 256) floats); each may be NULL
+int cffm_mlp_bwd_tfrag(const float* dout, const float* hraw, const float* b1, const float* x1, const float* mean2, const float* rstd2,
+                       const float* g2, const float* w2_n, const float* w1_n, const float* wp_n, float* dhs, float* dx1, float* dao, float* dg2,
+                       float* dbe2, float* db1, float* db2, float* dbp, float* dout_t, float* dh_t, float* dx1_t, long NP, void* stream) {
     REQUIRE(NP >= 0 && NP < (1L << 21), "mlp_bwd: bad sizes");
     if (!NP) return 0;
-    REQUIRE(dout && hraw && b1 && x1 && mean2 && rstd2 && g2 && w2_n && w1_n && wp_n && dhs && dx1 && dao, "mlp_bwd: null");
+    REQUIRE(dout && hraw && b1 && x1 && mean2 && rstd2 && g2 && w2_n && w1_n && wp_n && dx1 && dao, "mlp_bwd: null");
     REQUIRE(!mlp_lds_grant(), "mlp_bwd: LDS grant failed");
     PROF2(ST_MLP_BWD);
     hipStream_t st = (hipStream_t)stream;
@@ -1301,6 +1362,7 @@ int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const fl
     a.dout = dout; a.hraw = hraw; a.b1 = b1; a.x1 = x1; a.mean2 = mean2; a.rstd2 = rstd2; a.g2 = g2;
     a.w2n = (const f32x4*)w2_n; a.w1n = (const f32x4*)w1_n; a.wpn = (const f32x4*)wp_n;
     a.dhs = dhs; a.dx1 = dx1; a.dao = dao; a.rec_b1 = rec; a.rec_ln = rec + (size_t)nrec * 1024; a.NP = (int)NP;
+    a.dout_t = (f32x4*)dout_t; a.dh_t = (f32x4*)dh_t; a.dx1_t = (f32x4*)dx1_t;
     CFFM_LAUNCH((k_mlp_bwd<MLP_MT, MLP_D>), ((unsigned)nrec), (PNL_THREADS), PNL_FUSED_LDS(MLP_MT), st, a);
     RedSegs s1, s2;
     s1.nseg = 0;
@@ -1314,6 +1376,13 @@ int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const fl
     reduce_records(a.rec_ln, nrec, 1024, 1024, s2, st);
     CHECK_LAUNCH("mlp_bwd");
     return 0;
+}
+int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const float* x1, const float* mean2, const float* rstd2,
+                 const float* g2, const float* w2_n, const float* w1_n, const float* wp_n, float* dhs, float* dx1, float* dao, float* dg2,
+                 float* dbe2, float* db1, float* db2, float* dbp, long NP, void* stream) {
+    REQUIRE(dhs || !NP, "mlp_bwd: null");
+    return cffm_mlp_bwd_tfrag(dout, hraw, b1, x1, mean2, rstd2, g2, w2_n, w1_n, wp_n, dhs, dx1, dao, dg2, dbe2, db1, db2, dbp, nullptr, nullptr, nullptr, NP,
+                              stream);
 }
 
 // ------------------------------------------------------------------------------------------- CFFM++ (GTC) block, fused (round 5)
@@ -1528,13 +1597,18 @@ static int block_forward_impl(const cffm_geom* g, const cffm_block_params* p, co
     }
     if (sp && panel_qkv_on()) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_FWD);
-        REQUIRE(!panel_qkv_fwd(ws + L.zall, ws + L.w_frag, p->qkv_b, (h16*)(ws + L.qkv), NR, st), "block_forward: qkv gemm failed");
+        REQUIRE(!panel_qkv_fwd(ws + L.zall, ws + L.w_frag, p->qkv_b, (h16*)(ws + L.qkv), NR, st, dw_stream_sw() ? ws + L.zall_t : nullptr), "block_forward: qkv gemm failed");
     }
     TRY(cffm_attn_fwd(g, ws + L.qkv, key_src, q_dst, (const void*)(ws + L.bias), ws + L.ao, ws + L.lse, stream));
     if (sp && panel_on()) {
         // proj + residual + norm2 + Mlp in one row-panel launch (panel_kernels.h); weights in fragment order from k_param_prep
         const float* wf = ws + L.w_frag;
         PROF(ST_GEMM);
+        if (dw_stream_sw())     // z2 / act (and a copy of ao) in T-frag storage: operands of the streaming weight gradients
+            TRY(cffm_mlp_fwd_tfrag(ws + L.ao, x_tgt, tgt_bs, g->HW, wf + 768 * 256, wf + 768 * 256 + 256 * 256, wf + 768 * 256 + 256 * 256 + 1024 * 256,
+                                   p->proj_b, p->fc1_b, p->fc2_b, p->norm2_w, p->norm2_b, ws + L.x1, nullptr, ws + L.mean2, ws + L.rstd2, ws + L.hraw,
+                                   nullptr, ws + L.x2, ws + L.ao_t, ws + L.z2, ws + L.act, NP, stream));
+        else
         TRY(cffm_mlp_fwd(ws + L.ao, x_tgt, tgt_bs, g->HW, wf + 768 * 256, wf + 768 * 256 + 256 * 256, wf + 768 * 256 + 256 * 256 + 1024 * 256,
                          p->proj_b, p->fc1_b, p->fc2_b, p->norm2_w, p->norm2_b, ws + L.x1, ws + L.z2, ws + L.mean2, ws + L.rstd2, ws + L.hraw,
                          store_act() ? ws + L.act : nullptr /* CFFM_STORE_ACT=0: the fc2 weight gradient re-applies bias + GELU to hraw */,
@@ -1629,12 +1703,18 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     const Scratch S = scratch_layout(g);
     const long NR = (long)g->B * g->RC, NP = (long)g->B * g->HW;
     par = (defer && par) ? 1 : 0;
-    const long altb = S.alt, altact = altb + up(NP * CFFM_C), altqkv = altact + up(NP * CFFM_HID), altbias = altqkv + up(NR * 768);
+    const long altb = S.alt, altact = altb + up(NP * CFFM_C), altqkv = altact + up((NP + 31) / 32 * 32 * CFFM_HID), altbias = altqkv + up(NR * 768);
     float* dx1 = scratch + (par ? altb : S.b);
     float* dz2 = scratch + S.dz2;
     float* dao = scratch + S.dao;
     float* dact = scratch + (par ? altact : S.dact);
     float* dqkv = scratch + (par ? altqkv : S.dqkv);
+    // T-frag copies of dout | dx1 | dqkv (streaming weight gradients), one set per parity
+    const long NP32 = (NP + 31) / 32 * 32;
+    float* dout_t = scratch + S.tf + (par ? S.tf_stride : 0);
+    float* dx1_t = dout_t + up(NP32 * CFFM_C);
+    float* dqkv_t = dx1_t + up(NP32 * CFFM_C);
+    const int stream_dw = dw_stream_sw();
     CffaSlot cffa;           // library-owned: this block's dzall lives until the reference pass at the end of the range (cffa_finish)
     TRY(cffa_slot(g, slot, nslots, &cffa));
     float* dzall = cffa.dzall;
@@ -1661,9 +1741,26 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         // now, while allocating is still allowed -- a capture that follows eager steps must not grow it
         const GemmTN all4[4] = {{nullptr, nullptr, nullptr, NR, 768, CFFM_C}, {nullptr, nullptr, nullptr, NP, CFFM_HID, CFFM_C},
                                 {nullptr, nullptr, nullptr, NP, CFFM_C, CFFM_HID}, {nullptr, nullptr, nullptr, NP, CFFM_C, CFFM_C}};
-        const size_t need = gemm_tn_group_partial_floats(all4, 4, 480);
+        size_t need = gemm_tn_group_partial_floats(all4, 4, 480);
+        DwsPlan P4;
+        if (stream_dw && dw_stream_plan(all4, 4, dw_stream_target(), &P4)) need = P4.part_floats;
         REQUIRE(!need || lib_scratch2(need), "block_backward: scratch allocation failed");
     }
+    // a group of the block's weight gradients: the streaming kernel on T-frag operands (default), or the LDS-staged group
+    auto dw_group = [&](const cffm_wgrad* wg, const GemmTNPre* pre, int n, hipStream_t s, int target, void (*after)(hipStream_t)) -> int {
+        if (!stream_dw) return gemm_tn_group((const GemmTN*)wg, n, s, pre, s == st ? lib_scratch : lib_scratch2, target, after);
+        DwsPlan P;
+        if (!dw_stream_plan((const GemmTN*)wg, n, dw_stream_target(), &P)) return -1;
+        float* part = P.part_floats ? (s == st ? lib_scratch : lib_scratch2)(P.part_floats) : nullptr;
+        if (P.part_floats && !part) return -1;
+        return dw_group_stream((const GemmTN*)wg, n, s, part, dw_stream_target(), after);
+    };
+    // the four problems' operands: T-frag copies (streaming) or the split-4 / fp32 tensors themselves
+    const float* fc2_x = stream_dw ? ws + L.act : ((sp && panel_on() && !store_act()) ? ws + L.hraw : ws + L.act);
+    const cffm_wgrad wg_qkv = {stream_dw ? dqkv_t : dqkv, stream_dw ? ws + L.zall_t : ws + L.zall, gr->qkv_w, NR, 768, CFFM_C};
+    const cffm_wgrad wg_fc1 = {dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C};
+    const cffm_wgrad wg_fc2 = {stream_dw ? dout_t : dout, fc2_x, gr->fc2_w, NP, CFFM_C, CFFM_HID};
+    const cffm_wgrad wg_proj = {stream_dw ? dx1_t : dx1, stream_dw ? ws + L.ao_t : ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C};
     // x2 = x1 + act W2^T + b2
     // act = gelu(hraw + b1); hraw = z2 W1^T: the GELU backward runs in the epilogue of the fc2 input-gradient GEMM (dact is
     // never materialised; what is stored is dh, in split-4 storage since only GEMMs read it, plus column-sum records of it)
@@ -1673,6 +1770,11 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         // gradient records come out of it for the weight-gradient groups and the reductions below
         const float* wfn = ws + L.w_frag + PREP_WFLOATS;
         PROF(ST_GEMM);
+        if (stream_dw)
+            TRY(cffm_mlp_bwd_tfrag(dout, ws + L.hraw, p->fc1_b, ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, wfn + 768 * 256 + 256 * 256 + 1024 * 256,
+                                   wfn + 768 * 256 + 256 * 256, wfn + 768 * 256, nullptr, dx1, dao, gr->norm2_w, gr->norm2_b, gr->fc1_b, gr->fc2_b, gr->proj_b,
+                                   dout_t, dact, dx1_t, NP, stream));
+        else
         TRY(cffm_mlp_bwd(dout, ws + L.hraw, p->fc1_b, ws + L.x1, ws + L.mean2, ws + L.rstd2, p->norm2_w, wfn + 768 * 256 + 256 * 256 + 1024 * 256,
                          wfn + 768 * 256 + 256 * 256, wfn + 768 * 256, dact, dx1, dao, gr->norm2_w, gr->norm2_b, gr->fc1_b, gr->fc2_b, gr->proj_b, NP,
                          stream));
@@ -1680,12 +1782,12 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         if (!one_group) {
             sa = side_fork(st, 0);
             void* stream_a = (void*)sa;
-            const cffm_wgrad wga[2] = {{dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C}, {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}};
+            const cffm_wgrad wga[2] = {wg_fc1, wg_fc2};
             const GemmTNPre prea[2] = {{1, 1, nullptr}, {0, (panel && !store_act()) ? 2 : 1, p->fc1_b}};
             {
                 void* stream = stream_a;
                 PROF2(ST_G_DW);
-                REQUIRE(!gemm_tn_group((const GemmTN*)wga, 2, sa, prea, sa == st ? lib_scratch : lib_scratch2, 320), "block_backward: weight-gradient gemm failed");
+                REQUIRE(!dw_group(wga, prea, 2, sa, 320, nullptr), "block_backward: weight-gradient gemm failed");
             }
             side_mark(sa, st, 0);
         }
@@ -1743,12 +1845,16 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         seg_add(segs, 0, 768, gr->qkv_b, 0);
         reduce_records(qkv_rec, (int)nrec, 768, 768, segs, st);
     }
-    if (sp && (fork_order() & 2) && panel_qkv_on()) {     // chain first: the q|k|v input gradient is launched before the side work
-        side_fork_mark(st, 2);
+    if (sp && ((fork_order() & 2) || stream_dw) && panel_qkv_on()) {     // chain first: the q|k|v input gradient is launched before the side work
+        // (streaming weight gradients: the side work forks BEHIND this kernel -- it leaves the T-frag copy of dqkv the q|k|v weight gradient reads)
+        if (!stream_dw) side_fork_mark(st, 2);
         PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
-        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st, qkv_rec), "block_backward: q|k|v input-gradient gemm failed");
+        REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st, qkv_rec, stream_dw ? dqkv_t : nullptr), "block_backward: q|k|v input-gradient gemm failed");
+        if (stream_dw) side_fork_mark(st, 2);
         dx_done = 1;
     }
+    // the block's side work behind the dK/dV gather (weight gradients, bias-gradient tiles, the previous block's tail)
+    auto side_b = [&]() -> int {
     if (sp) {
         sb = dx_done ? side_fork_take(st, 2) : side_fork(st, 2);
         void* stream_b = (void*)sb;
@@ -1762,12 +1868,11 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             // ALL four weight gradients as one grouped launch (~480 workgroups with one slice length, one partial-sum launch: 59 us
             // where two groups of two take 2 x 53), on the side stream beside q|k|v's input gradient and the CFFA backward; every
             // operand lives until the end of the block now that ln_pool_bwd no longer writes over `dout`
-            const cffm_wgrad wg4[4] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C}, {dact, ws + L.z2, gr->fc1_w, NP, CFFM_HID, CFFM_C},
-                                       {dout, (panel && !store_act()) ? ws + L.hraw : ws + L.act, gr->fc2_w, NP, CFFM_C, CFFM_HID}, {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
+            const cffm_wgrad wg4[4] = {wg_qkv, wg_fc1, wg_fc2, wg_proj};
             const GemmTNPre pre4[4] = {{0, 1, nullptr}, {1, 1, nullptr}, {0, (panel && !store_act()) ? 2 : 1, p->fc1_b}, {0, 0, nullptr}};
             void* stream = stream_b;
             PROF(ST_GEMM); PROF2(ST_G_DW);
-            REQUIRE(!gemm_tn_group((const GemmTN*)wg4, 4, sb, pre4, sb == st ? lib_scratch : lib_scratch2, 480, dw_group_launched), "block_backward: weight-gradient gemm failed");
+            REQUIRE(!dw_group(wg4, pre4, 4, sb, 480, dw_group_launched), "block_backward: weight-gradient gemm failed");
             sa = sb;
             side_mark(sa, st, 0);
             if (bias_late) {
@@ -1779,12 +1884,12 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
             }
             if ((fork_order() & 64) && sb != st) TRY(tail_flush(st, false, sb));   // the PREVIOUS block's record reductions: no fork of their own
         } else {
-        const cffm_wgrad wgb[2] = {{dqkv, ws + L.zall, gr->qkv_w, NR, 768, CFFM_C}, {dx1, ws + L.ao, gr->proj_w, NP, CFFM_C, CFFM_C}};
+        const cffm_wgrad wgb[2] = {wg_qkv, wg_proj};
         const GemmTNPre preb[2] = {{0, 1, nullptr}, {0, 0, nullptr}};
         {
             void* stream = stream_b;
             PROF(ST_GEMM); PROF2(ST_G_DW);
-            REQUIRE(!gemm_tn_group((const GemmTN*)wgb, 2, sb, preb, sb == st ? lib_scratch : lib_scratch2, 320, dw_group_launched), "block_backward: weight-gradient gemm failed");
+            REQUIRE(!dw_group(wgb, preb, 2, sb, 320, dw_group_launched), "block_backward: weight-gradient gemm failed");
         }
         if (bias_late) {
             PROF(ST_ATTN_BWD);
@@ -1795,12 +1900,19 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
         }
         }
     }
+    return 0;
+    };
+    // Streaming weight gradients under capture: the group is launched AFTER the chain's next kernel (ln_pool_bwd_tgt below), so that kernel
+    // is the q|k|v input gradient's first-launched dependant and keeps the chain's hardware queue (see side_fork_mark); nothing the
+    // group reads is written by it (fc2's weight gradient reads the T-frag copy of dout, not dout).
+    const bool side_late = stream_dw && one_group && dx_done;
+    if (!side_late) TRY(side_b());
     if (dx_done) {
     } else if (sp && panel_qkv_on()) {
         PROF(ST_GEMM); PROF2(ST_G_QKV_DX);
         REQUIRE(!panel_qkv_dx(dqkv, ws + L.w_frag + PREP_WFLOATS, dzall, NR, st, qkv_rec), "block_backward: q|k|v input-gradient gemm failed");
     }
-    if (!one_group || dx_tgt == dout) side_join(sa, st, 0);    // fc2's weight gradient has read dout before an in-place ln_pool_bwd overwrites it
+    if (!side_late && (!one_group || dx_tgt == dout)) side_join(sa, st, 0);    // fc2's weight gradient has read dout before an in-place ln_pool_bwd overwrites it
 #ifndef CFFM_EMU
     if (g_side.dw_pending[par ^ 1] && g_side.dw_dout[par ^ 1] == dx_tgt) {   // (depth >= 3: the block before still reads its dout = our dx_tgt)
         side_wait(st, g_side.dw_done[par ^ 1]);
@@ -1811,6 +1923,7 @@ static int block_backward_impl(const cffm_geom* g, const cffm_block_params* p, c
     // follow in ONE pass at its end (cffa_finish): they need this block's pooled-cell rows of dzall and nothing else.
     TRY(ln_pool_bwd_tgt(g, x_tgt, tgt_bs, p->norm1_w, p->norm1_b, ws + L.M, ws + L.mean1, ws + L.rstd1, dzall, dx1, dx_tgt, dtgt_bs, cffa.rec,
                         stream));
+    if (side_late) TRY(side_b());
     // the record reductions (every block-partial record of this backward except the CFFA's is written by now):
     // parameter gradients only -> side stream (branch 3); the caller's stream then waits for the side stream once
 #ifndef CFFM_EMU

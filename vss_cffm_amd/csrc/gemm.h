@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include "gemm_kernels.h"
 #include "dw_kernels.h"
+#include "dws_kernels.h"
 
 // ---- hand-written split-bf16 MFMA path (default) -------------------------------------------------------------
 float* lib_scratch(size_t nfloats);   // cffm_hip.hip: library-owned device scratch (grows on demand)
@@ -283,6 +284,86 @@ static int dw_group_dma(const GemmTN* pr, int n, hipStream_t st, float* part, in
     }
 #endif
     CFFM_LAUNCH(k_dw_dma, ((unsigned)wg), (256), DWD_LDS, st, G);
+    if (after_gemm) after_gemm(st);
+    if (nsum) {
+        Sg.cnt = nsum;
+        for (int q = nsum; q < 4; ++q) { Sg.part[q] = nullptr; Sg.out[q] = nullptr; Sg.n[q] = 0; Sg.nsplit[q] = 0; Sg.blk_end[q] = blk; }
+        CFFM_LAUNCH(k_sum_splits_group, ((unsigned)blk), (256), 0, st, Sg);
+    }
+    return 0;
+}
+
+// ---- weight gradients with both operands in T-frag storage: the streaming kernel (dws_kernels.h), up to DWS_MAX problems per launch ----
+// The plan of a group: one number of k-steps per wave for all problems such that the launch has at most `target_wgs` workgroups (one per
+// CU: a workgroup holds ~350 registers per lane), then evened out inside each problem.
+struct DwsPlan { int S[DWS_MAX], kw[DWS_MAX], KS[DWS_MAX], tiles[DWS_MAX]; int wgs; size_t part_floats; };
+static bool dw_stream_plan(const GemmTN* pr, int n, int target_wgs, DwsPlan* P) {
+    if (n < 1 || n > DWS_MAX) return false;
+    long units = 0;
+    for (int p = 0; p < n; ++p) {
+        if (pr[p].N % DWS_TO || pr[p].K % DWS_TI || pr[p].N < DWS_TO || pr[p].K < DWS_TI || pr[p].M < 1) return false;
+        P->KS[p] = (int)((pr[p].M + 31) / 32);
+        P->tiles[p] = (pr[p].N / DWS_TO) * (pr[p].K / DWS_TI);
+        if ((long)P->KS[p] * 32 * pr[p].N * 4 >= (1L << 32) || (long)P->KS[p] * 32 * pr[p].K * 4 >= (1L << 32)) return false;
+        units += (long)P->tiles[p] * P->KS[p];
+    }
+    if (target_wgs < 1) target_wgs = 256;
+    long kw = (units + 4L * target_wgs - 1) / (4L * target_wgs);
+    if (kw < 1) kw = 1;
+    for (;; ++kw) {
+        long wgs = 0;
+        for (int p = 0; p < n; ++p) wgs += (long)P->tiles[p] * ((P->KS[p] + 4 * kw - 1) / (4 * kw));
+        bool single = true;
+        for (int p = 0; p < n; ++p) single = single && P->KS[p] <= 4 * kw;
+        if (wgs <= target_wgs || single) break;
+    }
+    P->wgs = 0;
+    P->part_floats = 0;
+    for (int p = 0; p < n; ++p) {
+        P->S[p] = (int)((P->KS[p] + 4 * kw - 1) / (4 * kw));
+        P->kw[p] = (P->KS[p] + 4 * P->S[p] - 1) / (4 * P->S[p]);
+        P->wgs += P->tiles[p] * P->S[p];
+        if (P->S[p] > 1) P->part_floats += (size_t)P->S[p] * pr[p].N * pr[p].K;
+    }
+    return true;
+}
+static int dw_stream_target() {      // tuning aid: CFFM_DWS_WGS
+    static int v = -1;
+    if (v < 0) { const char* e = cffm_tune("CFFM_DWS_WGS"); v = e ? atoi(e) : 0; if (v < 1) v = 256; }
+    return v;
+}
+// pr[p].dy / .x: T-frag storage of dy [M][N] / x [M][K] (rows past M zero); `part`: plan.part_floats floats of slab scratch (or NULL when 0)
+static int dw_group_stream(const GemmTN* pr, int n, hipStream_t st, float* part, int target_wgs, void (*after_gemm)(hipStream_t) = nullptr) {
+    DwsPlan P;
+    if (!dw_stream_plan(pr, n, target_wgs, &P)) return -1;
+    if (P.part_floats && !part) return -1;
+    DwsGroup G;
+    SumGroup Sg;
+    int wg = 0, blk = 0, nsum = 0;
+    for (int p = 0; p < n; ++p) {
+        G.DY[p] = (const f32x4*)pr[p].dy; G.X[p] = (const f32x4*)pr[p].x; G.N[p] = pr[p].N; G.K[p] = pr[p].K; G.KS[p] = P.KS[p]; G.kw[p] = P.kw[p];
+        G.C[p] = pr[p].dw;
+        if (P.S[p] > 1) {
+            G.C[p] = part;
+            Sg.part[nsum] = part; Sg.out[nsum] = pr[p].dw; Sg.n[nsum] = (long)pr[p].N * pr[p].K; Sg.nsplit[nsum] = P.S[p];
+            blk += (int)((Sg.n[nsum] / 4 + 255) / 256);
+            Sg.blk_end[nsum] = blk;
+            ++nsum;
+            part += (size_t)P.S[p] * pr[p].N * pr[p].K;
+        }
+        wg += P.tiles[p] * P.S[p];
+        G.wg_end[p] = wg;
+    }
+    for (int p = n; p < DWS_MAX; ++p) { G.DY[p] = G.X[p] = nullptr; G.C[p] = nullptr; G.N[p] = DWS_TO; G.K[p] = DWS_TI; G.KS[p] = 0; G.kw[p] = 1; G.wg_end[p] = wg; }
+    G.n = n;
+#ifndef CFFM_EMU
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void*)k_dw_stream, hipFuncAttributeMaxDynamicSharedMemorySize, DWS_LDS) != hipSuccess) return -1;
+        granted = true;
+    }
+#endif
+    CFFM_LAUNCH(k_dw_stream, ((unsigned)wg), (256), DWS_LDS, st, G);
     if (after_gemm) after_gemm(st);
     if (nsum) {
         Sg.cnt = nsum;

@@ -14,6 +14,7 @@
 #pragma once
 #include "cffm_common.h"
 #include "gemm_kernels.h"
+#include "dws_kernels.h"
 
 #ifndef PNL_ABLATE
 #define PNL_ABLATE 0      // profiling builds of scripts/r03_panel_bench.hip only: 1 no B loads in the loop, 2 no MFMAs, 4 no epilogue stores, 8 no panel staging
@@ -193,6 +194,40 @@ __device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT,
     }
 }
 
+// ---- T-frag copies of a panel image (dws_kernels.h: the operand order of the streaming weight-gradient kernel) ---------------------------
+// The hi / lo images [16 MT rows][256 columns] of a panel hold 16 MT / 8 row groups of 8 token rows; unit (k-step, column tile jt, h) of the
+// T-frag array wants, in lane (l15, g), rows 8 g .. 8 g + 7 of column 16 jt + l15: two transposed LDS reads (ds_read_b64_tr_b16: inside a
+// group of 16 lanes, lane i points at 4 contiguous columns 4 (i & 3) of row (i >> 2) and receives column (i & 15) of the 4 rows) and one
+// 16-byte store per lane -- 256 contiguous bytes per 16-lane group, a whole 1 KiB unit per wave instruction when the panel is a k-step.
+// `m0`: first token row of the panel (a multiple of 8); `jt0`: first column tile of the image in the array; `CT`: column tiles of the
+// array; `R`: token rows that exist (rows past R are written as zeros: an image row of a COMPUTED panel past the end holds finite
+// garbage); `R32`: rows of the array (R rounded up to 32; row groups past it are not written).  Wave-collective; call between the
+// barrier that publishes the image and the one that lets it be overwritten.
+template <int MT>
+__device__ __forceinline__ void pnl_tfrag_store(const bf16* __restrict__ hi, const bf16* __restrict__ lo, f32x4* __restrict__ dst, int m0, int jt0, int CT,
+                                                long R, long R32, int wave, int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    constexpr int NRG = 2 * MT, NOP = (NRG + 3) / 4;      // row groups of the panel, wave operations per unit
+#pragma unroll
+    for (int q = 0; q < 32 * NOP / PNL_WAVES; ++q) {
+        const int item = wave + PNL_WAVES * q;           // (unit, operation): units 0..31 = (column tile, h)
+        const int u = item / NOP, op = item % NOP, jt = u >> 1, h = u & 1;
+        const int rgl = 4 * op + g;                      // row group of the panel this 16-lane group transposes
+        const bf16* img = h ? lo : hi;
+        const int row = 8 * (rgl < NRG ? rgl : 0) + (l15 >> 2), col = 16 * jt + 4 * (l15 & 3);
+        const bf16x4 a = lds_tr4_bf16(img + pnl_off(row, col >> 3) + (col & 4));
+        const bf16x4 b = lds_tr4_bf16(img + pnl_off(row + 4, col >> 3) + (col & 4));
+        const long rg = (long)(m0 >> 3) + rgl, r0 = 8 * rg;
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = r0 + e < R ? a[e] : (bf16)0.f;
+            f[4 + e] = r0 + 4 + e < R ? b[e] : (bf16)0.f;
+        }
+        if (rgl < NRG && r0 < R32) dst[tfrag_unit(rg >> 2, jt0 + jt, h, CT) + 16 * (int)(rg & 3) + l15] = __builtin_bit_cast(f32x4, f);
+    }
+}
+
 // L2 warm-up of a fragment-ordered weight at the start of a fused kernel.  Every workgroup streams ALL of the block's weights (2.4 MB);
 // when nobody has read them since k_param_prep wrote them at the start of the step they sit in HBM, and the B ring (D k-steps = 16 KB
 // per wave in flight) cannot cover that latency: the second block's fused forward took 62 us against 42 for the first, whose weights
@@ -225,7 +260,8 @@ __device__ __forceinline__ uint32_t pnl_l2_touch(const void* w, long bytes, int 
 template <int MT, int NTW, int NT, int D, bool A_PRE, int EPI>
 __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restrict__ A, int lda, int M, int K, const f32x4* __restrict__ Wf,
                                                             float* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                                            void* __restrict__ aux = nullptr, float* __restrict__ colrec = nullptr) {
+                                                            void* __restrict__ aux = nullptr, float* __restrict__ colrec = nullptr,
+                                                            f32x4* __restrict__ a_t = nullptr /* T-frag copy of A [M][K] (pnl_tfrag_store), or NULL */) {
     CFFM_DYN_SMEM(smem);
     bf16* img = (bf16*)smem;     // [buf][hi | lo][16 MT][256]
     // colrec (fp32 A only): record blockIdx.x [K] = the column sums of this workgroup's 16 MT rows of A -- the bias gradient of the
@@ -279,6 +315,10 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
         PNL_COLSUM_GET(c)
         const bf16* hi = img + (c & 1) * 2 * PNL_IMG(MT);
         pnl_chunk_mma<MT, NTW, NT, D>(acc, ring, hi, hi + PNL_IMG(MT), st, jt0, 8 * c, l15, g, st, jt0, 8 * (c + 1));
+        // T-frag copy of this chunk BEHIND its product (the image stays until the chunk after next is staged): in front of it the 48 KB of
+        // stores hold up the B-fragment loads queued behind them (q|k|v forward 24 -> 31 us); spread over the product's steps
+        // the transposed reads stall the MFMA stream instead (q|k|v input gradient 28 -> 42 us, burst in front: 31)
+        if (a_t) pnl_tfrag_store<MT>(hi, hi + PNL_IMG(MT), a_t, m0, 16 * c, K / 16, M, ((long)M + 31) / 32 * 32, wave, lane);
         if (c + 1 < NCH) {
             bf16* nx = img + ((c + 1) & 1) * 2 * PNL_IMG(MT);
             pnl_stage_store<MT, A_PRE>(sr, nx, nx + PNL_IMG(MT), tid);
@@ -386,7 +426,8 @@ struct MlpFwdArgs {
     const float* xt; long xt_bs; int rows_per_batch;   // residual input: row m = xt + (m / rpb) * xt_bs + (m % rpb) * 256
     const f32x4 *wp, *w1, *w2;          // fragment-ordered weights, NT form (pnl_pack_weight)
     const float *bp, *b1, *b2, *g2, *be2;
-    float *x1, *z2s /* split-4 */, *mean2, *rstd2, *hraw, *acts /* split-4, or NULL: not stored (the fc2 weight gradient re-applies bias + GELU to hraw) */, *x2;
+    float *x1, *z2s /* split-4, or NULL */, *mean2, *rstd2, *hraw, *acts /* split-4, or NULL: not stored (the fc2 weight gradient re-applies bias + GELU to hraw) */, *x2;
+    f32x4 *ao_t, *z2_t, *act_t;         // T-frag copies of ao [NP][256], z2 [NP][256], act [NP][1024] for the streaming weight gradients (each may be NULL)
     int NP;
 };
 
@@ -423,6 +464,8 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
         }
     }
     pnl_lds_barrier();
+    const long NP32 = ((long)NP + 31) / 32 * 32;
+    if (a.ao_t) pnl_tfrag_store<MT>(P, P + PNL_IMG(MT), a.ao_t, m0, 0, 16, NP, NP32, wave, lane);
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2][MT];
 #pragma unroll
@@ -501,10 +544,11 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
             bf16x4 h, l;
             split4(zv, h, l);
             pnl_img_put(P, P + PNL_IMG(MT), 16 * i + l15, n, h, l);
-            if (PNL_ST(valid[i])) *(f32x4*)(a.z2s + mrow[i] * 256 + n) = pnl_pack_hl(h, l);
+            if (PNL_ST(valid[i]) && a.z2s) *(f32x4*)(a.z2s + mrow[i] * 256 + n) = pnl_pack_hl(h, l);
         }
     }
     pnl_lds_barrier();
+    if (a.z2_t) pnl_tfrag_store<MT>(P, P + PNL_IMG(MT), a.z2_t, m0, 0, 16, NP, NP32, wave, lane);
     // ---- Mlp: hidden chunks of 256 features: fc1 chunk -> GELU -> chunk image -> fc2 accumulates over the chunk
     f32x4 acc2[2][MT];
 #pragma unroll
@@ -538,6 +582,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
             }
         }
         pnl_lds_barrier();
+        if (a.act_t) pnl_tfrag_store<MT>(Ah, Ah + PNL_IMG(MT), a.act_t, m0, 16 * c, 64, NP, NP32, wave, lane);
         const int cn = c < 3 ? c + 1 : 0;
         pnl_chunk_mma<MT, 2, 2, D>(acc2, ring, Ah, Ah + PNL_IMG(MT), s2, 2 * wave, 8 * c, l15, g, s1, 16 * cn + 2 * wave, 0);
     }
@@ -557,7 +602,8 @@ struct MlpBwdArgs {
     const float* hraw; const float* b1; // saved fc1 product, fc1 bias
     const float *x1, *mean2, *rstd2, *g2;
     const f32x4 *w2n, *w1n, *wpn;       // fragment-ordered weights, NN form
-    float* dhs;                         // [NP][1024] split-4: gradient of hraw
+    float* dhs;                         // [NP][1024] split-4: gradient of hraw (or NULL)
+    f32x4 *dout_t, *dh_t, *dx1_t;       // T-frag copies of dout [NP][256], dh [NP][1024], dx1 [NP][256] for the streaming weight gradients (each may be NULL)
     float* dx1;                         // [NP][256]
     float* dao;                         // [NP][256]
     float* rec_b1;                      // [workgroups][1024] column sums of dh (fc1 bias gradient records)
@@ -597,6 +643,8 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
         }
     }
     pnl_lds_barrier();
+    const long NP32 = ((long)NP + 31) / 32 * 32;
+    if (a.dout_t) pnl_tfrag_store<MT>(P, P + PNL_IMG(MT), a.dout_t, m0, 0, 16, NP, NP32, wave, lane);
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     bool valid[MT];
     long mrow[MT];
@@ -641,13 +689,14 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
                 bf16x4 h, l;
                 split4(dh, h, l);
                 pnl_img_put(Ah, Ah + PNL_IMG(MT), 16 * i + l15, nl, h, l);
-                if (PNL_ST(valid[i])) *(f32x4*)(a.dhs + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
+                if (PNL_ST(valid[i]) && a.dhs) *(f32x4*)(a.dhs + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
                 cs += dh;
             }
             for (int e = 0; e < 4; ++e) cs[e] = row16_sum(cs[e]);
             if (l15 == 0) *(f32x4*)(a.rec_b1 + (long)blockIdx.x * 1024 + n) = cs;
         }
         pnl_lds_barrier();
+        if (a.dh_t) pnl_tfrag_store<MT>(Ah, Ah + PNL_IMG(MT), a.dh_t, m0, 16 * c, 64, NP, NP32, wave, lane);
         const bool more = c < 3;
         pnl_chunk_mma<MT, 2, 2, D>(dz, ring, Ah, Ah + PNL_IMG(MT), s1, 2 * wave, 8 * c, l15, g, more ? s2 : sp, more ? 16 * (c + 1) + 2 * wave : 2 * wave, 0);
     }
@@ -732,6 +781,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
         }
     }
     pnl_lds_barrier();
+    if (a.dx1_t) pnl_tfrag_store<MT>(P, P + PNL_IMG(MT), a.dx1_t, m0, 0, 16, NP, NP32, wave, lane);
     f32x4 dq[2][MT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
