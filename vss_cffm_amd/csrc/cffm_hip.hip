@@ -1195,6 +1195,8 @@ int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
     return 0;
 }
 
+// the prototype attention on the matrix pipe for K <= 128 (gtc_kernels.h).  CFFM_GTC_MFMA=0 (experiment builds): the VALU kernels for every K
+CFFM_SWITCH(gtc_mfma_sw, "CFFM_GTC_MFMA", 1)
 int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, float* o, float* lse,
                       int B, int T, int K, void* stream) {
     PROF(ST_GTC_FWD);
@@ -1206,6 +1208,21 @@ int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw,
         granted = true;
     }
 #endif
+    if (K <= 128 && gtc_mfma_sw()) {
+        // the matrix-pipe form (three-pass bf16 split): ~512 workgroups of four waves, each wave a run of 16-token tiles
+        const int tiles = (T + 15) / 16;
+        int tpw = (tiles * CFFM_HEADS * B + 4 * 512 - 1) / (4 * 512);
+        if (tpw < 1) tpw = 1;
+        const unsigned gx = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
+        const int U = (K + 31) / 32;
+        hipStream_t st = (hipStream_t)stream;
+        if (U == 1) CFFM_LAUNCH(k_gtc_attn_fwd_mfma<1>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(1), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
+        else if (U == 2) CFFM_LAUNCH(k_gtc_attn_fwd_mfma<2>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(2), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
+        else if (U == 3) CFFM_LAUNCH(k_gtc_attn_fwd_mfma<3>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(3), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
+        else CFFM_LAUNCH(k_gtc_attn_fwd_mfma<4>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(4), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
+        CHECK_LAUNCH("gtc_attn_fwd");
+        return 0;
+    }
     CFFM_LAUNCH(k_gtc_attn_fwd, ((T + GTC_TOK - 1) / GTC_TOK, CFFM_HEADS, B), (256), (size_t)gtf_lds(K), (hipStream_t)stream, q_raw, q_b, kv_raw, kv_b, o,
                 lse, T, K);
     CHECK_LAUNCH("gtc_attn_fwd");

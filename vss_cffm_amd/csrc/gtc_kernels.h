@@ -8,6 +8,7 @@
 // rows of the head sit in LDS, softmax is online.
 #pragma once
 #include "cffm_common.h"
+#include "gemm_kernels.h"      // mfma16x16x32_bf16, split4
 
 #define GTB_QS_ 36          // floats per row of the q / dO / o tiles in LDS (32 + 4: 16-byte aligned rows on different banks)
 
@@ -97,6 +98,139 @@ __global__ void __launch_bounds__(256) k_gtc_attn_fwd(const float* __restrict__ 
     for (int e = tid; e < GTC_TOK * 8; e += 256) {
         const int tl = e >> 3, c = e & 7, t = t0 + tl;
         if (t < T) *(f32x4*)(o + ((long)b * T + t) * CFFM_C + h * CFFM_HD + 4 * c) = *(const f32x4*)(Qs + tl * GTB_QS_ + 4 * c);
+    }
+}
+
+// Forward on the matrix pipe (round 5, third session; K <= 128).  49 * K * 32 MACs per token-head are little, but the VALU form spends them
+// at 16 broadcast LDS reads per key and wave (LDS-bound: 41-53 us at the reference's K = 100, cffm_head.py:217).  Here a WAVE owns 16 tokens
+// of one head at a time and the prototypes never leave its registers:
+//   S^T [keys x tokens] = Kc Q^T        A = Kc fragments (lane (key l15, channels 8 g ..)), built ONCE per wave; B = Q^T fragments straight
+//                                       from the lane's own q row (token l15, channels 8 g ..: two 16-byte loads);
+//   softmax over the keys of a token = over the 4 C registers x KT tiles of a lane, then two shuffles across the four lane groups;
+//   O^T [channels x tokens] = Vc^T P^T  A = Vc^T fragments (built once per wave from an LDS copy of the head's Vc rows), B = P^T from the C
+//                                       registers of two key tiles (k-slot (g, j) <-> key 32 u + 16 (j >> 2) + 4 g + (j & 3), the bijection
+//                                       of cfm_attn_kernels.h), so P never leaves the registers.
+// Every product is the three-pass bf16 hi / lo split of the Linear GEMMs (hi x lo + lo x hi + hi x hi, error ~2^-17): the block keeps its
+// 1e-4 tolerance -- no f16 operands here.  Keys are padded to 32 U (U = k-steps of the PV product, template parameter); padded keys carry
+// s = -inf.  grid (workgroups, 8 heads, B); a workgroup's four waves walk `tiles_per_wave` consecutive 16-token tiles each.
+#define GTM_LD 33           // floats per row of the Kc / Vc copies in LDS
+__host__ __device__ constexpr int gtm_lds(int U) { return 4 * (2 * 32 * U * GTM_LD); }
+template <int U>
+__global__ void __launch_bounds__(256) k_gtc_attn_fwd_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq,
+                                                            const float* __restrict__ kv_raw, const float* __restrict__ bkv,
+                                                            float* __restrict__ o, float* __restrict__ lse, int T, int K, int tiles_per_wave) {
+    constexpr int KT = 2 * U, KP = 32 * U;
+    CFFM_DYN_SMEM(smem);
+    float* Kc = (float*)smem;           // [KP][GTM_LD] (rows >= K zero)
+    float* Vc = Kc + KP * GTM_LD;
+    const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const float scale = 0.17677669529663687f;
+    for (int e = tid; e < KP * CFFM_HD; e += 256) {
+        const int k = e >> 5, d = e & 31;
+        float kc = 0.f, vc = 0.f;
+        if (k < K) {
+            const float* row = kv_raw + ((long)b * K + k) * 512 + h * CFFM_HD + d;
+            kc = row[0] + bkv[h * CFFM_HD + d];
+            vc = row[256] + bkv[256 + h * CFFM_HD + d];
+        }
+        Kc[k * GTM_LD + d] = kc; Vc[k * GTM_LD + d] = vc;
+    }
+    __syncthreads();
+    // the wave's constant fragments
+    bf16x8 kh[KT], kl[KT], vh[2][U], vl[2][U];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const float* r = Kc + (16 * t + l15) * GTM_LD + 8 * g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = r[e];
+            kh[t][e] = (bf16)x;
+            kl[t][e] = (bf16)(x - (float)kh[t][e]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = Vc[(32 * u + 16 * (j >> 2) + 4 * g + (j & 3)) * GTM_LD + 16 * mt + l15];
+                vh[mt][u][j] = (bf16)x;
+                vl[mt][u][j] = (bf16)(x - (float)vh[mt][u][j]);
+            }
+    const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
+    const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+    for (int it = 0; it < tiles_per_wave; ++it) {
+        const int t0 = 16 * (tile0 + it);
+        if (t0 >= T) break;                              // (wave-uniform)
+        const int t = t0 + l15;
+        const bool live = t < T;
+        const long row = (long)b * T + (live ? t : 0);
+        f32x4 q0 = (f32x4){0.f, 0.f, 0.f, 0.f}, q1 = q0;
+        if (live) {
+            q0 = (*(const f32x4*)(q_raw + row * CFFM_C + h * CFFM_HD + 8 * g) + bq0) * scale;
+            q1 = (*(const f32x4*)(q_raw + row * CFFM_C + h * CFFM_HD + 8 * g + 4) + bq1) * scale;
+        }
+        bf16x8 qh, ql;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qh[e] = (bf16)q0[e]; ql[e] = (bf16)(q0[e] - (float)qh[e]);
+            qh[4 + e] = (bf16)q1[e]; ql[4 + e] = (bf16)(q1[e] - (float)qh[4 + e]);
+        }
+        // S^T tiles: lane (token l15) holds keys 16 t + 4 g + r
+        f32x4 sv[KT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+            c = mfma16x16x32_bf16(kh[kt], ql, c);
+            c = mfma16x16x32_bf16(kl[kt], qh, c);
+            c = mfma16x16x32_bf16(kh[kt], qh, c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * kt + 4 * g + r >= K) c[r] = -INFINITY;
+                m = fmaxf(m, c[r]);
+            }
+            sv[kt] = c;
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = expf(sv[kt][r] - m);     // (a padded key: exp(-inf) = 0; key 0 always exists, so m is finite)
+                sv[kt][r] = pv;
+                l += pv;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 ov[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bf16x8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = sv[2 * u][e], c = sv[2 * u + 1][e];
+                ph[e] = (bf16)a; pl[e] = (bf16)(a - (float)ph[e]);
+                ph[4 + e] = (bf16)c; pl[4 + e] = (bf16)(c - (float)ph[4 + e]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                ov[mt] = mfma16x16x32_bf16(vh[mt][u], pl, ov[mt]);
+                ov[mt] = mfma16x16x32_bf16(vl[mt][u], ph, ov[mt]);
+                ov[mt] = mfma16x16x32_bf16(vh[mt][u], ph, ov[mt]);
+            }
+        }
+        // lane: channels 16 mt + 4 g .. + 3 of token l15
+        if (live) {
+            const float inv = 1.f / l;
+            float* orow = o + row * CFFM_C + h * CFFM_HD + 4 * g;
+            *(f32x4*)(orow) = ov[0] * inv;
+            *(f32x4*)(orow + 16) = ov[1] * inv;
+            if (g == 0) lse[row * CFFM_HEADS + h] = m + logf(l);
+        }
     }
 }
 
