@@ -1234,6 +1234,37 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
     PROF(ST_GTC_BWD);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(K >= 1 && K <= 256 && B >= 1 && T >= 1, "gtc_attn_bwd: K=%d outside 1..256", K);
+    if (K <= 128 && gtc_mfma_sw()) {
+        // the matrix-pipe form (gtc_kernels.h): dq per 16-token tile, then dKc / dVc per pair of tiles into one record per workgroup
+        const int tiles = (T + 15) / 16, pairs = (T + 31) / 32, U = (K + 31) / 32;
+        int tpw = (tiles * CFFM_HEADS * B + 4 * 512 - 1) / (4 * 512), ppw = (pairs * CFFM_HEADS * B + 4 * 256 - 1) / (4 * 256);
+        if (tpw < 1) tpw = 1;
+        if (ppw < 1) ppw = 1;
+        const unsigned g1 = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)), g2 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
+        const size_t nD = ((size_t)B * T * CFFM_HEADS + 63) / 64 * 64;
+        float* scr = lib_scratch(nD + (size_t)B * CFFM_HEADS * g2 * K * 64);
+        REQUIRE(scr, "gtc_attn_bwd: scratch allocation failed");
+        float* Dbuf = scr;
+        float* rec = scr + nD;
+#ifndef CFFM_EMU
+        static bool granted_m = false;
+        if (!granted_m) {
+            REQUIRE(hipFuncSetAttribute((const void*)k_gtc_attn_bwd_dkv_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, gtm_bwd_lds(4)) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)k_gtc_attn_bwd_dkv_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, gtm_bwd_lds(4)) == hipSuccess, "gtc_attn_bwd: LDS grant failed");
+            granted_m = true;
+        }
+#endif
+#define GTM_BWD(U_)                                                                                                                                              \
+        do {                                                                                                                                                 \
+            CFFM_LAUNCH(k_gtc_attn_bwd_dq_mfma<U_>, (g1, CFFM_HEADS, B), (256), (size_t)(4 * 32 * U_ * 64), st, q_raw, q_b, kv_raw, kv_b, o, dout, lse, dq_raw, Dbuf, T, K, tpw); \
+            CFFM_LAUNCH(k_gtc_attn_bwd_dkv_mfma<U_>, (g2, CFFM_HEADS, B), (256), (size_t)gtm_bwd_lds(U_), st, q_raw, q_b, kv_raw, kv_b, dout, lse, (const float*)Dbuf, rec, T, K, ppw); \
+        } while (0)
+        if (U == 1) GTM_BWD(1); else if (U == 2) GTM_BWD(2); else if (U == 3) GTM_BWD(3); else GTM_BWD(4);
+#undef GTM_BWD
+        CFFM_LAUNCH(k_gtc_dkv_sum, (K, CFFM_HEADS, B), (64), 0, st, (const float*)rec, (int)g2, K, dkv);
+        CHECK_LAUNCH("gtc_attn_bwd");
+        return 0;
+    }
     const int per = gtb_tok(K) * GTB_CHUNKS, nwg = (T + per - 1) / per;
     float* rec = lib_scratch((size_t)B * CFFM_HEADS * nwg * K * 64);       // one [K][64] record per workgroup: k_gtc_dkv_sum adds them in order
     REQUIRE(rec, "gtc_attn_bwd: scratch allocation failed");

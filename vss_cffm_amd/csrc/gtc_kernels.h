@@ -386,6 +386,256 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd(const float* __restrict__ 
             if (4 * kq + r < K) *(f32x4*)(out + (long)(4 * kq + r) * 64 + (isv ? 32 : 0) + 4 * d4) = accb[j][r];
     }
 }
+// Backward on the matrix pipe (K <= 128), two launches, every product the three-pass bf16 split of the forward:
+//   k_gtc_attn_bwd_dq_mfma   a wave per 16-token tile, keys x tokens orientation as in the forward: S^T = Kc Q^T, dP^T = Vc dO^T (A = row fragments of
+//                            the prototypes, read from bf16 hi / lo images in LDS; B = the lane's own q / dO rows), p = exp(s - lse),
+//                            ds = p (dp - D); dQ^T = Kc^T dS with dS as the B operand straight from the C registers (the k-slot <-> key bijection of
+//                            the forward) and the Kc^T fragments in registers.  D = sum_keys p dp (= sum_ch dO o) comes out of the same products; it is left in
+//                            Dbuf [B*T][8] for the second launch.
+//   k_gtc_attn_bwd_dkv_mfma  a wave per PAIR of 16-token tiles, tokens x keys orientation (the operands swapped: S = Q Kc^T, dP = dO Vc^T -- the same
+//                            fragments), so that p and ds of a key tile sit in the C registers as B operands of products that contract over the 32
+//                            TOKENS: dVc^T += dO^T P, dKc^T += Q^T dS (A = transposed q / dO tiles out of a wave-private LDS copy).  The wave's
+//                            accumulators (2 x 32 channels x K keys) live in registers over its run of pairs; the four waves of a workgroup are added
+//                            through LDS in wave order and leave ONE record [K][64] (dKc | dVc) -- k_gtc_dkv_sum adds the records in order as before.
+// Deterministic, no atomics.  (The VALU kernel above stays for K > 128.)
+#define GTM_SWZ(row) ((0x78 >> (((row) >> 1) & 6)) & 3)                   // the row swizzle of cfm_attn_kernels.h (ATT_ROW): 64-byte rows, conflict-free fragment reads
+#define GTM_ROW(row, chunk) ((row) * 32 + 8 * ((chunk) ^ GTM_SWZ(row)))   // bf16 element offset of 16-byte chunk `chunk` of row `row`
+#define GTM_TLD 36                                                        // floats per row of the wave-private q / dO tiles
+__host__ __device__ constexpr int gtm_bwd_lds(int U) { return 4 * 32 * U * 64 + 4 * 2 * 32 * GTM_TLD * 4; }   // four bf16 images + 4 waves x (q | dO) tiles (the record tiles reuse those)
+// bf16 hi / lo images of the head's Kc / Vc rows ([32 U][32], rows >= K zero): img[0] KcH, [1] KcL, [2] VcH, [3] VcL
+template <int U>
+__device__ __forceinline__ void gtm_build_images(bf16* img, const float* __restrict__ kv_raw, const float* __restrict__ bkv, int b, int h, int K, int tid) {
+    constexpr int KP = 32 * U;
+    for (int e = tid; e < KP * CFFM_HD; e += 256) {
+        const int k = e >> 5, d = e & 31;
+        float kc = 0.f, vc = 0.f;
+        if (k < K) {
+            const float* row = kv_raw + ((long)b * K + k) * 512 + h * CFFM_HD + d;
+            kc = row[0] + bkv[h * CFFM_HD + d];
+            vc = row[256] + bkv[256 + h * CFFM_HD + d];
+        }
+        const int o = GTM_ROW(k, d >> 3) + (d & 7);
+        const bf16 kh = (bf16)kc, vh = (bf16)vc;
+        img[o] = kh; img[KP * 32 + o] = (bf16)(kc - (float)kh);
+        img[2 * KP * 32 + o] = vh; img[3 * KP * 32 + o] = (bf16)(vc - (float)vh);
+    }
+}
+__device__ __forceinline__ void gtm_split8(f32x4 a, f32x4 b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16)a[e]; lo[e] = (bf16)(a[e] - (float)hi[e]);
+        hi[4 + e] = (bf16)b[e]; lo[4 + e] = (bf16)(b[e] - (float)hi[4 + e]);
+    }
+}
+__device__ __forceinline__ f32x4 gtm_mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
+    c = mfma16x16x32_bf16(ah, bl, c);
+    c = mfma16x16x32_bf16(al, bh, c);
+    return mfma16x16x32_bf16(ah, bh, c);
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const float* __restrict__ kv_raw,
+                                                               const float* __restrict__ bkv, const float* __restrict__ o, const float* __restrict__ dout,
+                                                               const float* __restrict__ lse, float* __restrict__ dq_raw, float* __restrict__ Dbuf, int T, int K,
+                                                               int tiles_per_wave) {
+    constexpr int KT = 2 * U, KP = 32 * U;
+    CFFM_DYN_SMEM(smem);
+    bf16* img = (bf16*)smem;
+    const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const float scale = 0.17677669529663687f;
+    gtm_build_images<U>(img, kv_raw, bkv, b, h, K, tid);
+    __syncthreads();
+    const bf16 *KH = img, *KL = img + KP * 32, *VH = img + 2 * KP * 32, *VL = img + 3 * KP * 32;
+    // Kc^T fragments: lane (channel 16 mt + l15, k-slot (g, j) <-> key 32 u + 16 (j >> 2) + 4 g + (j & 3))
+    bf16x8 kth[2][U], ktl[2][U];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = 32 * u + 16 * (j >> 2) + 4 * g + (j & 3), ch = 16 * mt + l15, off = GTM_ROW(key, ch >> 3) + (ch & 7);
+                kth[mt][u][j] = KH[off];
+                ktl[mt][u][j] = KL[off];
+            }
+    const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+    for (int it = 0; it < tiles_per_wave; ++it) {
+        const int t0 = 16 * (tile0 + it);
+        if (t0 >= T) break;                              // (wave-uniform)
+        const int t = t0 + l15;
+        const bool live = t < T;
+        const long row = (long)b * T + (live ? t : 0);
+        f32x4 q0 = z4, q1 = z4, g0 = z4, g1 = z4;
+        float ls = 0.f;
+        if (live) {
+            const long base = row * CFFM_C + h * CFFM_HD + 8 * g;
+            q0 = (*(const f32x4*)(q_raw + base) + bq0) * scale;
+            q1 = (*(const f32x4*)(q_raw + base + 4) + bq1) * scale;
+            g0 = *(const f32x4*)(dout + base); g1 = *(const f32x4*)(dout + base + 4);
+            ls = lse[row * CFFM_HEADS + h];
+        }
+        bf16x8 qh, ql, gh, gl;
+        gtm_split8(q0, q1, qh, ql);
+        gtm_split8(g0, g1, gh, gl);
+        // D = sum_ch dO o = sum_keys p dp: taken from the SAME products as dp, so that ds = p (dp - D) cancels to rounding noise of the
+        // fp32 sums, not of the split products, where it must (one prototype: p = 1, dp = D, ds = 0); the saved o is not read at all
+        f32x4 ds[KT], dpv[KT];
+        float D = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int ko = GTM_ROW(16 * kt + l15, g);
+            const f32x4 sv = gtm_mma3(*(const bf16x8*)(KH + ko), *(const bf16x8*)(KL + ko), qh, ql, z4);
+            dpv[kt] = gtm_mma3(*(const bf16x8*)(VH + ko), *(const bf16x8*)(VL + ko), gh, gl, z4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (live && 16 * kt + 4 * g + r < K) ? expf(sv[r] - ls) : 0.f;
+                ds[kt][r] = pv;
+                D += pv * dpv[kt][r];
+            }
+        }
+        D += __shfl_xor(D, 16, 64);
+        D += __shfl_xor(D, 32, 64);
+        if (live && g == 0) Dbuf[row * CFFM_HEADS + h] = D;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[kt][r] *= dpv[kt][r] - D;
+        f32x4 dq[2] = {z4, z4};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bf16x8 dh, dl;
+            gtm_split8(ds[2 * u], ds[2 * u + 1], dh, dl);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) dq[mt] = gtm_mma3(kth[mt][u], ktl[mt][u], dh, dl, dq[mt]);
+        }
+        if (live) {      // lane: channels 16 mt + 4 g .. + 3 of token l15
+            float* drow = dq_raw + row * CFFM_C + h * CFFM_HD + 4 * g;
+            *(f32x4*)(drow) = dq[0] * scale;
+            *(f32x4*)(drow + 16) = dq[1] * scale;
+        }
+    }
+}
+
+// grid (records per (clip, head), 8, B), 256 threads; rec [B][8][gridDim.x][K][64]
+template <int U>
+__global__ void __launch_bounds__(256) k_gtc_attn_bwd_dkv_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const float* __restrict__ kv_raw,
+                                                                const float* __restrict__ bkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                const float* __restrict__ Dbuf, float* __restrict__ rec, int T, int K, int pairs_per_wave) {
+    constexpr int KT = 2 * U, KP = 32 * U;
+    CFFM_DYN_SMEM(smem);
+    bf16* img = (bf16*)smem;
+    float* tiles = (float*)(img + 4 * KP * 32);         // [4 waves][q tile 32 x GTM_TLD | dO tile 32 x GTM_TLD]; later the waves' record tiles
+    const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const float scale = 0.17677669529663687f;
+    gtm_build_images<U>(img, kv_raw, bkv, b, h, K, tid);
+    __syncthreads();
+    const bf16 *KH = img, *KL = img + KP * 32, *VH = img + 2 * KP * 32, *VL = img + 3 * KP * 32;
+    float* Tq = tiles + wave * (2 * 32 * GTM_TLD);
+    float* Tg = Tq + 32 * GTM_TLD;
+    const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 aK[2][KT], aV[2][KT];      // dKc^T / dVc^T: lane (channel 16 mt + 4 g + r, key 16 t + l15)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) aK[mt][kt] = aV[mt][kt] = z4;
+    const int pair0 = (blockIdx.x * 4 + wave) * pairs_per_wave;
+    for (int it = 0; it < pairs_per_wave; ++it) {
+        const int t0 = 32 * (pair0 + it);
+        if (t0 >= T) break;                              // (wave-uniform)
+        bf16x8 qh[2], ql[2], gh[2], gl[2];
+        f32x4 ls[2], Dv[2];
+        wave_lds_sync();                                 // the previous pair's transposed reads are done
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int t = t0 + 16 * x + l15;
+            f32x4 q0 = z4, q1 = z4, g0 = z4, g1 = z4;
+            if (t < T) {
+                const long base = ((long)b * T + t) * CFFM_C + h * CFFM_HD + 8 * g;
+                q0 = (*(const f32x4*)(q_raw + base) + bq0) * scale;
+                q1 = (*(const f32x4*)(q_raw + base + 4) + bq1) * scale;
+                g0 = *(const f32x4*)(dout + base); g1 = *(const f32x4*)(dout + base + 4);
+            }
+            gtm_split8(q0, q1, qh[x], ql[x]);
+            gtm_split8(g0, g1, gh[x], gl[x]);
+            float* tq = Tq + (16 * x + l15) * GTM_TLD + 8 * g;
+            float* tg = Tg + (16 * x + l15) * GTM_TLD + 8 * g;
+            *(f32x4*)tq = q0; *(f32x4*)(tq + 4) = q1;
+            *(f32x4*)tg = g0; *(f32x4*)(tg + 4) = g1;
+            // the statistics of this lane's four tokens 4 g + r of the half (C rows of the tokens x keys orientation)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tt = t0 + 16 * x + 4 * g + r;
+                const long rr = ((long)b * T + (tt < T ? tt : 0)) * CFFM_HEADS + h;
+                ls[x][r] = tt < T ? lse[rr] : INFINITY;          // (exp(s - inf) = 0: a token past the end contributes nothing)
+                Dv[x][r] = tt < T ? Dbuf[rr] : 0.f;
+            }
+        }
+        wave_lds_sync();
+        // transposed q / dO fragments: lane (channel 16 mt + l15, k-slot (g, j) <-> token 16 (j >> 2) + 4 g + (j & 3) of the pair)
+        bf16x8 qth[2], qtl[2], gth[2], gtl[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 a0, a1, c0, c1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = Tq[(4 * g + j) * GTM_TLD + 16 * mt + l15]; a1[j] = Tq[(16 + 4 * g + j) * GTM_TLD + 16 * mt + l15];
+                c0[j] = Tg[(4 * g + j) * GTM_TLD + 16 * mt + l15]; c1[j] = Tg[(16 + 4 * g + j) * GTM_TLD + 16 * mt + l15];
+            }
+            gtm_split8(a0, a1, qth[mt], qtl[mt]);
+            gtm_split8(c0, c1, gth[mt], gtl[mt]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int ko = GTM_ROW(16 * kt + l15, g);
+            const bf16x8 kh = *(const bf16x8*)(KH + ko), kl = *(const bf16x8*)(KL + ko), vh = *(const bf16x8*)(VH + ko), vl = *(const bf16x8*)(VL + ko);
+            const bool kok = 16 * kt + l15 < K;
+            f32x4 pv[2], dsv[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const f32x4 sv = gtm_mma3(qh[x], ql[x], kh, kl, z4);     // S[token 4 g + r][key 16 kt + l15]
+                const f32x4 dp = gtm_mma3(gh[x], gl[x], vh, vl, z4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = kok ? expf(sv[r] - ls[x][r]) : 0.f;
+                    pv[x][r] = p;
+                    dsv[x][r] = p * (dp[r] - Dv[x][r]);
+                }
+            }
+            bf16x8 ph, pl, dh, dl;
+            gtm_split8(pv[0], pv[1], ph, pl);
+            gtm_split8(dsv[0], dsv[1], dh, dl);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                aV[mt][kt] = gtm_mma3(gth[mt], gtl[mt], ph, pl, aV[mt][kt]);
+                aK[mt][kt] = gtm_mma3(qth[mt], qtl[mt], dh, dl, aK[mt][kt]);
+            }
+        }
+    }
+    // ---- the record of this workgroup: the four waves' accumulators added in wave order, key tile by key tile
+    float* out = rec + (((long)(b * CFFM_HEADS + h) * gridDim.x + blockIdx.x) * K) * 64;
+    constexpr int RLD = 68;                               // floats per row of a record tile [16 keys][64]
+    float* R = tiles;                                     // [4 waves][16][RLD] (17 KB of the 36 KB tile area)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();                                  // the tile area is free (first trip: every wave is done with its q / dO tiles)
+        float* mine = R + wave * 16 * RLD + l15 * RLD + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            *(f32x4*)(mine + 16 * mt) = aK[mt][kt];
+            *(f32x4*)(mine + 32 + 16 * mt) = aV[mt][kt];
+        }
+        __syncthreads();
+        const int rowk = tid >> 4, c4 = 4 * (tid & 15), key = 16 * kt + rowk;
+        if (key < K) {
+            const float* src = R + rowk * RLD + c4;
+            *(f32x4*)(out + (long)key * 64 + c4) = (*(const f32x4*)(src) + *(const f32x4*)(src + 16 * RLD)) + (*(const f32x4*)(src + 32 * RLD) + *(const f32x4*)(src + 48 * RLD));
+        }
+    }
+}
+
 // dkv [B*K][512] (dKc at column h*32, dVc at 256 + h*32; dKc carries the q scale already) = the records of each (clip, head) added in
 // order.  grid (K, 8, B), 64 threads
 __global__ void __launch_bounds__(64) k_gtc_dkv_sum(const float* __restrict__ rec, int nrec, int K, float* __restrict__ dkv) {
