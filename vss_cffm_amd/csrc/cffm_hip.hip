@@ -1442,9 +1442,15 @@ int cffm_mlp_bwd(const float* dout, const float* hraw, const float* b1, const fl
 // from proj_cluster to the block output is the fused Mlp launch of the base block (k_mlp_fwd / k_mlp_bwd: same shapes), the four large
 // weight gradients are one grouped launch (k_gemm_group_tt), every bias / norm gradient is a record reduction in one launch.
 struct GtcWs {     // float offsets into the caller's workspace: what the forward keeps for the backward, then the backward's temporaries
-    long z, mean1, rstd1, cn, cmean, crstd, qraw, kvraw, ao, lse, x1, z2, mean2, rstd2, hraw, act, wf, wn, saved;
-    long dh, dx1, dao, dq, dz, dkv, dcn, total;
+    long z, mean1, rstd1, cn, cmean, crstd, qraw, kvraw, ao, lse, x1, z2, mean2, rstd2, hraw, act, wf, wn, z_t, ao_t, saved;
+    long dh, dx1, dao, dq, dz, dkv, dcn, dout_t, dx1_t, dq_t, total;
 };
+// The block's four large weight gradients by the streaming kernel (dws_kernels.h) -- everything of this block runs on ONE stream, so what the
+// kernel saves alone (51 -> 38 us) is saved in the step.  z2 / act / dh are then kept in T-frag storage only, z / ao / dout / dx1 / dq get
+// T-frag copies from the row-panel kernels that stage them.  GTC_DW_STREAM=0: the LDS-staged group on split-4 / fp32 operands.
+#ifndef GTC_DW_STREAM
+#define GTC_DW_STREAM 1
+#endif
 #define GTC_WFLOATS (2 * 256 * 256 + 2 * 1024 * 256)     // q third | proj_cluster | fc1 | fc2 in fragment order
 static GtcWs gtc_ws_layout(long nt, long nk) {
     GtcWs w;
@@ -1454,13 +1460,16 @@ static GtcWs gtc_ws_layout(long nt, long nk) {
     w.cn = p; p += up(nk * CFFM_C); w.cmean = p; p += up(nk); w.crstd = p; p += up(nk);
     w.qraw = p; p += up(nt * CFFM_C); w.kvraw = p; p += up(nk * 512);
     w.ao = p; p += up(nt * CFFM_C); w.lse = p; p += up(nt * CFFM_HEADS);
-    w.x1 = p; p += up(nt * CFFM_C); w.z2 = p; p += up(nt * CFFM_C); w.mean2 = p; p += up(nt); w.rstd2 = p; p += up(nt);
-    w.hraw = p; p += up(nt * CFFM_HID); w.act = p; p += up(nt * CFFM_HID);
+    const long nt32 = (nt + 31) / 32 * 32;      // T-frag storage pads the token rows to whole k-steps of 32
+    w.x1 = p; p += up(nt * CFFM_C); w.z2 = p; p += up(nt32 * CFFM_C); w.mean2 = p; p += up(nt); w.rstd2 = p; p += up(nt);
+    w.hraw = p; p += up(nt * CFFM_HID); w.act = p; p += up(nt32 * CFFM_HID);
     w.wf = p; p += up(GTC_WFLOATS); w.wn = p; p += up(GTC_WFLOATS);
+    w.z_t = p; p += up(nt32 * CFFM_C); w.ao_t = p; p += up(nt32 * CFFM_C);
     w.saved = p;
-    w.dh = p; p += up(nt * CFFM_HID);
+    w.dh = p; p += up(nt32 * CFFM_HID);
     w.dx1 = p; p += up(nt * CFFM_C); w.dao = p; p += up(nt * CFFM_C); w.dq = p; p += up(nt * CFFM_C); w.dz = p; p += up(nt * CFFM_C);
     w.dkv = p; p += up(nk * 512); w.dcn = p; p += up(nk * CFFM_C);
+    w.dout_t = p; p += up(nt32 * CFFM_C); w.dx1_t = p; p += up(nt32 * CFFM_C); w.dq_t = p; p += up(nt32 * CFFM_C);
     w.total = p;
     return w;
 }
@@ -1504,12 +1513,18 @@ int cffm_gtc_block_forward(const cffm_gtc_params* p, const float* x, const float
     }
     {
         PROF(ST_GEMM);
-        const int rc = panel_mt(nt) == 3 ? panel_gemm_launch<3, 2, true, 0>(ws + W.z, 256, nt, 256, wf, ws + W.qraw, 256, nullptr, nullptr, st)
-                                         : panel_gemm_launch<2, 2, true, 0>(ws + W.z, 256, nt, 256, wf, ws + W.qraw, 256, nullptr, nullptr, st);
+        float* z_t = GTC_DW_STREAM ? ws + W.z_t : nullptr;
+        const int rc = panel_mt(nt) == 3 ? panel_gemm_launch<3, 2, true, 0>(ws + W.z, 256, nt, 256, wf, ws + W.qraw, 256, nullptr, nullptr, st, nullptr, z_t)
+                                         : panel_gemm_launch<2, 2, true, 0>(ws + W.z, 256, nt, 256, wf, ws + W.qraw, 256, nullptr, nullptr, st, nullptr, z_t);
         REQUIRE(!rc, "gtc_block_forward: q gemm failed");
         REQUIRE(!gemm_nt(ws + W.cn, p->kv_w, ws + W.kvraw, nk, 512, 256, st), "gtc_block_forward: kv gemm failed");
     }
     TRY(cffm_gtc_attn_fwd(ws + W.qraw, p->qkv_b, ws + W.kvraw, p->kv_b, ws + W.ao, ws + W.lse, B, T, K, stream));
+    if (GTC_DW_STREAM)
+        TRY(cffm_mlp_fwd_tfrag(ws + W.ao, x, 0, (int)nt, wf + 256 * 256, wf + 2 * 256 * 256, wf + 2 * 256 * 256 + CFFM_HID * 256, p->proj_b, p->fc1_b, p->fc2_b,
+                               p->norm2_w, p->norm2_b, ws + W.x1, nullptr, ws + W.mean2, ws + W.rstd2, ws + W.hraw, nullptr, out, ws + W.ao_t, ws + W.z2,
+                               ws + W.act, nt, stream));
+    else
     TRY(cffm_mlp_fwd(ws + W.ao, x, 0, (int)nt, wf + 256 * 256, wf + 2 * 256 * 256, wf + 2 * 256 * 256 + CFFM_HID * 256, p->proj_b, p->fc1_b, p->fc2_b,
                      p->norm2_w, p->norm2_b, ws + W.x1, ws + W.z2, ws + W.mean2, ws + W.rstd2, ws + W.hraw, ws + W.act, out, nt, stream));
     return 0;
@@ -1535,6 +1550,11 @@ int cffm_gtc_block_backward(const cffm_gtc_params* p, const cffm_gtc_grads* g, c
 #endif
     RedScope reductions(st);      // the bias / norm record reductions below run as ONE launch (finish())
     // x2 = x1 + Mlp(LN2(x1)), x1 = x + o Wpc^T + bpc: the fused input-gradient chain of the base block
+    if (GTC_DW_STREAM)
+        TRY(cffm_mlp_bwd_tfrag(dout, ws + W.hraw, p->fc1_b, ws + W.x1, ws + W.mean2, ws + W.rstd2, p->norm2_w, wn + 2 * 256 * 256 + CFFM_HID * 256,
+                               wn + 2 * 256 * 256, wn + 256 * 256, nullptr, ws + W.dx1, ws + W.dao, g->norm2_w, g->norm2_b, g->fc1_b, g->fc2_b, g->proj_b,
+                               ws + W.dout_t, ws + W.dh, ws + W.dx1_t, nt, stream));
+    else
     TRY(cffm_mlp_bwd(dout, ws + W.hraw, p->fc1_b, ws + W.x1, ws + W.mean2, ws + W.rstd2, p->norm2_w, wn + 2 * 256 * 256 + CFFM_HID * 256, wn + 2 * 256 * 256,
                      wn + 256 * 256, ws + W.dh, ws + W.dx1, ws + W.dao, g->norm2_w, g->norm2_b, g->fc1_b, g->fc2_b, g->proj_b, nt, stream));
     TRY(cffm_gtc_attn_bwd(ws + W.qraw, p->qkv_b, ws + W.kvraw, p->kv_b, ws + W.ao, ws + W.dao, ws + W.lse, ws + W.dq, ws + W.dkv, B, T, K, stream));
@@ -1545,8 +1565,9 @@ int cffm_gtc_block_backward(const cffm_gtc_params* p, const cffm_gtc_grads* g, c
         const long nrec = (nt + 16 * mt - 1) / (16 * mt);
         float* qrec = red_scratch((size_t)nrec * 256, st);
         REQUIRE(qrec, "gtc_block_backward: scratch allocation failed");
-        const int rc = mt == 3 ? panel_gemm_launch<3, 2, false, 0>(ws + W.dq, 256, nt, 256, wn, ws + W.dz, 256, nullptr, nullptr, st, qrec)
-                               : panel_gemm_launch<2, 2, false, 0>(ws + W.dq, 256, nt, 256, wn, ws + W.dz, 256, nullptr, nullptr, st, qrec);
+        float* dq_t = GTC_DW_STREAM ? ws + W.dq_t : nullptr;
+        const int rc = mt == 3 ? panel_gemm_launch<3, 2, false, 0>(ws + W.dq, 256, nt, 256, wn, ws + W.dz, 256, nullptr, nullptr, st, qrec, dq_t)
+                               : panel_gemm_launch<2, 2, false, 0>(ws + W.dq, 256, nt, 256, wn, ws + W.dz, 256, nullptr, nullptr, st, qrec, dq_t);
         REQUIRE(!rc, "gtc_block_backward: q input-gradient gemm failed");
         RedSegs segs;
         segs.nseg = 0;
@@ -1559,6 +1580,15 @@ int cffm_gtc_block_backward(const cffm_gtc_params* p, const cffm_gtc_grads* g, c
         const cffm_wgrad wg4[4] = {{ws + W.dq, ws + W.z, g->qkv_w, nt, 256, 256}, {ws + W.dh, ws + W.z2, g->fc1_w, nt, CFFM_HID, 256},
                                    {dout, ws + W.act, g->fc2_w, nt, 256, CFFM_HID}, {ws + W.dx1, ws + W.ao, g->proj_w, nt, 256, 256}};
         const GemmTNPre pre4[4] = {{0, 1, nullptr}, {1, 1, nullptr}, {0, 1, nullptr}, {0, 0, nullptr}};
+        if (GTC_DW_STREAM) {
+            const cffm_wgrad wt4[4] = {{ws + W.dq_t, ws + W.z_t, g->qkv_w, nt, 256, 256}, {ws + W.dh, ws + W.z2, g->fc1_w, nt, CFFM_HID, 256},
+                                       {ws + W.dout_t, ws + W.act, g->fc2_w, nt, 256, CFFM_HID}, {ws + W.dx1_t, ws + W.ao_t, g->proj_w, nt, 256, 256}};
+            DwsPlan P;
+            REQUIRE(dw_stream_plan((const GemmTN*)wt4, 4, dw_stream_target(), &P), "gtc_block_backward: weight-gradient plan failed");
+            float* part = P.part_floats ? lib_scratch(P.part_floats) : nullptr;
+            REQUIRE(!P.part_floats || part, "gtc_block_backward: scratch allocation failed");
+            REQUIRE(!dw_group_stream((const GemmTN*)wt4, 4, st, part, dw_stream_target()), "gtc_block_backward: weight-gradient gemm failed");
+        } else
         REQUIRE(!gemm_tn_group((const GemmTN*)wg4, 4, st, pre4, lib_scratch, 480), "gtc_block_backward: weight-gradient gemm failed");
     }
     // the prototype side: [Kc|Vc] = cn Wkv^T + bkv on B*K rows
