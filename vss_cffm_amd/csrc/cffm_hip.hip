@@ -1216,10 +1216,15 @@ int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw,
         const unsigned gx = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
         const int U = (K + 31) / 32;
         hipStream_t st = (hipStream_t)stream;
-        if (U == 1) CFFM_LAUNCH(k_gtc_attn_fwd_mfma<1>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(1), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
-        else if (U == 2) CFFM_LAUNCH(k_gtc_attn_fwd_mfma<2>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(2), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
-        else if (U == 3) CFFM_LAUNCH(k_gtc_attn_fwd_mfma<3>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(3), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
-        else CFFM_LAUNCH(k_gtc_attn_fwd_mfma<4>, (gx, CFFM_HEADS, B), (256), (size_t)gtm_lds(4), st, q_raw, q_b, kv_raw, kv_b, o, lse, T, K, tpw);
+        f32x4* fr = (f32x4*)lib_scratch((size_t)B * CFFM_HEADS * gtm_frag_units(U) * 256);
+        REQUIRE(fr, "gtc_attn_fwd: scratch allocation failed");
+#define GTM_FWD(U_)                                                                                                                          \
+        do {                                                                                                                             \
+            CFFM_LAUNCH(k_gtc_pack_frags<U_>, (CFFM_HEADS, B, 2 * U_), (256), 0, st, kv_raw, kv_b, fr, K);                                       \
+            CFFM_LAUNCH(k_gtc_attn_fwd_mfma<U_>, (gx, CFFM_HEADS, B), (256), 0, st, q_raw, q_b, (const f32x4*)fr, o, lse, T, K, tpw);   \
+        } while (0)
+        if (U == 1) GTM_FWD(1); else if (U == 2) GTM_FWD(2); else if (U == 3) GTM_FWD(3); else GTM_FWD(4);
+#undef GTM_FWD
         CHECK_LAUNCH("gtc_attn_fwd");
         return 0;
     }
@@ -1242,10 +1247,12 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
         if (ppw < 1) ppw = 1;
         const unsigned g1 = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)), g2 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
         const size_t nD = ((size_t)B * T * CFFM_HEADS + 63) / 64 * 64;
-        float* scr = lib_scratch(nD + (size_t)B * CFFM_HEADS * g2 * K * 64);
+        const size_t nrecf = ((size_t)B * CFFM_HEADS * g2 * K * 64 + 63) / 64 * 64;
+        float* scr = lib_scratch(nD + nrecf + (size_t)B * CFFM_HEADS * gtm_frag_units(U) * 256);
         REQUIRE(scr, "gtc_attn_bwd: scratch allocation failed");
         float* Dbuf = scr;
         float* rec = scr + nD;
+        f32x4* fr = (f32x4*)(scr + nD + nrecf);
 #ifndef CFFM_EMU
         static bool granted_m = false;
         if (!granted_m) {
@@ -1256,10 +1263,12 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
 #endif
 #define GTM_BWD(U_)                                                                                                                                              \
         do {                                                                                                                                                 \
-            CFFM_LAUNCH(k_gtc_attn_bwd_dq_mfma<U_>, (g1, CFFM_HEADS, B), (256), (size_t)(4 * 32 * U_ * 64), st, q_raw, q_b, kv_raw, kv_b, o, dout, lse, dq_raw, Dbuf, T, K, tpw); \
-            CFFM_LAUNCH(k_gtc_attn_bwd_dkv_mfma<U_>, (g2, CFFM_HEADS, B), (256), (size_t)gtm_bwd_lds(U_), st, q_raw, q_b, kv_raw, kv_b, dout, lse, (const float*)Dbuf, rec, T, K, ppw); \
+            CFFM_LAUNCH(k_gtc_pack_frags<U_>, (CFFM_HEADS, B, 2 * U_), (256), 0, st, kv_raw, kv_b, fr, K);                                                           \
+            CFFM_LAUNCH(k_gtc_attn_bwd_dq_mfma<U_>, (g1, CFFM_HEADS, B), (256), (size_t)(8 * U_ * 1024), st, q_raw, q_b, (const f32x4*)fr, dout, lse, dq_raw, Dbuf, T, K, tpw); \
+            CFFM_LAUNCH(k_gtc_attn_bwd_dkv_mfma<U_>, (g2, CFFM_HEADS, B), (256), (size_t)gtm_bwd_lds(U_), st, q_raw, q_b, (const f32x4*)fr, dout, lse, (const float*)Dbuf, rec, T, K, ppw); \
         } while (0)
         if (U == 1) GTM_BWD(1); else if (U == 2) GTM_BWD(2); else if (U == 3) GTM_BWD(3); else GTM_BWD(4);
+        (void)o;
 #undef GTM_BWD
         CFFM_LAUNCH(k_gtc_dkv_sum, (K, CFFM_HEADS, B), (64), 0, st, (const float*)rec, (int)g2, K, dkv);
         CHECK_LAUNCH("gtc_attn_bwd");

@@ -101,63 +101,86 @@ __global__ void __launch_bounds__(256) k_gtc_attn_fwd(const float* __restrict__ 
     }
 }
 
+// The prototypes of a (clip, head) as MFMA fragments, made ONCE per call (k_gtc_pack_frags) instead of once per wave: every wave of the three
+// matrix-pipe kernels below needs the same 16-64 KB of bf16 hi / lo fragments of Kc / Vc, and building them in place -- scalar LDS reads of a
+// row-major copy, conversions, for the transposed forms one 2-byte read per element -- cost more than the products they feed (the forward
+// spent half of its 17.7 us at K = 100 there).  Layout per (clip, head), 16-byte words, unit = 64 lanes:
+//   KF  [KT tiles][hi | lo]      lane (l15, g): Kc[16 t + l15][8 g .. 8 g + 7]                      (A / B operand with keys as rows / columns)
+//   VF  [KT tiles][hi | lo]      the same of Vc
+//   KTF [2 mt][U][hi | lo]       lane (l15, g): Kc[key(u, g, j)][16 mt + l15], j = 0..7, key(u, g, j) = 32 u + 16 (j >> 2) + 4 g + (j & 3)
+//   VTF [2 mt][U][hi | lo]       the same of Vc                                                     (operands with channels as rows, k-slots = keys)
+// = 16 U units of 1 KiB per (clip, head): KF at unit 0, VF at 4 U, KTF at 8 U, VTF at 12 U.
+__host__ __device__ constexpr int gtm_frag_units(int U) { return 16 * U; }
+// grid (8 heads, B, 2 U): a workgroup makes four {hi, lo} unit pairs, a thread one lane of one pair, straight from kv_raw (8 loads)
+template <int U>
+__global__ void __launch_bounds__(256) k_gtc_pack_frags(const float* __restrict__ kv_raw, const float* __restrict__ bkv, f32x4* __restrict__ frags, int K) {
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, l15 = lane & 15, g = lane >> 4, pu = 4 * blockIdx.z + (tid >> 6);      // pair units: [0, 2U) KF, [2U, 4U) VF, [4U, 6U) KTF, [6U, 8U) VTF
+    const int grp = pu / (2 * U), idx = pu % (2 * U), vofs = (grp & 1) ? 256 : 0;
+    const float* base = kv_raw + (long)b * K * 512 + vofs + h * CFFM_HD;
+    const float* bias = bkv + vofs + h * CFFM_HD;
+    bf16x8 hi, lo;
+    if (grp < 2) {                       // row fragments: 8 consecutive channels of key 16 idx + l15
+        const int key = 16 * idx + l15;
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, c = a;
+        if (key < K) {
+            a = *(const f32x4*)(base + (long)key * 512 + 8 * g) + *(const f32x4*)(bias + 8 * g);
+            c = *(const f32x4*)(base + (long)key * 512 + 8 * g + 4) + *(const f32x4*)(bias + 8 * g + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = (bf16)a[j]; lo[j] = (bf16)(a[j] - (float)hi[j]);
+            hi[4 + j] = (bf16)c[j]; lo[4 + j] = (bf16)(c[j] - (float)hi[4 + j]);
+        }
+    } else {                             // transposed fragments: channel 16 mt + l15 of the 8 keys of k-slots (g, j)
+        const int mt = idx / U, u = idx % U, ch = 16 * mt + l15;
+        const float bv = bias[ch];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = 32 * u + 16 * (j >> 2) + 4 * g + (j & 3);
+            const float x = key < K ? base[(long)key * 512 + ch] + bv : 0.f;
+            hi[j] = (bf16)x;
+            lo[j] = (bf16)(x - (float)hi[j]);
+        }
+    }
+    f32x4* out = frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64;
+    out[(2 * pu) * 64 + lane] = __builtin_bit_cast(f32x4, hi);
+    out[(2 * pu + 1) * 64 + lane] = __builtin_bit_cast(f32x4, lo);
+}
+
 // Forward on the matrix pipe (round 5, third session; K <= 128).  49 * K * 32 MACs per token-head are little, but the VALU form spends them
 // at 16 broadcast LDS reads per key and wave (LDS-bound: 41-53 us at the reference's K = 100, cffm_head.py:217).  Here a WAVE owns 16 tokens
 // of one head at a time and the prototypes never leave its registers:
-//   S^T [keys x tokens] = Kc Q^T        A = Kc fragments (lane (key l15, channels 8 g ..)), built ONCE per wave; B = Q^T fragments straight
+//   S^T [keys x tokens] = Kc Q^T        A = Kc fragments (lane (key l15, channels 8 g ..)), loaded ONCE per wave; B = Q^T fragments straight
 //                                       from the lane's own q row (token l15, channels 8 g ..: two 16-byte loads);
 //   softmax over the keys of a token = over the 4 C registers x KT tiles of a lane, then two shuffles across the four lane groups;
-//   O^T [channels x tokens] = Vc^T P^T  A = Vc^T fragments (built once per wave from an LDS copy of the head's Vc rows), B = P^T from the C
+//   O^T [channels x tokens] = Vc^T P^T  A = Vc^T fragments (loaded once per wave), B = P^T from the C
 //                                       registers of two key tiles (k-slot (g, j) <-> key 32 u + 16 (j >> 2) + 4 g + (j & 3), the bijection
 //                                       of cfm_attn_kernels.h), so P never leaves the registers.
 // Every product is the three-pass bf16 hi / lo split of the Linear GEMMs (hi x lo + lo x hi + hi x hi, error ~2^-17): the block keeps its
 // 1e-4 tolerance -- no f16 operands here.  Keys are padded to 32 U (U = k-steps of the PV product, template parameter); padded keys carry
 // s = -inf.  grid (workgroups, 8 heads, B); a workgroup's four waves walk `tiles_per_wave` consecutive 16-token tiles each.
-#define GTM_LD 33           // floats per row of the Kc / Vc copies in LDS
-__host__ __device__ constexpr int gtm_lds(int U) { return 4 * (2 * 32 * U * GTM_LD); }
 template <int U>
-__global__ void __launch_bounds__(256) k_gtc_attn_fwd_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq,
-                                                            const float* __restrict__ kv_raw, const float* __restrict__ bkv,
+__global__ void __launch_bounds__(256) k_gtc_attn_fwd_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const f32x4* __restrict__ frags,
                                                             float* __restrict__ o, float* __restrict__ lse, int T, int K, int tiles_per_wave) {
-    constexpr int KT = 2 * U, KP = 32 * U;
-    CFFM_DYN_SMEM(smem);
-    float* Kc = (float*)smem;           // [KP][GTM_LD] (rows >= K zero)
-    float* Vc = Kc + KP * GTM_LD;
+    constexpr int KT = 2 * U;
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;
-    for (int e = tid; e < KP * CFFM_HD; e += 256) {
-        const int k = e >> 5, d = e & 31;
-        float kc = 0.f, vc = 0.f;
-        if (k < K) {
-            const float* row = kv_raw + ((long)b * K + k) * 512 + h * CFFM_HD + d;
-            kc = row[0] + bkv[h * CFFM_HD + d];
-            vc = row[256] + bkv[256 + h * CFFM_HD + d];
-        }
-        Kc[k * GTM_LD + d] = kc; Vc[k * GTM_LD + d] = vc;
-    }
-    __syncthreads();
-    // the wave's constant fragments
+    // the wave's constant fragments (k_gtc_pack_frags): 8 U coalesced 16-byte loads per lane
+    const f32x4* fr = frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64 + lane;
     bf16x8 kh[KT], kl[KT], vh[2][U], vl[2][U];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        const float* r = Kc + (16 * t + l15) * GTM_LD + 8 * g;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = r[e];
-            kh[t][e] = (bf16)x;
-            kl[t][e] = (bf16)(x - (float)kh[t][e]);
-        }
+        kh[t] = __builtin_bit_cast(bf16x8, fr[(2 * t) * 64]);
+        kl[t] = __builtin_bit_cast(bf16x8, fr[(2 * t + 1) * 64]);
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = Vc[(32 * u + 16 * (j >> 2) + 4 * g + (j & 3)) * GTM_LD + 16 * mt + l15];
-                vh[mt][u][j] = (bf16)x;
-                vl[mt][u][j] = (bf16)(x - (float)vh[mt][u][j]);
-            }
+        for (int u = 0; u < U; ++u) {
+            vh[mt][u] = __builtin_bit_cast(bf16x8, fr[(12 * U + 2 * (mt * U + u)) * 64]);
+            vl[mt][u] = __builtin_bit_cast(bf16x8, fr[(12 * U + 2 * (mt * U + u) + 1) * 64]);
+        }
     const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
     const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
     for (int it = 0; it < tiles_per_wave; ++it) {
@@ -388,7 +411,7 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd(const float* __restrict__ 
 }
 // Backward on the matrix pipe (K <= 128), two launches, every product the three-pass bf16 split of the forward:
 //   k_gtc_attn_bwd_dq_mfma   a wave per 16-token tile, keys x tokens orientation as in the forward: S^T = Kc Q^T, dP^T = Vc dO^T (A = row fragments of
-//                            the prototypes, read from bf16 hi / lo images in LDS; B = the lane's own q / dO rows), p = exp(s - lse),
+//                            the prototypes, read from an LDS copy of the packed fragments; B = the lane's own q / dO rows), p = exp(s - lse),
 //                            ds = p (dp - D); dQ^T = Kc^T dS with dS as the B operand straight from the C registers (the k-slot <-> key bijection of
 //                            the forward) and the Kc^T fragments in registers.  D = sum_keys p dp (= sum_ch dO o) comes out of the same products; it is left in
 //                            Dbuf [B*T][8] for the second launch.
@@ -398,27 +421,14 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd(const float* __restrict__ 
 //                            accumulators (2 x 32 channels x K keys) live in registers over its run of pairs; the four waves of a workgroup are added
 //                            through LDS in wave order and leave ONE record [K][64] (dKc | dVc) -- k_gtc_dkv_sum adds the records in order as before.
 // Deterministic, no atomics.  (The VALU kernel above stays for K > 128.)
-#define GTM_SWZ(row) ((0x78 >> (((row) >> 1) & 6)) & 3)                   // the row swizzle of cfm_attn_kernels.h (ATT_ROW): 64-byte rows, conflict-free fragment reads
-#define GTM_ROW(row, chunk) ((row) * 32 + 8 * ((chunk) ^ GTM_SWZ(row)))   // bf16 element offset of 16-byte chunk `chunk` of row `row`
 #define GTM_TLD 36                                                        // floats per row of the wave-private q / dO tiles
-__host__ __device__ constexpr int gtm_bwd_lds(int U) { return 4 * 32 * U * 64 + 4 * 2 * 32 * GTM_TLD * 4; }   // four bf16 images + 4 waves x (q | dO) tiles (the record tiles reuse those)
-// bf16 hi / lo images of the head's Kc / Vc rows ([32 U][32], rows >= K zero): img[0] KcH, [1] KcL, [2] VcH, [3] VcL
+__host__ __device__ constexpr int gtm_bwd_lds(int U) { return 8 * U * 1024 + 4 * 2 * 32 * GTM_TLD * 4; }   // the KF | VF units + 4 waves x (q | dO) tiles (the record tiles reuse those)
+// the row fragments KF | VF of the head (k_gtc_pack_frags units [0, 8 U)) copied into LDS: a wave then reads fragment (tile t, hi | lo) of Kc
+// at unit 2 t (+ 1), of Vc at 4 U + 2 t (+ 1), lane-linear 16-byte reads
 template <int U>
-__device__ __forceinline__ void gtm_build_images(bf16* img, const float* __restrict__ kv_raw, const float* __restrict__ bkv, int b, int h, int K, int tid) {
-    constexpr int KP = 32 * U;
-    for (int e = tid; e < KP * CFFM_HD; e += 256) {
-        const int k = e >> 5, d = e & 31;
-        float kc = 0.f, vc = 0.f;
-        if (k < K) {
-            const float* row = kv_raw + ((long)b * K + k) * 512 + h * CFFM_HD + d;
-            kc = row[0] + bkv[h * CFFM_HD + d];
-            vc = row[256] + bkv[256 + h * CFFM_HD + d];
-        }
-        const int o = GTM_ROW(k, d >> 3) + (d & 7);
-        const bf16 kh = (bf16)kc, vh = (bf16)vc;
-        img[o] = kh; img[KP * 32 + o] = (bf16)(kc - (float)kh);
-        img[2 * KP * 32 + o] = vh; img[3 * KP * 32 + o] = (bf16)(vc - (float)vh);
-    }
+__device__ __forceinline__ void gtm_copy_row_frags(f32x4* lds, const f32x4* __restrict__ fr, int tid) {
+#pragma unroll
+    for (int q = 0; q < 2 * U; ++q) lds[tid + 256 * q] = fr[tid + 256 * q];
 }
 __device__ __forceinline__ void gtm_split8(f32x4 a, f32x4 b, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -434,30 +444,26 @@ __device__ __forceinline__ f32x4 gtm_mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x
 }
 
 template <int U>
-__global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const float* __restrict__ kv_raw,
-                                                               const float* __restrict__ bkv, const float* __restrict__ o, const float* __restrict__ dout,
-                                                               const float* __restrict__ lse, float* __restrict__ dq_raw, float* __restrict__ Dbuf, int T, int K,
-                                                               int tiles_per_wave) {
-    constexpr int KT = 2 * U, KP = 32 * U;
+__global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const f32x4* __restrict__ frags,
+                                                               const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ dq_raw,
+                                                               float* __restrict__ Dbuf, int T, int K, int tiles_per_wave) {
+    constexpr int KT = 2 * U;
     CFFM_DYN_SMEM(smem);
-    bf16* img = (bf16*)smem;
+    f32x4* RF = (f32x4*)smem;            // KF | VF units
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;
-    gtm_build_images<U>(img, kv_raw, bkv, b, h, K, tid);
-    __syncthreads();
-    const bf16 *KH = img, *KL = img + KP * 32, *VH = img + 2 * KP * 32, *VL = img + 3 * KP * 32;
+    const f32x4* fr = frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64;
+    gtm_copy_row_frags<U>(RF, fr, tid);
     // Kc^T fragments: lane (channel 16 mt + l15, k-slot (g, j) <-> key 32 u + 16 (j >> 2) + 4 g + (j & 3))
     bf16x8 kth[2][U], ktl[2][U];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int key = 32 * u + 16 * (j >> 2) + 4 * g + (j & 3), ch = 16 * mt + l15, off = GTM_ROW(key, ch >> 3) + (ch & 7);
-                kth[mt][u][j] = KH[off];
-                ktl[mt][u][j] = KL[off];
-            }
+        for (int u = 0; u < U; ++u) {
+            kth[mt][u] = __builtin_bit_cast(bf16x8, fr[(8 * U + 2 * (mt * U + u)) * 64 + lane]);
+            ktl[mt][u] = __builtin_bit_cast(bf16x8, fr[(8 * U + 2 * (mt * U + u) + 1) * 64 + lane]);
+        }
+    __syncthreads();
     const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
@@ -485,9 +491,8 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __res
         float D = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const int ko = GTM_ROW(16 * kt + l15, g);
-            const f32x4 sv = gtm_mma3(*(const bf16x8*)(KH + ko), *(const bf16x8*)(KL + ko), qh, ql, z4);
-            dpv[kt] = gtm_mma3(*(const bf16x8*)(VH + ko), *(const bf16x8*)(VL + ko), gh, gl, z4);
+            const f32x4 sv = gtm_mma3(__builtin_bit_cast(bf16x8, RF[(2 * kt) * 64 + lane]), __builtin_bit_cast(bf16x8, RF[(2 * kt + 1) * 64 + lane]), qh, ql, z4);
+            dpv[kt] = gtm_mma3(__builtin_bit_cast(bf16x8, RF[(4 * U + 2 * kt) * 64 + lane]), __builtin_bit_cast(bf16x8, RF[(4 * U + 2 * kt + 1) * 64 + lane]), gh, gl, z4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = (live && 16 * kt + 4 * g + r < K) ? expf(sv[r] - ls) : 0.f;
@@ -520,18 +525,17 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __res
 
 // grid (records per (clip, head), 8, B), 256 threads; rec [B][8][gridDim.x][K][64]
 template <int U>
-__global__ void __launch_bounds__(256) k_gtc_attn_bwd_dkv_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const float* __restrict__ kv_raw,
-                                                                const float* __restrict__ bkv, const float* __restrict__ dout, const float* __restrict__ lse,
-                                                                const float* __restrict__ Dbuf, float* __restrict__ rec, int T, int K, int pairs_per_wave) {
-    constexpr int KT = 2 * U, KP = 32 * U;
+__global__ void __launch_bounds__(256) k_gtc_attn_bwd_dkv_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const f32x4* __restrict__ frags,
+                                                                const float* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ Dbuf,
+                                                                float* __restrict__ rec, int T, int K, int pairs_per_wave) {
+    constexpr int KT = 2 * U;
     CFFM_DYN_SMEM(smem);
-    bf16* img = (bf16*)smem;
-    float* tiles = (float*)(img + 4 * KP * 32);         // [4 waves][q tile 32 x GTM_TLD | dO tile 32 x GTM_TLD]; later the waves' record tiles
+    f32x4* RF = (f32x4*)smem;            // KF | VF units
+    float* tiles = (float*)(RF + 8 * U * 64);           // [4 waves][q tile 32 x GTM_TLD | dO tile 32 x GTM_TLD]; later the waves' record tiles
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;
-    gtm_build_images<U>(img, kv_raw, bkv, b, h, K, tid);
+    gtm_copy_row_frags<U>(RF, frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64, tid);
     __syncthreads();
-    const bf16 *KH = img, *KL = img + KP * 32, *VH = img + 2 * KP * 32, *VL = img + 3 * KP * 32;
     float* Tq = tiles + wave * (2 * 32 * GTM_TLD);
     float* Tg = Tq + 32 * GTM_TLD;
     const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
@@ -589,8 +593,8 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dkv_mfma(const float* __re
         }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const int ko = GTM_ROW(16 * kt + l15, g);
-            const bf16x8 kh = *(const bf16x8*)(KH + ko), kl = *(const bf16x8*)(KL + ko), vh = *(const bf16x8*)(VH + ko), vl = *(const bf16x8*)(VL + ko);
+            const bf16x8 kh = __builtin_bit_cast(bf16x8, RF[(2 * kt) * 64 + lane]), kl = __builtin_bit_cast(bf16x8, RF[(2 * kt + 1) * 64 + lane]);
+            const bf16x8 vh = __builtin_bit_cast(bf16x8, RF[(4 * U + 2 * kt) * 64 + lane]), vl = __builtin_bit_cast(bf16x8, RF[(4 * U + 2 * kt + 1) * 64 + lane]);
             const bool kok = 16 * kt + l15 < K;
             f32x4 pv[2], dsv[2];
 #pragma unroll
