@@ -9,6 +9,7 @@
 #   r05_head_step.txt              torch-profiler attribution of the whole-head step
 #   r05_gtc_step.json, r05_gtc_kernel_stats.csv, r05_gtc_fused_vs_unfused.txt   the CFFM++ prototype layer (BASELINE config 5)
 #   r05_dw_dma_bench.txt           the LDS-DMA weight-gradient kernel against the register-staged group
+#   r05_dw_stream_bench.txt        the streaming weight-gradient kernel (T-frag operands) against the register-staged group
 #   r05_gpu_suite.txt              tail of pytest -m gpu
 
 cd "$(dirname "$0")/.." && R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out/pmc
@@ -57,4 +58,5 @@ bash scripts/kstats.sh "" "." > gpurun_out/r05_stage_kernel_stats.txt 2>&1
 bash scripts/r02_head_profile.sh > gpurun_out/r05_head_step.txt 2>&1; head -12 gpurun_out/r05_head_step.txt
 bash scripts/r05_gtc.sh > gpurun_out/r05_gtc_all.txt 2>&1; grep -A3 "K=100" gpurun_out/r05_gtc_step.json | head -5
 python scripts/r05_dw_dma_bench.py > gpurun_out/r05_dw_dma_bench.txt 2>&1; tail -4 gpurun_out/r05_dw_dma_bench.txt
+python scripts/r05_dw_stream_bench.py > gpurun_out/r05_dw_stream_bench.txt 2>&1; tail -8 gpurun_out/r05_dw_stream_bench.txt
 timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -4 > gpurun_out/r05_gpu_suite.txt; cat gpurun_out/r05_gpu_suite.txt

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) k_gtc_attn_fwd_mfma(const float* __restri
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = expf(sv[kt][r] - m);     // (a padded key: exp(-inf) = 0; key 0 always exists, so m is finite)
+                const float pv = fast_exp2((sv[kt][r] - m) * 1.4426950408889634f);     // one v_exp_f32 (a padded key: 2^-inf = 0; key 0 always exists, so m is finite)
                 sv[kt][r] = pv;
                 l += pv;
             }
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __res
             dpv[kt] = gtm_mma3(__builtin_bit_cast(bf16x8, RF[(4 * U + 2 * kt) * 64 + lane]), __builtin_bit_cast(bf16x8, RF[(4 * U + 2 * kt + 1) * 64 + lane]), gh, gl, z4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = (live && 16 * kt + 4 * g + r < K) ? expf(sv[r] - ls) : 0.f;
+                const float pv = (live && 16 * kt + 4 * g + r < K) ? fast_exp2((sv[r] - ls) * 1.4426950408889634f) : 0.f;
                 ds[kt][r] = pv;
                 D += pv * dpv[kt][r];
             }
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dkv_mfma(const float* __re
                 const f32x4 dp = gtm_mma3(gh[x], gl[x], vh, vl, z4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = kok ? expf(sv[r] - ls[x][r]) : 0.f;
+                    const float p = kok ? fast_exp2((sv[r] - ls[x][r]) * 1.4426950408889634f) : 0.f;
                     pv[x][r] = p;
                     dsv[x][r] = p * (dp[r] - Dv[x][r]);
                 }
