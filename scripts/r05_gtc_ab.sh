@@ -11,6 +11,6 @@ from vss_cffm_amd import _lib
 _lib.LIB_PATH = os.path.abspath(os.environ['CFFM_LIB'])
 import bench
 j = bench.gtc_step(torch.device('cuda:0'), 2)
-print(os.environ['CFFM_LIB'], ' '.join('%s %.4f ms (dw %.1f, mlp %.1f / %.1f, gemm %.1f us)' % (k, j[k]['ms_per_step'], j[k]['stage_us_per_step']['gemm_dw_group'], j[k]['stage_us_per_step']['mlp_fwd_fused'], j[k]['stage_us_per_step']['mlp_bwd_fused'], j[k]['stage_us_per_step']['linear_gemm']) for k in ('K=8', 'K=100')))
+print(os.environ['CFFM_LIB'], ' '.join('%s %.4f ms (attn %.1f / %.1f, dw %.1f, mlp %.1f / %.1f, gemm %.1f us)' % (k, j[k]['ms_per_step'], j[k]['stage_us_per_step']['gtc_attn_fwd'], j[k]['stage_us_per_step']['gtc_attn_bwd'], j[k]['stage_us_per_step']['gemm_dw_group'], j[k]['stage_us_per_step']['mlp_fwd_fused'], j[k]['stage_us_per_step']['mlp_bwd_fused'], j[k]['stage_us_per_step']['linear_gemm']) for k in ('K=8', 'K=100')))
 PY
 done; done

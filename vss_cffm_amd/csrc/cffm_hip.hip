@@ -1197,6 +1197,16 @@ int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 
 // the prototype attention on the matrix pipe for K <= 128 (gtc_kernels.h).  CFFM_GTC_MFMA=0 (experiment builds): the VALU kernels for every K
 CFFM_SWITCH(gtc_mfma_sw, "CFFM_GTC_MFMA", 1)
+// workgroups the three matrix-pipe kernels aim for (a wave walks ceil(tiles / (4 x workgroups)) tiles)
+#ifndef GTM_WGS_FWD
+#define GTM_WGS_FWD 512
+#endif
+#ifndef GTM_WGS_DQ
+#define GTM_WGS_DQ 512
+#endif
+#ifndef GTM_WGS_DKV
+#define GTM_WGS_DKV 256
+#endif
 int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, float* o, float* lse,
                       int B, int T, int K, void* stream) {
     PROF(ST_GTC_FWD);
@@ -1211,7 +1221,7 @@ int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw,
     if (K <= 128 && gtc_mfma_sw()) {
         // the matrix-pipe form (three-pass bf16 split): ~512 workgroups of four waves, each wave a run of 16-token tiles
         const int tiles = (T + 15) / 16;
-        int tpw = (tiles * CFFM_HEADS * B + 4 * 512 - 1) / (4 * 512);
+        int tpw = (tiles * CFFM_HEADS * B + 4 * GTM_WGS_FWD - 1) / (4 * GTM_WGS_FWD);
         if (tpw < 1) tpw = 1;
         const unsigned gx = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
         const int U = (K + 31) / 32;
@@ -1220,8 +1230,8 @@ int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw,
         REQUIRE(fr, "gtc_attn_fwd: scratch allocation failed");
 #define GTM_FWD(U_)                                                                                                                          \
         do {                                                                                                                             \
-            CFFM_LAUNCH(k_gtc_pack_frags<U_>, (CFFM_HEADS, B, 2 * U_), (256), 0, st, kv_raw, kv_b, fr, K);                                       \
-            CFFM_LAUNCH(k_gtc_attn_fwd_mfma<U_>, (gx, CFFM_HEADS, B), (256), 0, st, q_raw, q_b, (const f32x4*)fr, o, lse, T, K, tpw);   \
+            if (U_ > 1) CFFM_LAUNCH(k_gtc_pack_frags<U_>, (CFFM_HEADS, B, 2 * U_), (256), 0, st, kv_raw, kv_b, fr, K);                   \
+            CFFM_LAUNCH(k_gtc_attn_fwd_mfma<U_>, (gx, CFFM_HEADS, B), (256), 0, st, q_raw, q_b, (const f32x4*)(U_ > 1 ? fr : nullptr), kv_raw, kv_b, o, lse, T, K, tpw);   \
         } while (0)
         if (U == 1) GTM_FWD(1); else if (U == 2) GTM_FWD(2); else if (U == 3) GTM_FWD(3); else GTM_FWD(4);
 #undef GTM_FWD
@@ -1242,7 +1252,7 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
     if (K <= 128 && gtc_mfma_sw()) {
         // the matrix-pipe form (gtc_kernels.h): dq per 16-token tile, then dKc / dVc per pair of tiles into one record per workgroup
         const int tiles = (T + 15) / 16, pairs = (T + 31) / 32, U = (K + 31) / 32;
-        int tpw = (tiles * CFFM_HEADS * B + 4 * 512 - 1) / (4 * 512), ppw = (pairs * CFFM_HEADS * B + 4 * 256 - 1) / (4 * 256);
+        int tpw = (tiles * CFFM_HEADS * B + 4 * GTM_WGS_DQ - 1) / (4 * GTM_WGS_DQ), ppw = (pairs * CFFM_HEADS * B + 4 * GTM_WGS_DKV - 1) / (4 * GTM_WGS_DKV);
         if (tpw < 1) tpw = 1;
         if (ppw < 1) ppw = 1;
         const unsigned g1 = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)), g2 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
@@ -1263,9 +1273,10 @@ int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw,
 #endif
 #define GTM_BWD(U_)                                                                                                                                              \
         do {                                                                                                                                                 \
-            CFFM_LAUNCH(k_gtc_pack_frags<U_>, (CFFM_HEADS, B, 2 * U_), (256), 0, st, kv_raw, kv_b, fr, K);                                                           \
-            CFFM_LAUNCH(k_gtc_attn_bwd_dq_mfma<U_>, (g1, CFFM_HEADS, B), (256), (size_t)(8 * U_ * 1024), st, q_raw, q_b, (const f32x4*)fr, dout, lse, dq_raw, Dbuf, T, K, tpw); \
-            CFFM_LAUNCH(k_gtc_attn_bwd_dkv_mfma<U_>, (g2, CFFM_HEADS, B), (256), (size_t)gtm_bwd_lds(U_), st, q_raw, q_b, (const f32x4*)fr, dout, lse, (const float*)Dbuf, rec, T, K, ppw); \
+            const f32x4* fq = U_ > 1 ? (const f32x4*)fr : nullptr;        /* U = 1: the kernels make their own copy (gtm_pack_local) */                        \
+            if (U_ > 1) CFFM_LAUNCH(k_gtc_pack_frags<U_>, (CFFM_HEADS, B, 2 * U_), (256), 0, st, kv_raw, kv_b, fr, K);                                       \
+            CFFM_LAUNCH(k_gtc_attn_bwd_dq_mfma<U_>, (g1, CFFM_HEADS, B), (256), (size_t)(8 * U_ * 1024), st, q_raw, q_b, fq, kv_raw, kv_b, dout, lse, dq_raw, Dbuf, T, K, tpw); \
+            CFFM_LAUNCH(k_gtc_attn_bwd_dkv_mfma<U_>, (g2, CFFM_HEADS, B), (256), (size_t)gtm_bwd_lds(U_), st, q_raw, q_b, fq, kv_raw, kv_b, dout, lse, (const float*)Dbuf, rec, T, K, ppw); \
         } while (0)
         if (U == 1) GTM_BWD(1); else if (U == 2) GTM_BWD(2); else if (U == 3) GTM_BWD(3); else GTM_BWD(4);
         (void)o;

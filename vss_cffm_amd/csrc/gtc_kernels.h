@@ -111,15 +111,14 @@ __global__ void __launch_bounds__(256) k_gtc_attn_fwd(const float* __restrict__ 
 //   VTF [2 mt][U][hi | lo]       the same of Vc                                                     (operands with channels as rows, k-slots = keys)
 // = 16 U units of 1 KiB per (clip, head): KF at unit 0, VF at 4 U, KTF at 8 U, VTF at 12 U.
 __host__ __device__ constexpr int gtm_frag_units(int U) { return 16 * U; }
-// grid (8 heads, B, 2 U): a workgroup makes four {hi, lo} unit pairs, a thread one lane of one pair, straight from kv_raw (8 loads)
+// lane `lane` of unit pair `pu` of (clip b, head h): pair units [0, 2U) KF, [2U, 4U) VF, [4U, 6U) KTF, [6U, 8U) VTF; straight from kv_raw (8 loads)
 template <int U>
-__global__ void __launch_bounds__(256) k_gtc_pack_frags(const float* __restrict__ kv_raw, const float* __restrict__ bkv, f32x4* __restrict__ frags, int K) {
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int lane = tid & 63, l15 = lane & 15, g = lane >> 4, pu = 4 * blockIdx.z + (tid >> 6);      // pair units: [0, 2U) KF, [2U, 4U) VF, [4U, 6U) KTF, [6U, 8U) VTF
+__device__ __forceinline__ void gtm_pack_item(const float* __restrict__ kv_raw, const float* __restrict__ bkv, int b, int h, int K, int pu, int lane,
+                                              bf16x8& hi, bf16x8& lo) {
+    const int l15 = lane & 15, g = lane >> 4;
     const int grp = pu / (2 * U), idx = pu % (2 * U), vofs = (grp & 1) ? 256 : 0;
     const float* base = kv_raw + (long)b * K * 512 + vofs + h * CFFM_HD;
     const float* bias = bkv + vofs + h * CFFM_HD;
-    bf16x8 hi, lo;
     if (grp < 2) {                       // row fragments: 8 consecutive channels of key 16 idx + l15
         const int key = 16 * idx + l15;
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, c = a;
@@ -143,10 +142,33 @@ __global__ void __launch_bounds__(256) k_gtc_pack_frags(const float* __restrict_
             lo[j] = (bf16)(x - (float)hi[j]);
         }
     }
+}
+// grid (8 heads, B, 2 U): a workgroup makes four {hi, lo} unit pairs, a thread one lane of one pair
+template <int U>
+__global__ void __launch_bounds__(256) k_gtc_pack_frags(const float* __restrict__ kv_raw, const float* __restrict__ bkv, f32x4* __restrict__ frags, int K) {
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, pu = 4 * blockIdx.z + (tid >> 6);
+    bf16x8 hi, lo;
+    gtm_pack_item<U>(kv_raw, bkv, b, h, K, pu, lane, hi, lo);
     f32x4* out = frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64;
     out[(2 * pu) * 64 + lane] = __builtin_bit_cast(f32x4, hi);
     out[(2 * pu + 1) * 64 + lane] = __builtin_bit_cast(f32x4, lo);
 }
+// The same inside a kernel, into LDS (frags == NULL): for U = 1 (K <= 32: 16 units, 4 items per thread) the workgroup makes its own copy --
+// two packing launches per step cost more there than they save (gtc_step at K = 8: 0.262 ms with fragments built in the kernels, 0.267-0.273
+// with the packing kernel); from U = 2 on the packing kernel wins (K = 100: 0.297-0.300 against 0.287-0.290).  Ends with a barrier.
+template <int U>
+__device__ __forceinline__ void gtm_pack_local(f32x4* lds, const float* __restrict__ kv_raw, const float* __restrict__ bkv, int b, int h, int K, int tid) {
+#pragma unroll
+    for (int q = 0; q < 2 * U; ++q) {
+        const int item = tid + 256 * q, pu = item >> 6, lane = item & 63;
+        bf16x8 hi, lo;
+        gtm_pack_item<U>(kv_raw, bkv, b, h, K, pu, lane, hi, lo);
+        lds[(2 * pu) * 64 + lane] = __builtin_bit_cast(f32x4, hi);
+        lds[(2 * pu + 1) * 64 + lane] = __builtin_bit_cast(f32x4, lo);
+    }
+    __syncthreads();
+}
+#define GTM_LOCAL_UNITS(U) ((U) == 1 ? 16 * 64 : 1)      // f32x4 words of the local copy (U = 1 only)
 
 // Forward on the matrix pipe (round 5, third session; K <= 128).  49 * K * 32 MACs per token-head are little, but the VALU form spends them
 // at 16 broadcast LDS reads per key and wave (LDS-bound: 41-53 us at the reference's K = 100, cffm_head.py:217).  Here a WAVE owns 16 tokens
@@ -162,12 +184,18 @@ __global__ void __launch_bounds__(256) k_gtc_pack_frags(const float* __restrict_
 // s = -inf.  grid (workgroups, 8 heads, B); a workgroup's four waves walk `tiles_per_wave` consecutive 16-token tiles each.
 template <int U>
 __global__ void __launch_bounds__(256) k_gtc_attn_fwd_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const f32x4* __restrict__ frags,
+                                                            const float* __restrict__ kv_raw, const float* __restrict__ bkv,
                                                             float* __restrict__ o, float* __restrict__ lse, int T, int K, int tiles_per_wave) {
     constexpr int KT = 2 * U;
+    __shared__ f32x4 sfr[GTM_LOCAL_UNITS(U)];
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;
-    // the wave's constant fragments (k_gtc_pack_frags): 8 U coalesced 16-byte loads per lane
+    // the wave's constant fragments (k_gtc_pack_frags, or the workgroup's own copy when frags == NULL): 8 U coalesced 16-byte loads per lane
     const f32x4* fr = frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64 + lane;
+    if (U == 1 && !frags) {
+        gtm_pack_local<U>(sfr, kv_raw, bkv, b, h, K, tid);
+        fr = sfr + lane;
+    }
     bf16x8 kh[KT], kl[KT], vh[2][U], vl[2][U];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -183,16 +211,26 @@ __global__ void __launch_bounds__(256) k_gtc_attn_fwd_mfma(const float* __restri
         }
     const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
     const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+    // the lane's q row of a tile (raw): requested a tile ahead, so that a wave's run of tiles does not pay one memory round trip per tile
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 n0 = z4, n1 = z4;
+    {
+        const int t = 16 * tile0 + l15;
+        if (t < T) {
+            const float* qp = q_raw + ((long)b * T + t) * CFFM_C + h * CFFM_HD + 8 * g;
+            n0 = *(const f32x4*)qp; n1 = *(const f32x4*)(qp + 4);
+        }
+    }
     for (int it = 0; it < tiles_per_wave; ++it) {
         const int t0 = 16 * (tile0 + it);
         if (t0 >= T) break;                              // (wave-uniform)
         const int t = t0 + l15;
         const bool live = t < T;
         const long row = (long)b * T + (live ? t : 0);
-        f32x4 q0 = (f32x4){0.f, 0.f, 0.f, 0.f}, q1 = q0;
-        if (live) {
-            q0 = (*(const f32x4*)(q_raw + row * CFFM_C + h * CFFM_HD + 8 * g) + bq0) * scale;
-            q1 = (*(const f32x4*)(q_raw + row * CFFM_C + h * CFFM_HD + 8 * g + 4) + bq1) * scale;
+        const f32x4 q0 = live ? (n0 + bq0) * scale : z4, q1 = live ? (n1 + bq1) * scale : z4;
+        if (it + 1 < tiles_per_wave && t + 16 < T) {
+            const float* qp = q_raw + (row + 16) * CFFM_C + h * CFFM_HD + 8 * g;
+            n0 = *(const f32x4*)qp; n1 = *(const f32x4*)(qp + 4);
         }
         bf16x8 qh, ql;
 #pragma unroll
@@ -445,14 +483,20 @@ __device__ __forceinline__ f32x4 gtm_mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x
 
 template <int U>
 __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const f32x4* __restrict__ frags,
+                                                               const float* __restrict__ kv_raw, const float* __restrict__ bkv,
                                                                const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ dq_raw,
                                                                float* __restrict__ Dbuf, int T, int K, int tiles_per_wave) {
     constexpr int KT = 2 * U;
     CFFM_DYN_SMEM(smem);
+    __shared__ f32x4 sfr[GTM_LOCAL_UNITS(U)];
     f32x4* RF = (f32x4*)smem;            // KF | VF units
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;
     const f32x4* fr = frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64;
+    if (U == 1 && !frags) {
+        gtm_pack_local<U>(sfr, kv_raw, bkv, b, h, K, tid);
+        fr = sfr;
+    }
     gtm_copy_row_frags<U>(RF, fr, tid);
     // Kc^T fragments: lane (channel 16 mt + l15, k-slot (g, j) <-> key 32 u + 16 (j >> 2) + 4 g + (j & 3))
     bf16x8 kth[2][U], ktl[2][U];
@@ -467,20 +511,27 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __res
     const f32x4 bq0 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g), bq1 = *(const f32x4*)(bq + h * CFFM_HD + 8 * g + 4);
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+    f32x4 nq0 = z4, nq1 = z4, ng0 = z4, ng1 = z4;
+    float nls = 0.f;
     for (int it = 0; it < tiles_per_wave; ++it) {
         const int t0 = 16 * (tile0 + it);
         if (t0 >= T) break;                              // (wave-uniform)
         const int t = t0 + l15;
         const bool live = t < T;
         const long row = (long)b * T + (live ? t : 0);
-        f32x4 q0 = z4, q1 = z4, g0 = z4, g1 = z4;
-        float ls = 0.f;
-        if (live) {
+        if (it == 0 && live) {                           // (later tiles: requested a tile ahead, below)
             const long base = row * CFFM_C + h * CFFM_HD + 8 * g;
-            q0 = (*(const f32x4*)(q_raw + base) + bq0) * scale;
-            q1 = (*(const f32x4*)(q_raw + base + 4) + bq1) * scale;
-            g0 = *(const f32x4*)(dout + base); g1 = *(const f32x4*)(dout + base + 4);
-            ls = lse[row * CFFM_HEADS + h];
+            nq0 = *(const f32x4*)(q_raw + base); nq1 = *(const f32x4*)(q_raw + base + 4);
+            ng0 = *(const f32x4*)(dout + base); ng1 = *(const f32x4*)(dout + base + 4);
+            nls = lse[row * CFFM_HEADS + h];
+        }
+        const f32x4 q0 = live ? (nq0 + bq0) * scale : z4, q1 = live ? (nq1 + bq1) * scale : z4, g0 = live ? ng0 : z4, g1 = live ? ng1 : z4;
+        const float ls = live ? nls : 0.f;
+        if (it + 1 < tiles_per_wave && t + 16 < T) {
+            const long base = (row + 16) * CFFM_C + h * CFFM_HD + 8 * g;
+            nq0 = *(const f32x4*)(q_raw + base); nq1 = *(const f32x4*)(q_raw + base + 4);
+            ng0 = *(const f32x4*)(dout + base); ng1 = *(const f32x4*)(dout + base + 4);
+            nls = lse[(row + 16) * CFFM_HEADS + h];
         }
         bf16x8 qh, ql, gh, gl;
         gtm_split8(q0, q1, qh, ql);
@@ -526,15 +577,24 @@ __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dq_mfma(const float* __res
 // grid (records per (clip, head), 8, B), 256 threads; rec [B][8][gridDim.x][K][64]
 template <int U>
 __global__ void __launch_bounds__(256) k_gtc_attn_bwd_dkv_mfma(const float* __restrict__ q_raw, const float* __restrict__ bq, const f32x4* __restrict__ frags,
+                                                                const float* __restrict__ kv_raw, const float* __restrict__ bkv,
                                                                 const float* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                 float* __restrict__ rec, int T, int K, int pairs_per_wave) {
     constexpr int KT = 2 * U;
     CFFM_DYN_SMEM(smem);
+    __shared__ f32x4 sfr[GTM_LOCAL_UNITS(U)];
     f32x4* RF = (f32x4*)smem;            // KF | VF units
     float* tiles = (float*)(RF + 8 * U * 64);           // [4 waves][q tile 32 x GTM_TLD | dO tile 32 x GTM_TLD]; later the waves' record tiles
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const float scale = 0.17677669529663687f;
-    gtm_copy_row_frags<U>(RF, frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64, tid);
+    {
+        const f32x4* fr = frags + (long)(b * CFFM_HEADS + h) * gtm_frag_units(U) * 64;
+        if (U == 1 && !frags) {
+            gtm_pack_local<U>(sfr, kv_raw, bkv, b, h, K, tid);
+            fr = sfr;
+        }
+        gtm_copy_row_frags<U>(RF, fr, tid);
+    }
     __syncthreads();
     float* Tq = tiles + wave * (2 * 32 * GTM_TLD);
     float* Tg = Tq + 32 * GTM_TLD;
