@@ -205,7 +205,9 @@ int cffm_residual_out(const float* x1, const float* oraw, const float* b2, float
 int cffm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
                        long nrows, void* stream);
 /* q_raw [B*T,256] = LN(x) Wq^T without bias, kv_raw [B*K,512] = LN(centers) Wkv^T without bias; softmax over the K
- * prototypes per (token, head); o [B*T,256]; lse [B*T,8] */
+ * prototypes per (token, head); o [B*T,256]; lse [B*T,8].  K <= 128: on the matrix pipe (three-pass bf16 split of every product: the
+ * 1e-4 tolerance of the fp32 form is kept), the head's Kc / Vc packed once per call as MFMA fragments; above: fp32 on the VALU.  The
+ * backward's `o` is not read by the matrix-pipe form (D = sum_keys p dp comes out of the same products as dp). */
 int cffm_gtc_attn_fwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, float* o, float* lse,
                       int B, int T, int K, void* stream);
 int cffm_gtc_attn_bwd(const float* q_raw, const float* q_b, const float* kv_raw, const float* kv_b, const float* o,

@@ -3,9 +3,9 @@
 // pvt/swin_transformer_2d.py:208-262 with only_use_cluster_center_as_context=True (:216): no in-window
 // keys, no position bias, no mask, so window partition / padding are numerically no-ops
 // (SURVEY.md A "GTC is window-independent") and the op is plain [token, head] x K attention.
-// HBM-bound (reads q, writes o once); 49*K*32 MACs per token-head is far below the MFMA ridge, so
-// this stays on the VALU: 8 lanes own one (token, head) (4 of the 32 dims each), the K centre
-// rows of the head sit in LDS, softmax is online.
+// Two forms: K <= 128 (the reference's default is 100) on the matrix pipe -- three-pass bf16 hi / lo products, so the block
+// keeps its 1e-4 tolerance: k_gtc_pack_frags + k_gtc_attn_fwd_mfma / _bwd_dq_mfma / _bwd_dkv_mfma below -- and, above that,
+// fp32 on the VALU: a lane owns a token, the K centre rows of the head sit in LDS, softmax is online (k_gtc_attn_fwd / _bwd).
 #pragma once
 #include "cffm_common.h"
 #include "gemm_kernels.h"      // mfma16x16x32_bf16, split4
