@@ -171,6 +171,42 @@ def attn_fwd_back_to_back(lib, dev, b, n=50):
     return 1e3 * e0.elapsed_time(e1) / n
 
 
+def dw_stream_alone(lib, dev, b, n=30):
+    """The block's four weight gradients (q|k|v, fc1, fc2, proj at b clips) by the streaming kernel on T-frag operands (csrc/dws_kernels.h), alone,
+    n launches between one pair of events -- the form the CFFM++ prototype block uses and cffm_dw_stream(1) selects for the base block (not its
+    default: DESIGN 3h) -- and the register-staged group the base block runs, measured the same way: us per call (launch + slab sum)."""
+    class WGrad(C.Structure):
+        _fields_ = [('dy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('M', C.c_long), ('N', C.c_int), ('K', C.c_int)]
+    lib.cffm_tfrag_floats.restype = C.c_long
+    nw_ = ((GRID + 6) // 7) ** 2       # 7 x 7 windows of the padded grid
+    nr, npx = b * 64 * nw_, b * GRID * GRID
+    shapes = [(nr, 768, 256), (npx, 1024, 256), (npx, 256, 1024), (npx, 256, 256)]
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    keep, pa, pb = [], [], []
+    for m, n_, k in shapes:
+        dy, x = torch.randn(m, n_, device=dev), torch.randn(m, k, device=dev)
+        dyt, xt = torch.empty(lib.cffm_tfrag_floats(m, n_), device=dev), torch.empty(lib.cffm_tfrag_floats(m, k), device=dev)
+        assert lib.cffm_tfrag_pack(P(dy), P(dyt), m, n_, st) == 0 and lib.cffm_tfrag_pack(P(x), P(xt), m, k, st) == 0
+        dw = torch.empty(n_, k, device=dev)
+        keep += [dy, x, dyt, xt, dw]
+        pa.append(WGrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), m, n_, k))
+        pb.append(WGrad(dyt.data_ptr(), xt.data_ptr(), dw.data_ptr(), m, n_, k))
+    pa, pb = (WGrad * 4)(*pa), (WGrad * 4)(*pb)
+    out = {}
+    for name, fn in (('register_staged', lambda: lib.cffm_linear_bwd_weight_group(pa, 4, st)), ('streaming', lambda: lib.cffm_linear_bwd_weight_tfrag_group(pb, 4, st))):
+        for _ in range(5):
+            assert fn() == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out[name] = 1e3 * e0.elapsed_time(e1) / n
+    return out
+
+
 def launch_ranks(n):
     """Re-run this script as n ranks through torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free
     port); rank 0's JSON line passes through on stdout.  Fails loudly when the box has fewer than n GPUs -- a silent N = 1
@@ -887,6 +923,17 @@ def main():
                                 if (use_graph and graph_events) else
                                 ('eager pass right after the timed graph replays' if use_graph else 'inside the timed region'))}
         rk = roofline_kernels(stages, b, nw, hw) if stages else None
+        if rk is not None and not multi:
+            try:     # the two forms of the block's weight gradients, each alone (information: the base step runs the register-staged one)
+                dwa = dw_stream_alone(lib, dev, b)
+                fl = rk['gemm_dw_group']['flops']
+                rk['gemm_dw_alone'] = {k_: {'us': round(v_, 1), 'achieved_tflops': round(fl / v_ / 1e6, 1), 'frac': round(fl / v_ / 1e6 / (MFMA_F16_PEAK_TF / 3.0), 4)}
+                                       for k_, v_ in dwa.items()}
+                rk['gemm_dw_alone']['note'] = ('the block\'s four weight gradients as one group, launch + slab sum, 30 calls between one pair of events: the register-staged '
+                                               'kernel the base block runs beside its chain, and the streaming kernel on T-frag operands (csrc/dws_kernels.h) the CFFM++ '
+                                               'prototype block runs; in the base step the streaming form is slower (DESIGN 3h)')
+            except Exception as e:   # noqa: BLE001  (information only)
+                sys.stderr.write('bench.py: weight-gradient stand-alone timing failed: %s\n' % e)
         hs = hs_all
         out = {
             'metric': 'clips/sec (fwd+bwd) CFFM-B1 480x480 T=4 hot path (CFFA+CFM, decoder_focal depth 2)',
