@@ -207,3 +207,44 @@ def test_dw_tfrag_emulated():
 def test_dw_tfrag_gpu():
     run_dw_tfrag_checks(_lib.get(), torch.device('cuda'), [(7, 64, 128), (100, 256, 128), (1000, 128, 128), (7201, 256, 256), (10368, 768, 256),
                                                            (7200, 1024, 256), (7200, 256, 1024), (7200, 256, 256)], group=(4, 5, 6, 7))
+
+
+def run_gtc_attn_stage_checks(lib, device, cases, tol=2e-5):
+    """cffm_gtc_attn_fwd / _bwd (WindowAttention_cluster, pvt/swin_transformer_2d.py:232-257, with only_use_cluster_center_as_context) as stages
+    against torch in fp64: every template instance of the matrix-pipe kernels (K <= 32, 64, 96, 128: one to four k-steps of 32 keys, keys
+    padded with -inf), the VALU form above 128, token counts that leave the last 16-token tile / the last pair of tiles / a wave's run ragged."""
+    gen = torch.Generator().manual_seed(31)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else None
+    for (B, T, K) in cases:
+        q_raw, kv_raw = torch.randn(B * T, 256, generator=gen), torch.randn(B * K, 512, generator=gen)
+        bq, bkv = torch.randn(256, generator=gen) * 0.3, torch.randn(512, generator=gen) * 0.3
+        dout = torch.randn(B * T, 256, generator=gen)
+        # reference
+        qd, kvd = q_raw.double().requires_grad_(True), kv_raw.double().requires_grad_(True)
+        q = ((qd + bq.double()) * 32 ** -0.5).view(B, T, 8, 32).permute(0, 2, 1, 3)
+        kv = (kvd + bkv.double()).view(B, K, 2, 8, 32).permute(2, 0, 3, 1, 4)
+        s = q @ kv[0].transpose(-1, -2)
+        o_ref = (s.softmax(-1) @ kv[1]).permute(0, 2, 1, 3).reshape(B * T, 256)
+        lse_ref = s.logsumexp(-1).permute(0, 2, 1).reshape(B * T, 8)
+        o_ref.backward(dout.double())
+        d = lambda t: t.to(device)
+        o, lse = torch.full((B * T, 256), float('nan'), device=device), torch.full((B * T, 8), float('nan'), device=device)
+        assert lib.cffm_gtc_attn_fwd(P(d(q_raw)), P(d(bq)), P(d(kv_raw)), P(d(bkv)), P(o), P(lse), B, T, K, stream) == 0, lib.cffm_last_error()
+        assert rel(o, o_ref.detach()) < tol and rel(lse, lse_ref.detach()) < tol, (B, T, K)
+        dq, dkv = torch.full((B * T, 256), float('nan'), device=device), torch.full((B * K, 512), float('nan'), device=device)
+        qr, kvr = d(q_raw), d(kv_raw)
+        assert lib.cffm_gtc_attn_bwd(P(qr), P(d(bq)), P(kvr), P(d(bkv)), P(o), P(d(dout)), P(lse), P(dq), P(dkv), B, T, K, stream) == 0, lib.cffm_last_error()
+        if K == 1:      # softmax over one key is the constant 1: nothing flows to q (exact zeros in the reference)
+            assert float(qd.grad.abs().max()) == 0.0 and float(dq.abs().max()) < 1e-5 and rel(dkv, kvd.grad) < tol, (B, T, K)
+        else:
+            assert rel(dq, qd.grad) < tol and rel(dkv, kvd.grad) < tol, (B, T, K, rel(dq, qd.grad), rel(dkv, kvd.grad))
+
+
+def test_gtc_attn_stages_emulated():
+    run_gtc_attn_stage_checks(emu.lib(), torch.device('cpu'), [(1, 35, 8), (2, 17, 33), (1, 70, 64), (1, 33, 65), (1, 16, 96), (1, 20, 128), (1, 40, 130), (1, 3, 1)])
+
+
+@pytest.mark.gpu
+def test_gtc_attn_stages_gpu():
+    run_gtc_attn_stage_checks(_lib.get(), torch.device('cuda'), [(1, 35, 8), (2, 17, 33), (2, 700, 64), (1, 333, 65), (2, 3600, 96), (1, 1000, 128), (1, 100, 130),
+                                                                 (2, 3600, 100), (1, 1, 1), (1, 15, 32)])
