@@ -307,6 +307,25 @@ def test_gtc_block_vs_oracle_odd_prototype_counts(b, h, w, k):
         run_gtc_vs_oracle(torch.device('cpu'), b, h, w, k)
 
 
+def run_gtc_ragged_panel_tail(device, h, w):
+    """Token counts T with 8192 < T <= 12288 run the q projection as 48-row panels (panel_mt == 3); when T mod 96 is in 33..48 the last panel
+    ends inside a 32-row k-step of the T-frag copies the streaming weight gradient contracts over, and the row groups behind it belong to
+    no panel: the last workgroup has to write them as zeros (round 5 left them uninitialised: a NaN / garbage attn.qkv.weight gradient).
+    The block's workspace is NaN-filled here so that any row group nobody wrote shows."""
+    from vss_cffm_amd import ops
+    assert 8192 < h * w <= 12288 and 33 <= (h * w) % 96 <= 48
+    ops._WS_FILL = float('nan')
+    try:
+        run_gtc_vs_oracle(device, 1, h, w, 2)
+    finally:
+        ops._WS_FILL = None
+
+
+def test_gtc_ragged_panel_tail_emulated():
+    with emu.active():
+        run_gtc_ragged_panel_tail(torch.device('cpu'), 76, 108)      # T = 8208
+
+
 def run_blockwise_backward_equals_whole(device, depth=3, h=8, w=9):
     """The layer backward walked block by block (what data-parallel training does: cffm_layer_backward_range per block, a hook after each)
     runs the CFFA reference pass once per RANGE, accumulating into dx of the reference frames; called whole it runs ONE pass over all

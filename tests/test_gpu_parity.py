@@ -374,6 +374,13 @@ def test_training_trajectory_against_oracle():
     assert drift < 0.02, drift
 
 
+@pytest.mark.parametrize('h,w', [(76, 108), (100, 108)])
+def test_gtc_ragged_panel_tail_gpu(h, w):
+    """T = 8208 / 10800 (48-row panels whose last one ends inside a k-step of the T-frag copies), workspace NaN-filled."""
+    from tests.test_emu_kernels import run_gtc_ragged_panel_tail
+    run_gtc_ragged_panel_tail(dev(), h, w)
+
+
 @pytest.mark.parametrize('b,h,w,k', [(1, 5, 7, 1), (2, 9, 9, 6), (1, 10, 13, 130), (2, 60, 60, 100)])
 def test_gtc_block_vs_oracle_odd_prototype_counts_gpu(b, h, w, k):
     """The fused CFFM++ block (cffm_gtc_block_forward / _backward) against the oracle: K = 1, K not a multiple of 4, K > 128 (32-token

@@ -224,7 +224,11 @@ __device__ __forceinline__ void pnl_tfrag_store(const bf16* __restrict__ hi, con
             f[e] = r0 + e < R ? a[e] : (bf16)0.f;
             f[4 + e] = r0 + 4 + e < R ? b[e] : (bf16)0.f;
         }
-        if (rgl < NRG && r0 < R32) dst[tfrag_unit(rg >> 2, jt0 + jt, h, CT) + 16 * (int)(rg & 3) + l15] = __builtin_bit_cast(f32x4, f);
+        // A 48-row panel (MT = 3) is one and a half k-steps: when the LAST panel ends inside a k-step (M mod 96 in 33..48) the row groups
+        // between its end and R32 belong to nobody, and the streaming kernel contracts over them ("rows >= R are zeros") -- the last
+        // workgroup writes them too (at most two groups: rgl 6, 7 of its second operation; r0 >= R there, so f is all zeros).
+        const bool tail = (NRG % 4 != 0) && rgl >= NRG && (long)m0 + 16 * MT >= R;
+        if ((rgl < NRG || tail) && r0 < R32) dst[tfrag_unit(rg >> 2, jt0 + jt, h, CT) + 16 * (int)(rg & 3) + l15] = __builtin_bit_cast(f32x4, f);
     }
 }
 

@@ -930,6 +930,23 @@ GTC_PARAM_KEYS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bia
                   'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias')
 
 
+# expected shapes of the 14 parameters (dim 256, mlp_ratio 4: the only CFFM++ prototype block the library is built for)
+GTC_PARAM_SHAPES = ((256,), (256,), (768, 256), (768,), (512, 256), (512,), (256, 256), (256,), (256,), (256,), (1024, 256), (1024,),
+                    (256, 1024), (256,))
+_WS_FILL = None      # tests only: fill value for the block's (otherwise uninitialised) workspace, e.g. NaN
+
+
+def _gtc_check_params(p, dev):
+    """The library takes raw pointers: a mis-ordered, non-fp32 or off-device parameter list would be out-of-bounds device accesses, so
+    it is refused here (the per-stage path of rounds 1-4 checked each tensor at its stage call)."""
+    if len(p) != len(GTC_PARAM_KEYS):
+        raise _lib.CffmError('gtc_block: %d parameters expected (GTC_PARAM_KEYS order), got %d' % (len(GTC_PARAM_KEYS), len(p)))
+    for key, shape, t in zip(GTC_PARAM_KEYS, GTC_PARAM_SHAPES, p):
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev:
+            raise _lib.CffmError('gtc_block: parameter %s must be float32 %s on %s, got %s %s on %s'
+                                 % (key, shape, dev, t.dtype, tuple(t.shape), t.device))
+
+
 def _gtc_ptrs(ts):
     """cffm_gtc_params / cffm_gtc_grads from 14 tensors in GTC_PARAM_KEYS order."""
     s = _lib.GtcPtrs()
@@ -950,6 +967,7 @@ class _GtcBlockFn(torch.autograd.Function):
         _require_device(x, 'gtc input')
         _require_device(centers, 'gtc centers')
         p = [t.detach().contiguous() for t in p]
+        _gtc_check_params(p, x.device)
         x, centers = x.contiguous(), centers.contiguous()
         b, t, c = x.shape
         k = centers.shape[1]
@@ -959,6 +977,8 @@ class _GtcBlockFn(torch.autograd.Function):
         if n <= 0:
             raise _lib.CffmError('gtc_block: bad sizes B=%d T=%d K=%d' % (b, t, k))
         ws = torch.empty(n, dtype=torch.float32, device=x.device)
+        if _WS_FILL is not None:
+            ws.fill_(_WS_FILL)
         out = torch.empty(b, t, c, dtype=torch.float32, device=x.device)
         ps = _gtc_ptrs(p)
         _lib.check(lib.cffm_gtc_block_forward(C.byref(ps), _ptr(x), _ptr(centers), _ptr(out), _ptr(ws), b, t, k, _stream(x)), lib)
@@ -970,6 +990,9 @@ class _GtcBlockFn(torch.autograd.Function):
         lib = _lib.get()
         x, centers, ws = ctx.saved_tensors[:3]
         p = list(ctx.saved_tensors[3:])
+        if dout.shape != x.shape or dout.dtype != torch.float32 or dout.device != x.device:
+            raise _lib.CffmError('gtc_block backward: float32 gradient of shape %s on %s expected, got %s %s on %s'
+                                 % (tuple(x.shape), x.device, dout.dtype, tuple(dout.shape), dout.device))
         dout = dout.contiguous()
         b, t, c = x.shape
         k = centers.shape[1]
