@@ -106,15 +106,15 @@ def test_every_gradient_element_is_written_and_the_padding_is_zeroed():
         run_nan_poisoned_backward(torch.device('cpu'))
 
 
-def run_depth3_against_oracle(device, b, h, w):
+def run_depth3_against_oracle(device, b, h, w, depth=3, seed=21):
     """Three blocks (the goldens stop at depth 2): every block ADDS its reference-frame gradients to what the later blocks wrote,
     the target-frame gradient ping-pongs between two buffers an odd number of times, and the pass-through frames' upstream
     gradient joins in the final layout pass.  Forward, dx of all four frames and every parameter gradient against the oracle under
-    torch autograd on the same seeded inputs."""
-    depth = 3
-    st = R.layer_state(depth, seed=21)
-    x = R.synth_input('x', (b, 4, 256, h, w), seed=22)
-    gy = R.synth_input('g', (b, 4, 256, h, w), seed=23, scale=1.0)
+    torch autograd on the same seeded inputs.  depth = 4 (CFFM-B5: local_configs/cffm/B5/cffm.b5.480x480.vspw2.160k.py:140) is the first
+    depth at which the reference-frame pass fills all RB_MAXD block slots and both scratch sets of the backward are used twice."""
+    st = R.layer_state(depth, seed=seed)
+    x = R.synth_input('x', (b, 4, 256, h, w), seed=seed + 1)
+    gy = R.synth_input('g', (b, 4, 256, h, w), seed=seed + 2, scale=1.0)
     xo = x.clone().requires_grad_(True)
     so = {k: v.clone().requires_grad_(True) for k, v in st.items()}
     yo = O.layer_forward(xo, so, depth)
@@ -143,6 +143,11 @@ def run_depth3_against_oracle(device, b, h, w):
 def test_depth3_layer_against_oracle_emulated():
     with emu.active():
         run_depth3_against_oracle(torch.device('cpu'), 1, 8, 10)
+
+
+def test_depth4_layer_against_oracle_emulated():
+    with emu.active():
+        run_depth3_against_oracle(torch.device('cpu'), 1, 8, 10, depth=4, seed=61)
 
 
 def test_stages_against_oracle_intermediates():

@@ -106,6 +106,50 @@ def test_depth3_layer_against_oracle():
     run_depth3_against_oracle(dev(), 2, 20, 27)
 
 
+def test_depth4_layer_against_oracle_eager_and_replayed():
+    """CFFM-B5's depth (local_configs/cffm/B5/cffm.b5.480x480.vspw2.160k.py:140: depths=4) at a ragged grid: against the oracle launched
+    eagerly, then the same forward + backward captured in a HIP graph and replayed -- dx and every gradient whose summation order does not
+    depend on the launch mode bit-identical to the eager run (four blocks: every RB_MAXD slot of the reference-frame pass, both scratch
+    sets of the backward used twice)."""
+    from tests.test_emu_kernels import run_depth3_against_oracle, flat_params
+    from vss_cffm_amd import ops
+    depth, b, h, w = 4, 2, 20, 27
+    run_depth3_against_oracle(dev(), b, h, w, depth=depth, seed=61)
+    st = R.layer_state(depth, seed=61)
+    params = [p.detach().to(dev()).requires_grad_(True) for p in flat_params(st, depth)]
+    xd = R.synth_input('x', (b, 4, 256, h, w), seed=62).to(dev()).requires_grad_(True)
+    gy = R.synth_input('g', (b, 4, 256, h, w), seed=63, scale=1.0).to(dev())
+
+    def body():
+        for p in params:
+            p.grad = None
+        xd.grad = None
+        y = ops.cffm_layer(xd, depth, params)
+        y.backward(gy)
+        return y
+
+    y_e = body().detach().clone()
+    ref = (xd.grad.clone(), [p.grad.clone() for p in params])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y_g = body()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_g.detach(), y_e) and torch.equal(xd.grad, ref[0])
+    for i, p in enumerate(params):
+        k = ops.BLOCK_PARAM_KEYS[i % ops.NPB][0]
+        if k.endswith('.weight') and p.dim() == 2 and 'pool' not in k:      # Linear weight gradients: other split of the contraction under capture
+            assert float((p.grad - ref[1][i]).abs().max()) <= 2e-6 * float(ref[1][i].abs().max()), (i, k)
+        else:
+            assert torch.equal(p.grad, ref[1][i]), (i, k)
+
+
 def test_nonsquare_vspw_test_shape_forward():
     """VSPW test frames give a 60x108 grid: nW=144, padding on one axis only."""
     depth, b, h, w = 2, 1, 60, 108
