@@ -144,14 +144,15 @@ def roofline_kernels(stages, b, nw, hw):
     return out
 
 
-def attn_fwd_back_to_back(lib, dev, b, n=50):
+def attn_fwd_back_to_back(lib, dev, b, n=50, grid=None):
     """k_cfm_attn_fwd alone, n launches between ONE pair of events (the two records around a single 14 us launch add ~4 us to its
     interval; rocprofv3's kernel-trace duration -- profiles/ -- is the figure this approaches): us per launch."""
     import numpy as np
     import vss_cffm_amd as V
     from vss_cffm_amd import ops
-    g = ops.make_geom(lib, b, GRID, GRID)
-    key_src, q_dst = ops.device_tables(GRID, GRID, dev)[:2]
+    grid = GRID if grid is None else grid
+    g = ops.make_geom(lib, b, grid, grid)
+    key_src, q_dst = ops.device_tables(grid, grid, dev)[:2]
     gen = torch.Generator().manual_seed(3)
     qkv = (torch.randn(b * g.RC, 768, generator=gen) * 0.5).half().to(dev)
     biasf = (torch.randn(8 * 4 * 10 * 512, generator=gen) * 0.5).half().to(dev)      # f16 bias fragments: BIASH_HALFS (cffm_common.h), tile pairs
@@ -406,9 +407,102 @@ def gtc_step(dev, b, ks=(8, 100), steps=20):
         e = {'ms_per_step': round(ms, 4), 'clips_per_s': round(b * 1e3 / ms, 1), 'eager_ms': round(eager_ms, 4),
              'graph_replay_ms': None if graph_ms is None else round(graph_ms, 4), 'attention_mflop_fwd': round(flops / 1e6, 1),
              'stage_us_per_step': kern}
+        # roofline of the prototype attention.  Forward: reads q (the q third of a [b*3600, 768] fp32 array: 1 KiB rows) and the
+        # packed prototypes, writes the fp32 output; backward (dq kernel + dKc/dVc kernel): reads q, dO twice, writes dq.  Against HBM on those
+        # bytes and against the three-pass split-bf16 MFMA peak (2500 / 3 TF) on QK^T + AV (x 2.5 for the backward's five products); the
+        # binding bound is min(MFMA peak, AI x 8 TB/s).  Stage times are HIP-event intervals (~2-3 us of record cost each: conservative).
+        np_b = b * GRID * GRID * 256 * 4.0
+        for nm, by_, fl_ in (('gtc_attn_fwd', 2 * np_b, flops), ('gtc_attn_bwd', 5 * np_b, 2.5 * flops)):
+            if kern.get(nm):
+                us_ = kern[nm]
+                bound = min(MFMA_F16_PEAK_TF / 3.0, fl_ / by_ * HBM_PEAK_GBS / 1e3)
+                e.setdefault('roofline', {})[nm] = {'us': us_, 'flops': int(fl_), 'bytes': int(by_), 'achieved_tflops': round(fl_ / us_ / 1e6, 1),
+                                                     'hbm_frac': round(by_ / (us_ * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'bound_tflops': round(bound, 1),
+                                                     'frac_of_bound': round(fl_ / us_ / 1e6 / bound, 4)}
         if note:
             e['graph_note'] = note
         out['K=%d' % k] = e
+    return out
+
+
+def cfg4_step(dev, b=2, grid=64, steps=20):
+    """BASELINE config 4 ("CFFM-B2 512x512 T=4, batch 2/GPU"): the B2 head has the same decoder_focal as B1 (C = 256, depth 2: SURVEY 3.4),
+    so the config differs from the headline in the GRID only -- 64 x 64 tokens, padded to 70 x 70: nW = 100, 1600 attention workgroups.
+    Forward + backward + AdamW (lr = 0: same kernels) of the layer on [b,4,256,64,64], median of `steps`, launched eagerly and replayed
+    from one HIP graph; the roofline kernel back to back at this size.  `cfg4_step` in the JSON line: a context number, not `value`."""
+    import vss_cffm_amd as V
+    from vss_cffm_amd import _lib
+    lib = _lib.get()
+    torch.manual_seed(0)
+    layer = V.BasicLayer3d3(dim=256, depth=DEPTH, num_heads=8, window_size=7, expand_size=3, pool_method='fc',
+                            focal_level=2, focal_window=5, focal_l_clips=[1, 2, 3], focal_kernel_clips=[7, 5, 3])
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if n.endswith('attn.qkv.weight'):
+                p.normal_(0, 0.08)
+            elif 'relative_position_bias_table' in n:
+                p.normal_(0, 0.5)
+    layer.to(dev)
+    groups = V.optim.paramwise_groups((('decode_head.decoder_focal.' + n, p) for n, p in layer.named_parameters()), base_lr=0.0, base_wd=0.01)
+    opt = V.optim.AdamW(groups, lr=0.0, betas=(0.9, 0.999), weight_decay=0.01)
+    gen = torch.Generator(device='cpu').manual_seed(77)
+    x = (torch.randn(b, T, 256, grid, grid, generator=gen) * 1.5).to(dev)
+    gy = torch.zeros(b, T, 256, grid, grid)
+    gy[:, -1] = torch.randn(b, 256, grid, grid, generator=gen) / (b * 256 * grid * grid)
+    gy = gy.to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        layer(x).backward(gy)
+        opt.step()
+
+    def timed(fn):
+        ts = []
+        for _ in range(steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+    for _ in range(20):
+        step()
+    eager_ms = timed(step)
+    graph_ms, note = None, None
+    try:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for _ in range(10):
+            g.replay()
+        graph_ms = timed(g.replay)
+    except Exception as ex:   # noqa: BLE001  (information only: the eager number stands)
+        note = 'graph capture failed: %s' % str(ex).splitlines()[0][:160]
+        torch.cuda.synchronize(dev)
+    ms = eager_ms if graph_ms is None else min(eager_ms, graph_ms)
+    nw, hw = ((grid + 6) // 7) ** 2, grid * grid
+    out = {'workload': 'CFFM-B2 512x512 T=4 hot path: [%d,4,256,%d,%d] fp32, depth 2, fwd+bwd+AdamW; nW = %d; median of %d steps' % (b, grid, grid, nw, steps),
+           'ms_per_step': round(ms, 4), 'clips_per_s': round(b * 1e3 / ms, 1), 'eager_ms': round(eager_ms, 4),
+           'graph_replay_ms': None if graph_ms is None else round(graph_ms, 4)}
+    if note:
+        out['graph_note'] = note
+    try:
+        us = attn_fwd_back_to_back(lib, dev, b, grid=grid)
+        by = algorithmic_bytes_attn_fwd(b, nw, hw)
+        out['attn_fwd'] = {'back_to_back_us': round(us, 2), 'workgroups': b * nw * 8, 'algorithmic_bytes_per_launch': by,
+                           'frac_back_to_back': round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                           'mfma_achieved_tflops': round(attn_flops(b, nw) / (us * 1e-6) / 1e12, 1)}
+    except Exception as e:   # noqa: BLE001
+        out['attn_fwd'] = {'error': str(e)[:160]}
     return out
 
 
@@ -427,6 +521,7 @@ def main():
     ap.add_argument('--spinup-steps', type=int, default=1000, help='untimed device spin-up steps before the warmup steps (~1 s)')
     ap.add_argument('--no-head-step', action='store_true', help='skip the whole-head training step reported as `head_step`')
     ap.add_argument('--no-gtc-step', action='store_true', help='skip the CFFM++ prototype-layer step (BASELINE config 5) reported as `gtc_step`')
+    ap.add_argument('--no-cfg4-step', action='store_true', help='skip the 512x512 (64 x 64 token grid) step (BASELINE config 4) reported as `cfg4_step`')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -873,6 +968,12 @@ def main():
             gs = gtc_step(dev, b)
         except Exception as e:   # noqa: BLE001  (context only: never costs the headline)
             gs = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
+    c4 = None
+    if rank == 0 and not args.no_cfg4_step:
+        try:
+            c4 = cfg4_step(dev)
+        except Exception as e:   # noqa: BLE001  (context only: never costs the headline)
+            c4 = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
     if rank == 0:
         nw, hw = ((GRID + 6) // 7) ** 2, GRID * GRID
         stages = {}
@@ -916,6 +1017,13 @@ def main():
                     # (f16 q/k/v in, fp32 output + LSE out: 11.6 MB per clip-block)
                     'mfma_bound_tflops': round(min(MFMA_F16_PEAK_TF, attn_flops(b, nw) / (11.6e6 * b) * HBM_PEAK_GBS / 1e3), 1),
                     'mfma_frac_of_bound': round(tf / min(MFMA_F16_PEAK_TF, attn_flops(b, nw) / (11.6e6 * b) * HBM_PEAK_GBS / 1e3), 4),
+                    # the same two figures on the back-to-back time (what rocprofv3 reports for the kernel), and the plain
+                    # statement that the north_star's ">= 30 % of MFMA peak on QK^T / AV" is NOT met: the kernel's arithmetic intensity on
+                    # the bytes it really moves caps it at bound_tflops (~0.32 of the 2.5 PF peak), and it reaches frac_of_bound of that
+                    'bound_tflops': round(min(MFMA_F16_PEAK_TF, attn_flops(b, nw) / (11.6e6 * b) * HBM_PEAK_GBS / 1e3), 1),
+                    'frac_of_bound': None if b2b_us is None else round(attn_flops(b, nw) / (b2b_us * 1e-6) / 1e12 / min(MFMA_F16_PEAK_TF, attn_flops(b, nw) / (11.6e6 * b) * HBM_PEAK_GBS / 1e3), 4),
+                    'mfma_frac_back_to_back': None if b2b_us is None else round(attn_flops(b, nw) / (b2b_us * 1e-6) / 1e12 / MFMA_F16_PEAK_TF, 5),
+                    'north_star_mfma_target': {'target_frac_of_peak': 0.30, 'met': False},
                     'note': ('achieved = SURVEY 8(d) algorithmic bytes (fp32 q/k/v + output: 18.37 MB per clip-block) / average '
                             'launch time = interval between two HIP events around the launch on its stream (%s); it includes the '
                             'cost of the records themselves: an event pair with nothing between measures event_pair_overhead_us the '
@@ -949,11 +1057,12 @@ def main():
             'config': {'workload': 'CFFM-B1 480x480 T=4: hot path on [B,4,256,60,60] fp32, depth 2, fwd+bwd+AdamW',
                        'clips_per_gpu': b, 'global_batch': world * b, 'parallelism': 'dp%d' % world, 'spinup_steps': args.spinup_steps, 'hip_graph': use_graph, 'hip_graph_calibration': graph_cal, 'ranks_in_sync': ranks_in_sync, 'params_finite': params_finite, 'hip_graph_note': graph_note if not use_graph else ('one graph per step' if not multi else (nonlocal_note[-1] if nonlocal_note else coll_info.get('form'))),
                        'grad_allreduce': ('RCCL (torch DDP)' if args.ddp else ('RCCL, one asynchronous all-reduce per block of the flat gradient buffer, overlapped with the backward of the next block' if coll_info.get('blockwise') else 'RCCL, ONE all-reduce of the flat gradient buffer (6.8 MB) behind the backward; CFFM_BENCH_EXCHANGE=blockwise selects the per-block overlapped form')) if multi else 'none'},
-            'roofline': roof, 'roofline_kernels': rk, 'head_step': hs, 'gtc_step': gs,
+            'roofline': roof, 'roofline_kernels': rk, 'head_step': hs, 'gtc_step': gs, 'cfg4_step': c4,
             'rccl': {'world': world, 'backend': (dist.get_backend() if multi else None)}, 'collective': collective,
-            'tolerance': {'forward': 5e-4, 'gradients': 2e-3, 'contract': 1e-3,
+            'tolerance': {'forward': 5e-4, 'gradients': 1.5e-3, 'contract': 1e-3,
                           'note': 'max|a-b|/max|b| vs the reference (tests/test_gpu_parity.py): forward measured 1.3-1.6e-4; gradients '
-                                  'measured <= 1.1e-3 (f16 operands of dS/dP in the attention backward), gated at 2e-3'},
+                                  'measured <= 1.1e-3 (f16 operands of dS/dP in the attention backward), gated at 1.5e-3 -- looser than the contract\'s 1e-3, which is worded on outputs; '
+                                  'justified by the 30-step training-trajectory test against the oracle (DESIGN 3g)'},
             'kernels': stages,
             'kernels_note': 'per-stage HIP-event times from a separate instrumented pass of %d steps after the timed region '
                             '(event records on every launch slow the step by ~25 %%, so they are kept out of `value`)' % bsteps,

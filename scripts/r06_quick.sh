@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.." && R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
 T=${1:-quick}; shift
 SEL=${@:-tests/test_attn_bwd.py tests/test_gpu_parity.py}
 timeout 1500 python -m pytest $SEL -x -q -m gpu -s 2>&1 | grep -v "^$" | tail -30 > gpurun_out/r06_${T}_tests.txt; tail -12 gpurun_out/r06_${T}_tests.txt
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-head-step > gpurun_out/r06_${T}_bench.json 2> gpurun_out/r06_${T}_bench.err; tail -2 gpurun_out/r06_${T}_bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-head-step --no-cfg4-step > gpurun_out/r06_${T}_bench.json 2> gpurun_out/r06_${T}_bench.err; tail -2 gpurun_out/r06_${T}_bench.err
 python - "$T" <<'PY'
 import json, sys
 T = sys.argv[1]

@@ -3,7 +3,7 @@
 # (which kernels overlap, where the gaps are).  usage: scripts/r06_trace.sh <tag> [extra bench args]
 cd "$(dirname "$0")/.." && R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
 TAG=${1:-x}; shift
-(cd /tmp && rm -rf /tmp/bp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp -o x -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-head-step --no-gtc-step --no-stage-timing --spinup-steps 50 "$@" > $R/gpurun_out/r06_trace_$TAG.json 2>/dev/null)
+(cd /tmp && rm -rf /tmp/bp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp -o x -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-head-step --no-cfg4-step --no-gtc-step --no-stage-timing --spinup-steps 50 "$@" > $R/gpurun_out/r06_trace_$TAG.json 2>/dev/null)
 cp $(find /tmp/bp -name '*kernel_stats.csv' | head -1) gpurun_out/r06_kernel_stats_$TAG.csv
 python - $TAG <<'PY'
 import csv, sys, glob, json

@@ -80,7 +80,7 @@ def test_bench_single_rank_over_rccl_takes_the_one_graph_form(exchange):
     per-block overlapped form (CFFM_BENCH_EXCHANGE=blockwise)."""
     env = dict(os.environ, PYTHONPATH=ROOT, CFFM_BENCH_FORCE_DIST='1', CFFM_BENCH_EXCHANGE=exchange)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--spinup-steps', '10',
-                        '--no-cpu-baseline', '--no-head-step', '--no-gtc-step'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--no-head-step', '--no-gtc-step', '--no-cfg4-step'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -259,6 +259,23 @@ def _worker_blockwise_preexisting(rank, world, port, out):
         finally:
             red.remove()
         torch.save({k: p.grad.clone() for k, p in acc_in.items()}, os.path.join(out, 'pgrad_acc%d.pt' % rank))
+        # (d) ADVICE r5: ONE reducer serving TWO layers in one backward.  The layer that runs its backward first has its slices adopted
+        #     as .grad when its autograd node returns; the other layer's first block must not take those for "gradients already there"
+        #     (it looks at its own parameters only: ops.current_backward_params) -- every block of both layers is exchanged overlapped,
+        #     no fallback.
+        m2 = _layer()
+        V.distributed.broadcast_parameters(m2, 0)
+        for p in list(m.parameters()) + list(m2.parameters()):
+            p.grad = None
+        red = V.distributed.BlockwiseReducer().install(list(m.parameters()) + list(m2.parameters()))
+        try:
+            ((m(x)[:, -1] * g).sum() + (m2(x2)[:, -1] * g2).sum()).backward()
+            n_blocks = len(red.log)
+            assert not red.accumulating and len(red.pending) == n_blocks and n_blocks == len(m.blocks) + len(m2.blocks)
+            assert red.finish() == n_blocks and red.fallbacks == 0
+        finally:
+            red.remove()
+        torch.save({k: p.grad.clone() for k, p in m2.named_parameters()}, os.path.join(out, 'pgrad_two%d.pt' % rank))
     torch.save(mine, os.path.join(out, 'pgrad%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -308,6 +325,11 @@ def test_blockwise_reducer_with_preexisting_grads_gloo(tmp_path):
         assert torch.equal(a0[k], a1[k]), k
         want = (per_rank[0][k] + per_rank[1][k] + second[0][k] + second[1][k]) / world
         assert H.rel_err(a0[k], want) < 1e-5, k
+    # (d) the second layer of a two-layer backward under one reducer: the ranks' mean of its own gradients (same weights, clip r + 7)
+    t0, t1 = (torch.load(os.path.join(str(tmp_path), 'pgrad_two%d.pt' % r)) for r in range(world))
+    for k in t0:
+        assert torch.equal(t0[k], t1[k]), k
+        assert H.rel_err(t0[k], (second[0][k] + second[1][k]) / world) < 1e-5, k
 
 
 def _bn_case(rank_or_all, world):

@@ -63,7 +63,10 @@ class PhotoMetricDistortionClips:
     (mmcv.bgr2hsv / hsv2bgr = ``cv2.cvtColor``), restated from OpenCV's published source because neither mmcv nor cv2 exists in the
     boxes this was built and tested in: those two steps are checked against ``oracle/cv_oracle.py`` only (parity unpinned).
     ``on_hsv``: ``'apply'`` (default); ``'skip'`` leaves the two HSV steps out silently, ``'warn'`` with one RuntimeWarning per instance,
-    ``'raise'`` refuses a clip that draws them (for runs that accept nothing unpinned).  ``draw()`` returns every decision in all modes."""
+    ``'raise'`` refuses a clip that draws them (for runs that accept nothing unpinned).  ``draw()`` returns every decision in all modes.
+    (The default was ``'warn'`` -- steps left out -- until round 5: callers of the older package now get the two HSV steps applied.
+    TODO(pin): run ``tests/test_data_cv.py::test_oracle_against_cv2_where_it_exists`` on a box that has cv2; SIMD / IPP builds of
+    OpenCV may differ from the published scalar arithmetic in the last bit -- INTEGRATION.md section 1 says the same.)"""
 
     def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, on_hsv='apply',
                  np_random=np.random):

@@ -143,9 +143,15 @@ class BlockwiseReducer:
         # may still be mid all-reduce, so their exchange is completed here, before autograd adds into that memory (the
         # detection used to be keyed to `not self.pending` and skipped exactly this case).  Averaged-then-accumulated gradients stay
         # correct under finish()'s second average: avg_r(avg(g1) + g2_r) = avg(g1) + avg(g2).
+        # "Already there" is asked of the parameters of the layer whose backward is starting (ops.current_backward_params) -- with one
+        # reducer serving two CFFM layers the second layer's first block otherwise saw the gradients the FIRST layer's backward had just
+        # adopted and fell back to the non-overlapped exchange on every step; direct callers of start() fall back to every
+        # installed parameter.
         first = (block == depth - 1) if depth else (not self.pending)
         if self.params is not None and first and not self.accumulating:
-            self.accumulating = any(p.grad is not None for p in self.params)
+            from . import ops
+            scope = ops.current_backward_params if ops.current_backward_params is not None else self.params
+            self.accumulating = any(p.grad is not None for p in scope)
             if self.accumulating and self.pending:
                 self._drain()
         if self.accumulating:

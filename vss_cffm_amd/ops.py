@@ -140,6 +140,10 @@ def block_ws_layout(lib, g):
 # Optional callable(block_index, flat_gradient_slice, depth), invoked by the layer's backward right after block `block_index`'s
 # kernels have been enqueued on the current stream (blocks come last-to-first).  None: the whole backward is one library call.
 block_grad_hook = None
+# While a layer's backward hands its blocks to the hook: the parameter tensors of THAT layer (26 * depth, block-major).  A hook that
+# serves several layers (one BlockwiseReducer for two CFFM layers) looks here to tell "this layer's .grad tensors exist already"
+# (gradient accumulation: nothing may be exchanged block by block) from "another layer's backward has just adopted its gradients".
+current_backward_params = None
 
 
 class _LayerFn(torch.autograd.Function):
@@ -210,11 +214,16 @@ class _LayerFn(torch.autograd.Function):
             # flat gradient buffer is handed to the hook -- data-parallel training starts that block's all-reduce there,
             # overlapping it with the backward of the blocks still to come (vss_cffm_amd.distributed.BlockwiseReducer)
             per = sum(sizes[:NPB])
-            for i in range(depth - 1, -1, -1):
-                _checked_padded(lib, lib.cffm_layer_backward_range, C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx),
-                                                         _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved),
-                                                         _ptr(ctx.scratch), i, i, _stream(dy))
-                hook(i, flat[i * per:(i + 1) * per], depth)
+            global current_backward_params
+            current_backward_params = params
+            try:
+                for i in range(depth - 1, -1, -1):
+                    _checked_padded(lib, lib.cffm_layer_backward_range, C.byref(g), depth, pstructs, gstructs, _ptr(dy), dy_bs, _ptr(dx),
+                                                             _ptr(key_src), _ptr(q_dst), _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved),
+                                                             _ptr(ctx.scratch), i, i, _stream(dy))
+                    hook(i, flat[i * per:(i + 1) * per], depth)
+            finally:
+                current_backward_params = None
         return (dx, None) + tuple(grads)
 
 
@@ -318,12 +327,17 @@ class _LayerFullFn(torch.autograd.Function):
         pstructs, gstructs = block_structs(params, depth), block_structs(grads, depth)
         hook = block_grad_hook
         per = sum(sizes[:NPB])
-        for first, last in ([(depth - 1, 0)] if hook is None else [(i, i) for i in range(depth - 1, -1, -1)]):
-            _checked_padded(lib, lib.cffm_layer_backward_full, C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst),
-                                                    _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch), first, last,
-                                                    _stream(dy))
-            if hook is not None:
-                hook(first, flat[first * per:(first + 1) * per], depth)
+        global current_backward_params
+        current_backward_params = params
+        try:
+            for first, last in ([(depth - 1, 0)] if hook is None else [(i, i) for i in range(depth - 1, -1, -1)]):
+                _checked_padded(lib, lib.cffm_layer_backward_full, C.byref(g), depth, pstructs, gstructs, _ptr(dy), _ptr(dx), _ptr(key_src), _ptr(q_dst),
+                                                        _ptr(inv_ptr), _ptr(inv_idx), _ptr(saved), _ptr(ctx.scratch), first, last,
+                                                        _stream(dy))
+                if hook is not None:
+                    hook(first, flat[first * per:(first + 1) * per], depth)
+        finally:
+            current_backward_params = None
         return (dx, None) + tuple(grads)
 
 
