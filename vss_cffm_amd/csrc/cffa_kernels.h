@@ -323,9 +323,6 @@ __global__ void __launch_bounds__(LNP_THREADS, 6) k_ln_pool_fwd(Geo G, const flo
 #endif
 #define LNB_THREADS (64 * LNB_WAVES)
 #define LNB_PIX ((CFFM_WA + LNB_SPLIT * LNB_WAVES - 1) / (LNB_SPLIT * LNB_WAVES))
-#ifndef LNPB_ABLATE
-#define LNPB_ABLATE 0   // profiling builds only: 1 no dM reductions, 2 no LN reductions, 4 no dx stores
-#endif
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
@@ -384,25 +381,15 @@ __global__ void __launch_bounds__(LNB_THREADS) k_ln_pool_bwd_tgt(Geo G, const fl
         const f32x4 xh = (xr[k] - mur[k]) * rs;
         const f32x4 z = xh * gm + bt;
         const f32x4 dz = dzr[k] + m0[k] * dp;
-#if !(LNPB_ABLATE & 1)
         const float dm = wave_sum_hi(dot4(dp, z));
         if (lane == 63) sdM[i] = dm;                    // pixel i belongs to exactly one wave of one workgroup
-#endif
         ag += dz * xh;
         ab += dz;
         const f32x4 gz = dz * gm;
-#if LNPB_ABLATE & 2
-        const float m1 = gz[0], m2 = gz[1];
-#else
         const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
         const float m2 = wave_sum(dot4(gz, xh)) * (1.f / CFFM_C);
-#endif
         const f32x4 dx = (gz - m1 - xh * m2) * rs + addr[k];
-#if LNPB_ABLATE & 4
-        ag += dx;
-#else
         *(f32x4*)(dxf + pix * CFFM_C + 4 * lane) = dx;
-#endif
     }
     *(f32x4*)(&red[wave][0][4 * lane]) = ag;
     *(f32x4*)(&red[wave][1][4 * lane]) = ab;
@@ -493,27 +480,17 @@ __device__ __forceinline__ void ln_pool_bwd_ref_frame(const Geo& G, const RefRow
                     const int c = d * 14 + g0 - 1 + u * NCD + v;
                     const f32x4 dp = *(const f32x4*)(sP + c * CFFM_C + 4 * lane);
                     dz += sMm[c * CFFM_WA + i] * dp;
-#if !(LNPB_ABLATE & 1)
                     const float dm = wave_sum_hi(dot4(dp, z));
                     if (lane == 63) sdM[c * CFFM_WA + i] = dm;
-#endif
                 }
             ag[d] += dz * xh;
             ab[d] += dz;
             gz += dz * gm[d];
         }
-#if LNPB_ABLATE & 2
-        const float m1 = gz[0], m2 = gz[1];
-#else
         const float m1 = wave_sum(gz[0] + gz[1] + gz[2] + gz[3]) * (1.f / CFFM_C);
         const float m2 = wave_sum(dot4(gz, xh)) * (1.f / CFFM_C);
-#endif
         const f32x4 dx = (gz - m1 - xh * m2) * rs + R.add[k];
-#if LNPB_ABLATE & 4
-        ag[0] += dx;
-#else
         *(f32x4*)(dxf + pix * CFFM_C + 4 * lane) = dx;
-#endif
     }
 }
 

@@ -7,18 +7,6 @@
 #endif
 #include <stdint.h>
 
-// ---- profiling / rejected-variant switches -------------------------------------------------------------------------------------
-// The kernels carry compile-time hooks of measurements recorded in DESIGN.md (ablations: *_ABLATE, in-kernel cycle stamps:
-// *_TIMING, rejected forms: FWD_DMA, VFLAG_RD, the persistent attention forward, the wave-specialised fused Mlp kernels).  They
-// exist only in -DCFFM_EXPERIMENTS builds (scripts/): build_native.sh does not define it, and without it every switch is pinned to
-// "off" here, so libcffm_hip.so contains exactly the kernels bench.py runs.
-#ifndef CFFM_EXPERIMENTS
-#if defined(GEMM_ABLATE) || defined(FWD_ABLATE) || defined(BWD_ABLATE) || defined(LNPB_ABLATE) || defined(PNL_ABLATE) || defined(FWD_DMA) || \
-    defined(VFLAG_RD) || defined(FWD_TIMING) || defined(BWD_TIMING) || defined(UPCE_ABLATE)
-#error "profiling switches need -DCFFM_EXPERIMENTS"
-#endif
-#endif
-
 // Tuning switches (launch shapes, stream forks, rejected forms kept for A/B runs) are read from the environment only in
 // -DCFFM_EXPERIMENTS builds (scripts/): the product library is built without it, and there every switch IS its default -- what
 // bench.py and the -m gpu tests run is the only configuration libcffm_hip.so has.  (The one exception is documented where it is read:
@@ -216,13 +204,7 @@ __device__ __forceinline__ f32x4 split4_pack(f32x4 x) {
     const f32x2_t a = __builtin_bit_cast(f32x2_t, h), b = __builtin_bit_cast(f32x2_t, l);
     return (f32x4){a[0], a[1], b[0], b[1]};
 }
-#ifndef GEMM_ABLATE
-#define GEMM_ABLATE 0
-#endif
 __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
-#if GEMM_ABLATE & 16
-    { unsplit4(x, hi, lo); return; }
-#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         hi[e] = (bf16)x[e];

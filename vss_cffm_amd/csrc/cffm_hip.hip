@@ -930,12 +930,6 @@ int cffm_attn_bwd(const cffm_geom* g, const void* qkv16, const int* key_src, con
     return 0;
 }
 
-#ifdef BWD_TIMING
-extern "C" int cffm_debug_bwd_stamps(long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwd_t), sizeof(long long) * 256) == hipSuccess ? 0 : -1; }
-#endif
-#ifdef FWD_TIMING
-extern "C" int cffm_debug_fwd_stamps(long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fwd_t), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : -1; }
-#endif
 int cffm_linear_fwd(const float* x, const float* w, float* y, long M, int N, int K, void* stream) {
     PROF(ST_GEMM);
     return gemm_nt(x, w, y, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_fwd: gemm failed") : 0;

@@ -41,20 +41,7 @@
 #define ATT_ROW(row, chunk) ((row) * ATT_KS_STRIDE + 8 * ((chunk) ^ ATT_SWZ(row)))
 
 // the 4 key-validity flags (0 / -inf) of this lane's keys 16t + 4g .. +3
-#ifndef VFLAG_RD
-#define VFLAG_RD 0
-#endif
-__device__ __forceinline__ f32x4 vflag4(const float* vflag, int o) {
-#if VFLAG_RD == 1
-    return (f32x4){vflag[o], vflag[o + 1], vflag[o + 2], vflag[o + 3]};
-#elif VFLAG_RD == 2
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 a = *(const f32x2*)(vflag + o), b = *(const f32x2*)(vflag + o + 2);
-    return (f32x4){a[0], a[1], b[0], b[1]};
-#else
-    return *(const f32x4*)(vflag + o);
-#endif
-}
+__device__ __forceinline__ f32x4 vflag4(const float* vflag, int o) { return *(const f32x4*)(vflag + o); }
 #define CFFM_FIRST_POOLED_KEY 181   // keys 0..180 = own window + ring: always present; 181.. = pooled cells (may fall off the grid)
 #define ATT_FWD_LDS (2 * CFFM_NKEY_PAD * ATT_KS_STRIDE * sizeof(f16) + CFFM_NKEY_PAD * 4)
 // MFMA A-operand fragment of the TRANSPOSED view of a row image `img` (ATT_ROW layout): A[i = column c0 + (lane & 15)]
@@ -186,21 +173,10 @@ __device__ __forceinline__ void stage_kv(buf_t rs_qkv, uint32_t soff_k, const in
 }
 
 // grid: B*nW*8 workgroups (head fastest), 256 threads
-#ifndef FWD_DMA
-#define FWD_DMA 0   // 1: stage K / V by LDS-DMA (buffer_load ... lds) instead of through registers: measured 15.0 vs 14.5 us -- the
-#endif              //    staging is bound by the L2 -> CU burst of all resident workgroups (scripts/r02_fwd_timing.py), not by the ds_write pass
-#ifndef FWD_ABLATE
-#define FWD_ABLATE 0   // profiling builds only (scripts/r02_fwd_ablate.sh): 1 no bias loads, 2 no K/V row gathers, 8 no exp
-#endif
-#ifdef FWD_TIMING   // profiling builds only: shader-clock stamps of wave 0 of a few workgroups (scripts/r02_fwd_timing.py)
-__device__ long long g_fwd_t[64 * 8];
-#define FWD_STAMP(i) do { if ((tid & 63) == 0 && wave == 0 && (blockIdx.x % 24) == 0 && blockIdx.x / 24 < 64) g_fwd_t[(blockIdx.x / 24) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define FWD_STAMP(i)
-#endif
-#ifndef FWD_OCC
+// (K / V staged through registers, not by LDS-DMA: 14.5 vs 15.0 us -- the staging is bound by the L2 -> CU burst of all resident workgroups,
+//  not by the ds_write pass; the LDS-DMA leg, the ablation switches and the shader-clock stamps of rounds 2-5 live in the repository's
+//  history: scripts/README.md, "profiling legs")
 #define FWD_OCC 4   // workgroups per CU: 39.2 KB of LDS and <= 128 VGPRs each
-#endif
 __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16* __restrict__ qkv,
                                                        const int* __restrict__ key_src, const int* __restrict__ q_dst,
                                                        const h16* __restrict__ biasH, float* __restrict__ ao,
@@ -213,88 +189,38 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
     const int h = blockIdx.x & 7, wb = blockIdx.x >> 3, w = wb % G.nW, b = wb / G.nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int qcol = 16 * wave + (lane & 15), g = lane >> 4, l15 = lane & 15;
-
-    FWD_STAMP(0);
     // ---- stage ----
-    // Global loads go out in three batches, each complete before anything waits on it: the key-table entries of this
-    // thread's 5 rows (+ the destination pixel the epilogue needs), then the 10 gathered 16-byte K/V segments and
-    // this lane's Q fragment (straight into the MFMA operand: Q never touches LDS), then the wave's 19 bias tiles.
+    // Global loads go out in three batches, each complete before anything waits on it: the key-table entries of this thread's 5
+    // rows (+ the destination pixel the epilogue needs), then the 10 gathered 16-byte K/V segments and this lane's Q fragment
+    // (straight into the MFMA operand: Q never touches LDS), then the wave's 10 bias fragments.
     // A (token, head) slice is 64 B of f16 = four 16-byte chunks.  K and V are both kept as ROWS: the PV step reads V
     // through the LDS transpose read (lds_tr4), so no transposed image is written.
+    // (One workgroup per (window, head), NOT persistent over windows: round 6 measured the loop form with the bias fragments kept
+    // across windows at 14.3-15.7 us against 13.9-14.4 -- they would have to live through the PV phase next to s[19], which spills at
+    // four workgroups per CU and costs the fourth workgroup otherwise: profiles/r06_attn_fwd_persistent_ab.txt.)
     const buf_t rs_qkv = qkv_rsrc(G, qkv);
     const int qdst = (qcol < CFFM_WA) ? q_dst[w * CFFM_WA + qcol] : -1;
-#if FWD_DMA
-    // K / V rows by LDS-DMA: a wave-instruction moves 16 rows x 64 B (4 adjacent lanes = the four 16-byte chunks of one (token,
-    // head) slice) from the q|k|v rows straight into the row image -- no staging registers, no ds_write pass (4 workgroups x
-    // 39 KB of ds_write_b128 per CU and round cost ~1.1 k cycles per workgroup: scripts/r02_fwd_timing.py).  The DMA writes
-    // lane-linearly, so the ATT_ROW chunk permutation is applied to the SOURCE: the lane at chunk position sc of row r fetches
-    // chunk sc ^ ATT_SWZ(r).  An absent key (-1) is an out-of-range offset: zeros land in its row.
-    const uint32_t soff_k = qkv_soff_k(G, b, h);
-    const int* ksrc = key_src + w * CFFM_NKEY_PAD;
-    {
-        const int srow = lane >> 2, sc = lane & 3;
-        int src[5];
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int i = wave + 4 * it;
-            src[it] = i < 19 ? ksrc[16 * i + srow] : -1;
-        }
-        // every use of the table entries comes BEFORE the first DMA is issued: with an LDS-DMA in flight hipcc waits vmcnt(0) at
-        // the next use of any ordinary load result, which would serialise the five batches into five memory round trips
-        uint32_t off[5];
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int i = wave + 4 * it, row = 16 * i + srow;
-            off[it] = (src[it] >= 0 && !(FWD_ABLATE & 2)) ? (uint32_t)src[it] * 1536u + 16u * (uint32_t)(sc ^ ATT_SWZ(row)) : BUF_OOB;
-            if (i < 19 && sc == 0) vflag[row] = src[it] >= 0 ? 0.f : -INFINITY;
-        }
-        sched_fence();
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int i = wave + 4 * it;
-            if (i < 19) {
-                buf_ld16_lds(rs_qkv, off[it], soff_k, Ks + 16 * i * ATT_KS_STRIDE);
-                buf_ld16_lds(rs_qkv, off[it], soff_k + 512, Vs + 16 * i * ATT_KS_STRIDE);
-            }
-        }
-    }
-    const f16x8 qfrag = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)(w * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
-                                  (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
-    // the wave's 19 bias fragments (L2-resident f16 table)
-    const buf_t rs_bias = biash_rsrc(biasH);
-    const uint32_t bvoff = (FWD_ABLATE & 1) ? BUF_OOB : biash_voff(lane);
-    f16x8 bh[10];
-#pragma unroll
-    for (int t = 0; t < 10; ++t) bh[t] = buf_ld_h8(rs_bias, bvoff, biash_soff(h, wave, t));
-    FWD_STAMP(1);
-    FWD_STAMP(2);
-#else
-    // Global loads go out in three batches, each complete before anything waits on it: the key-table entries of this thread's 5
-    // rows, then the 10 gathered 16-byte K/V segments and this lane's Q fragment (straight into the MFMA operand: Q never
-    // touches LDS), then the wave's bias fragments (the first FWD_BIAS_EARLY before the LDS stores, the rest across the barrier:
-    // all 19 next to the 45 registers of gathered rows would spill at the 128-register budget of 4 workgroups per CU).
     KvRegs<256> kv;
     kv_load<256>(kv, rs_qkv, qkv_soff_k(G, b, h), key_src + w * CFFM_NKEY_PAD, tid);
     const f16x8 qfrag = buf_ld_h8(rs_qkv, qcol < CFFM_WA ? (uint32_t)(w * CFFM_WA + qcol) * 1536u + 16u * g : BUF_OOB,
                                   (uint32_t)(((long)b * G.RC * 768 + h * CFFM_HD) * 2));
     const buf_t rs_bias = biash_rsrc(biasH);
-    const uint32_t bvoff = (FWD_ABLATE & 1) ? BUF_OOB : biash_voff(lane);
+    const uint32_t bvoff = biash_voff(lane);
     f16x8 bh[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) bh[t] = buf_ld_h8(rs_bias, bvoff, biash_soff(h, wave, t));
-    FWD_STAMP(1);
     kv_store<256>(kv, Ks, Vs, vflag, tid);
-    FWD_STAMP(2);
-#endif
     __syncthreads();
-    FWD_STAMP(3);
+    const f16x8 sel0 = bias_sel_frag(lane, 0), sel1 = bias_sel_frag(lane, 1);
+    f16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
 
     // ---- S^T = K Q^T (+bias, +mask), softmax over the 289 keys of each query column -----------------
     // VALU budget: per 16-key tile and lane 2 v_max3 + 4 (v_fma + v_exp) + 2 v_cvt_pk.  The position bias arrives on the matrix
     // pipe (Sel * B, see bias_sel_frag) with the mask of the tiles that can hold an absent key (the pooled groups, keys >= 181:
     // own and ring keys always exist) as ITS C-in; exp(s - m) is 2^(s log2e - m log2e), one FMA feeding v_exp_f32; the row sums
     // come out of the matrix pipe too (a constant all-ones A operand next to V^T: 10 more MFMAs instead of 76 adds).
-    const f16x8 sel0 = bias_sel_frag(lane, 0), sel1 = bias_sel_frag(lane, 1);
     f32x4 s[19];
     float m = -INFINITY;
 #pragma unroll
@@ -308,14 +234,10 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float m2 = m * CFFM_LOG2E;
-    FWD_STAMP(4);
 
     // ---- O^T = V^T P^T : A = V^T[d][key slots] read transposed out of the V rows, B = P^T from registers; the third
     //      accumulator (A = ones) is the softmax denominator of the f16-rounded weights the product really uses ----------
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, osum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
 #pragma unroll
     for (int kt = 0; kt < 10; ++kt) {
         f16x4 ph[2];
@@ -325,7 +247,7 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
             if (t < 19) {
                 f32x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] = (FWD_ABLATE & 8) ? fmaf(s[t < 19 ? t : 0][r], CFFM_LOG2E, -m2) : fast_exp2(fmaf(s[t < 19 ? t : 0][r], CFFM_LOG2E, -m2));
+                for (int r = 0; r < 4; ++r) p[r] = fast_exp2(fmaf(s[t][r], CFFM_LOG2E, -m2));
                 ph[u] = to_f16x4(p);
             } else {
                 ph[u] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
@@ -337,7 +259,6 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
             o[mt] = mfma16x16x32_f16(att_tr_frag<CFFM_NKEY_PAD>(Vs, 32 * kt, 16 * mt, lane), pf, o[mt]);
         osum = mfma16x16x32_f16(ones, pf, osum);
     }
-    FWD_STAMP(5);
     const float l = osum[0];      // every row of the ones-product is the column sum: l of query l15, in all four lane groups
 
     // ---- epilogue: normalise, un-window, drop padded pixels (cffm_transformer.py:812-821) ------------
@@ -348,7 +269,6 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
         *(f32x4*)(orow) = o[0] * inv;
         *(f32x4*)(orow + 16) = o[1] * inv;
     }
-    FWD_STAMP(6);
 }
 
 // =====================================================================================================
@@ -374,16 +294,6 @@ __global__ void __launch_bounds__(256, FWD_OCC) k_cfm_attn_fwd(Geo G, const h16*
 #define ATT_BK_TAB (320 + 64)                               // ints of one table buffer: the window's key-table slice, its q_dst slice
 #define ATT_BK_RAW (2 * 64 * CFFM_HD + 64)                  // floats of the parking area: dO rows, O rows, the LSE row
 #define ATT_BK_LDS ((2 * ATT_BK_IMG + 4 * 64 * ATT_KS_STRIDE + 2 * ATT_BK_DSROWS * ATT_KS_STRIDE) * 2 + (ATT_BK_RAW + 2 * CFFM_NKEY_PAD + 4 * 64 + 4 + 8 + 3 * ATT_BK_TAB) * 4)
-#ifndef BK_ABLATE
-#define BK_ABLATE 0   // profiling builds only: 1 no DMA, 2 no key phase, 4 no query phase, 8 no partial-row stores, 16 no exp
-#endif
-#ifdef BWD_TIMING   // profiling builds only: shader-clock stamps of the third window of (head 0, group 0), every wave (scripts/r04_ks_timing.py)
-__device__ long long g_bwd_t[16 * 16];
-#define KS_STAMP(i) do { if (lane == 0 && blockIdx.x == 0 && grp == 0 && (wb == wb0 + 2 || (wb == wb0 + 3 && (i) == 0))) \
-    g_bwd_t[wave * 16 + (wb == wb0 + 3 ? 9 : (i))] = __builtin_readcyclecounter(); } while (0)
-#else
-#define KS_STAMP(i)
-#endif
 __device__ __forceinline__ void wait_vm0() {   // every outstanding global access of this wave -- LDS-DMA included -- has completed
 #ifndef CFFM_EMU
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), gfx9 encoding
@@ -491,7 +401,6 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     // table slices of window wb -> buffer tb: waves 7..11 one 64-entry piece of the key table each (the last one runs 16 entries into the
     // next window's slice or off the table: never used), wave 6 the q_dst slice
     auto tab_issue = [&](int w, int tb) {
-        if (BK_ABLATE & 1) return;
         if (wave >= 7) dma_ld4(dm_tab, 4u * (uint32_t)(64 * (wave - 7) + lane), (uint32_t)(w * CFFM_NKEY_PAD * 4), tabs + tb * ATT_BK_TAB + 64 * (wave - 7));
         else if (wave == 6) dma_ld4(dm_qd, 4u * (uint32_t)lane, (uint32_t)(w * CFFM_WA * 4), tabs + tb * ATT_BK_TAB + 320);
         sched_fence();
@@ -521,7 +430,6 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
             if (i < 19 && sc4 == 0) vfl[bi * CFFM_NKEY_PAD + 16 * i + drow] = o.kv[it] != BUF_OOB ? 0.f : -INFINITY;
         }
         sched_fence();
-        if (BK_ABLATE & 1) return;
         if (wave < 8) {
             dma_ld16(dm_dao, o.rows, ps, raw + 8 * wave * CFFM_HD);
             dma_ld16(dm_ao, o.rows, ps, raw + 64 * CFFM_HD + 8 * wave * CFFM_HD);
@@ -534,7 +442,6 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
     // chains of the wave's first key tile: all waves issuing their five to seven DMAs at once right behind the barrier kept every wave
     // of the CU in the texture addresser's queue for ~2 k cycles (shader-clock stamps, scripts/r04_ks_timing.py).
     auto dma_piece = [&](int b, const DmaOff& o, int bi, int k) {
-        if (BK_ABLATE & 1) return;
         const uint32_t soff_k = qkv_soff_k(G, b, h);
         f16* Ks = img + bi * ATT_BK_IMG;
         f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
@@ -620,76 +527,67 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
         // The K / V / Q DMAs of this window were issued a window ago; the only accesses younger than them are the wave's stores of the
         // previous window (2 partial-row stores per key tile and at most one more): waiting for those as well would expose their round
         // trip to HBM at every window.  (Not so for the first window: its DMAs were issued just now.)
-        KS_STAMP(0);
-        if ((BK_ABLATE & 32) || wb == wb0 || ntile == 0) wait_vm0(); else if (ntile == 1) wait_vm<2>(); else wait_vm<4>();
-        KS_STAMP(1);
+        if (wb == wb0 || ntile == 0) wait_vm0(); else if (ntile == 1) wait_vm<2>(); else wait_vm<4>();
         __syncthreads();   // B1: window wb's K / V / Q rows are in image bi, its dO_h rows, D, LSE, 1 / sc are written; image bi ^ 1, the dS
                            //     images and the parking area are free
-        KS_STAMP(2);
         const bool more = wb + 1 < wb1;
         if (more) dma_rows(n1, onx, bi ^ 1);   // flags and row DMAs of window wb + 1; the rest goes out inside the key phase
-        KS_STAMP(3);
         const f16* Ks = img + bi * ATT_BK_IMG;
         const f16* Vs = Ks + CFFM_NKEY_PAD * ATT_KS_STRIDE;
         const f16* Q = Qs + bi * 64 * ATT_KS_STRIDE;
         const f16* dO = dOs + bi * 64 * ATT_KS_STRIDE;
         const float isc = sisc[bi];
         // ---- key phase: the wave's key tiles against all 64 queries
-        if (!(BK_ABLATE & 2)) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = t0 + u;
-                if (u < ntile) {
-                    sched_fence();
-                    const f16x8 kf = *(const f16x8*)(Ks + 512 * t + lrow);
-                    const f16x8 vf = *(const f16x8*)(Vs + 512 * t + lrow);
-                    const float mk = t >= 11 ? vfl[bi * CFFM_NKEY_PAD + 16 * t + l15] : 0.f;   // only keys >= 181 can be absent
-                    const f32x4 c0 = (f32x4){mk, mk, mk, mk};
-                    f16x4 ph[4], dsh[4];
+        for (int u = 0; u < 2; ++u) {
+            const int t = t0 + u;
+            if (u < ntile) {
+                sched_fence();
+                const f16x8 kf = *(const f16x8*)(Ks + 512 * t + lrow);
+                const f16x8 vf = *(const f16x8*)(Vs + 512 * t + lrow);
+                const float mk = t >= 11 ? vfl[bi * CFFM_NKEY_PAD + 16 * t + l15] : 0.f;   // only keys >= 181 can be absent
+                const f32x4 c0 = (f32x4){mk, mk, mk, mk};
+                f16x4 ph[4], dsh[4];
 #pragma unroll
-                    for (int qt = 0; qt < 4; ++qt) {
-                        if (u == 0 && more) dma_piece(n1.b, onx, bi ^ 1, qt);
-                        const f16x8 qf = *(const f16x8*)(Q + 512 * qt + lrow);
-                        const f16x8 dof = *(const f16x8*)(dO + 512 * qt + lrow);
-                        const f32x4 sv = mfma16x16x32_f16(qf, kf, mfma16x16x32_f16(bT[qt], u ? sel1 : sel0, c0));   // Q K^T + bias + mask
-                        const f32x4 dp = mfma16x16x32_f16(dof, vf, (f32x4){0.f, 0.f, 0.f, 0.f});
-                        const f32x4 lq = *(const f32x4*)(lse2 + bi * 64 + 16 * qt + 4 * g), Dq = *(const f32x4*)(sD + bi * 64 + 16 * qt + 4 * g);
-                        f32x4 pr, ds;
+                for (int qt = 0; qt < 4; ++qt) {
+                    if (u == 0 && more) dma_piece(n1.b, onx, bi ^ 1, qt);
+                    const f16x8 qf = *(const f16x8*)(Q + 512 * qt + lrow);
+                    const f16x8 dof = *(const f16x8*)(dO + 512 * qt + lrow);
+                    const f32x4 sv = mfma16x16x32_f16(qf, kf, mfma16x16x32_f16(bT[qt], u ? sel1 : sel0, c0));   // Q K^T + bias + mask
+                    const f32x4 dp = mfma16x16x32_f16(dof, vf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    const f32x4 lq = *(const f32x4*)(lse2 + bi * 64 + 16 * qt + 4 * g), Dq = *(const f32x4*)(sD + bi * 64 + 16 * qt + 4 * g);
+                    f32x4 pr, ds;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            pr[r] = (BK_ABLATE & 16) ? fmaf(sv[r], CFFM_LOG2E, -lq[r]) : fast_exp2(fmaf(sv[r], CFFM_LOG2E, -lq[r]));
-                            ds[r] = pr[r] * (dp[r] - Dq[r]);
-                        }
-                        dB[u][qt] += ds * isc;
-                        ph[qt] = to_f16x4(pr);
-                        dsh[qt] = to_f16x4(ds);
-                        // dS image: row = key, 8 bytes = queries 16 qt + 4 g .. + 3
-                        *(f16x4*)(DS + (qt >> 1) * ATT_BK_DSROWS * ATT_KS_STRIDE + 512 * t + ((qt & 1) ? dsw1 : dsw0)) = dsh[qt];
+                    for (int r = 0; r < 4; ++r) {
+                        pr[r] = fast_exp2(fmaf(sv[r], CFFM_LOG2E, -lq[r]));
+                        ds[r] = pr[r] * (dp[r] - Dq[r]);
                     }
-                    if (u == 0 && more) {   // the last pieces: Q rows, the table slices of window wb + 3 -- all DMAs precede the wave's stores
-                        dma_piece(n1.b, onx, bi ^ 1, 4);
-                        if (wb + 3 < wb1) tab_issue(n3.w, r3);
-                    }
-                    f32x4 aK[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, aV[2] = {aK[0], aK[0]};
+                    dB[u][qt] += ds * isc;
+                    ph[qt] = to_f16x4(pr);
+                    dsh[qt] = to_f16x4(ds);
+                    // dS image: row = key, 8 bytes = queries 16 qt + 4 g .. + 3
+                    *(f16x4*)(DS + (qt >> 1) * ATT_BK_DSROWS * ATT_KS_STRIDE + 512 * t + ((qt & 1) ? dsw1 : dsw0)) = dsh[qt];
+                }
+                if (u == 0 && more) {   // the last pieces: Q rows, the table slices of window wb + 3 -- all DMAs precede the wave's stores
+                    dma_piece(n1.b, onx, bi ^ 1, 4);
+                    if (wb + 3 < wb1) tab_issue(n3.w, r3);
+                }
+                f32x4 aK[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, aV[2] = {aK[0], aK[0]};
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const f16x8 pf = cat_f16x4(ph[2 * a], ph[2 * a + 1]), dsf = cat_f16x4(dsh[2 * a], dsh[2 * a + 1]);
+                for (int a = 0; a < 2; ++a) {
+                    const f16x8 pf = cat_f16x4(ph[2 * a], ph[2 * a + 1]), dsf = cat_f16x4(dsh[2 * a], dsh[2 * a + 1]);
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            aV[mt] = mfma16x16x32_f16(att_tr_frag_at(dO + 1024 * a, mt ? ltp1 : ltp0), pf, aV[mt]);
-                            aK[mt] = mfma16x16x32_f16(att_tr_frag_at(Q + 1024 * a, mt ? ltp1 : ltp0), dsf, aK[mt]);
-                        }
-                    }
-                    // tiles [channel 8 g + 4 mt + r][key = l15]: 16 bytes of the key's partial row (8 heads x (K 32 | V 32) halfs) per store,
-                    // a quarter-wave covers the head's whole 64-byte K (V) slice; an absent key's stores go out of range and are dropped
-                    if (!(BK_ABLATE & 8)) {
-                        const uint32_t so = (uint32_t)(((long)wb * CFFM_NKEY_PAD + 16 * t) * 1024);
-                        const uint32_t vo = mk == 0.f ? (uint32_t)(l15 * 1024 + (h * 2 * CFFM_HD + 8 * g) * 2) : BUF_OOB;
-                        buf_st16_pair(rs_part, __builtin_bit_cast(f32x4, cat_f16x4(to_f16x4(aK[0]), to_f16x4(aK[1]))),
-                                      __builtin_bit_cast(f32x4, cat_f16x4(to_f16x4(aV[0]), to_f16x4(aV[1]))), vo, so, so + 64);
+                    for (int mt = 0; mt < 2; ++mt) {
+                        aV[mt] = mfma16x16x32_f16(att_tr_frag_at(dO + 1024 * a, mt ? ltp1 : ltp0), pf, aV[mt]);
+                        aK[mt] = mfma16x16x32_f16(att_tr_frag_at(Q + 1024 * a, mt ? ltp1 : ltp0), dsf, aK[mt]);
                     }
                 }
-                KS_STAMP(4 + u);
+                // tiles [channel 8 g + 4 mt + r][key = l15]: 16 bytes of the key's partial row (8 heads x (K 32 | V 32) halfs) per store,
+                // a quarter-wave covers the head's whole 64-byte K (V) slice; an absent key's stores go out of range and are dropped
+                const uint32_t so = (uint32_t)(((long)wb * CFFM_NKEY_PAD + 16 * t) * 1024);
+                const uint32_t vo = mk == 0.f ? (uint32_t)(l15 * 1024 + (h * 2 * CFFM_HD + 8 * g) * 2) : BUF_OOB;
+                buf_st16_pair(rs_part, __builtin_bit_cast(f32x4, cat_f16x4(to_f16x4(aK[0]), to_f16x4(aK[1]))),
+                              __builtin_bit_cast(f32x4, cat_f16x4(to_f16x4(aV[0]), to_f16x4(aV[1]))), vo, so, so + 64);
             }
         }
         // the next window's dO / O / LSE rows have landed: of this wave's accesses only its K / V DMAs, the Q or table DMA and the
@@ -706,30 +604,25 @@ __global__ void __launch_bounds__(ATT_BK_THREADS) k_cfm_attn_bwd(Geo G, const h1
             dma_prep(n2.w, a, onx);
         }
         if (more && wave < 9) {   // younger than the row DMAs: waves 0..6 >= 9 accesses, wave 7 (one K / V tile to fetch) 7, wave 8 (one key tile) 5
-            if (BK_ABLATE & 32) wait_vm0(); else if (wave < 7) wait_vm<8>(); else if (wave == 7) wait_vm<6>(); else wait_vm<4>();
+            if (wave < 7) wait_vm<8>(); else if (wave == 7) wait_vm<6>(); else wait_vm<4>();
             if (wave < 8) rows_max();
         }
-        KS_STAMP(6);
         __syncthreads();   // B2: the dS images of window wb and the parked rows of window wb + 1 are complete
-        KS_STAMP(7);
         if (wave >= 8) {
             if (more) rows_convert(wb + 1, bi ^ 1);
         } else {
             // ---- query phase: dQ^T[16 channels mt][16 queries qt] = K^T dS^T over the 10 key pairs
-            if (!(BK_ABLATE & 4)) {
-                const int qt = wave & 3, mt = wave >> 2;
-                const f16* D = DS + (qt >> 1) * ATT_BK_DSROWS * ATT_KS_STRIDE;
-                const int la = mt ? ltr1 : ltr0, lb = (qt & 1) ? ltr1 : ltr0;
-                f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int qt = wave & 3, mt = wave >> 2;
+            const f16* D = DS + (qt >> 1) * ATT_BK_DSROWS * ATT_KS_STRIDE;
+            const int la = mt ? ltr1 : ltr0, lb = (qt & 1) ? ltr1 : ltr0;
+            f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int p = 0; p < 10; ++p)
-                    dq = mfma16x16x32_f16(att_tr_frag_at(Ks + 1024 * p, la, p == 9), att_tr_frag_at(D + 1024 * p, lb), dq);
-                const int q = 16 * qt + l15;
-                if (q < CFFM_WA)
-                    *(f32x4*)(dqkv + ((long)b * G.RC + w * CFFM_WA + q) * 768 + h * CFFM_HD + 16 * mt + 4 * g) = dq * (scale * isc);
-            }
+            for (int p = 0; p < 10; ++p)
+                dq = mfma16x16x32_f16(att_tr_frag_at(Ks + 1024 * p, la, p == 9), att_tr_frag_at(D + 1024 * p, lb), dq);
+            const int q = 16 * qt + l15;
+            if (q < CFFM_WA)
+                *(f32x4*)(dqkv + ((long)b * G.RC + w * CFFM_WA + q) * 768 + h * CFFM_HD + 16 * mt + 4 * g) = dq * (scale * isc);
         }
-        KS_STAMP(8);
         cur = n1;
         r3 = r3 == 2 ? 0 : r3 + 1;
     }

@@ -27,9 +27,6 @@
 #pragma once
 #include "cffm_common.h"
 
-#ifndef GEMM_ABLATE
-#define GEMM_ABLATE 0   // profiling builds only: 1 no global loads in the K-loop, 2 no split / LDS stores, 4 no MFMAs, 8 no fast path, 16 no split arithmetic
-#endif
 // (bf16 types and the split-4 helpers: cffm_common.h)
 
 __device__ __forceinline__ f32x4 mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -279,7 +276,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
     // Fast path (whole K-tiles; a row-contiguous operand also whole row tiles): while at least 2*PF tiles remain every
     // step multiplies, splits and loads unconditionally, so the loop body is ONE basic block and the scheduling hints
     // below can place the split's VALU work / LDS writes / buffer loads between the MFMAs.
-    if ((kend - kbeg) % BK == 0 && (!A_T || M % BM == 0) && (!B_T || N % BN == 0) && !(GEMM_ABLATE & 8)) {
+    if ((kend - kbeg) % BK == 0 && (!A_T || M % BM == 0) && (!B_T || N % BN == 0)) {
         const buf_t rsa = buf_make(A, (uint32_t)((A_T ? K : M) * (long)lda * 4)), rsb = buf_make(B, (uint32_t)((B_T ? K : N) * (long)ldb * 4));
         const uint32_t va = tile_voff<BM, A_T, BK>(lda, tid), vb = tile_voff<BN, B_T, BK>(ldb, tid);
         const uint32_t lda4 = lda * 4, ldb4 = ldb * 4;
@@ -325,7 +322,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
             if (t < NKT) {   // uniform across the workgroup
                 const int cur = (t & 1) * IMG, nxt = IMG - cur;
 #pragma unroll
-                for (int ks = 0; ks < ((GEMM_ABLATE & 4) ? 0 : BK); ks += 32) {
+                for (int ks = 0; ks < BK; ks += 32) {
                     bf16x8 bh[NT], bl[NT];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
@@ -344,11 +341,11 @@ __device__ __forceinline__ void gemm_tile(char* smem, const float* __restrict__ 
                         }
                     }
                 }
-                if (t + 1 < NKT && !(GEMM_ABLATE & 2)) {
+                if (t + 1 < NKT) {
                     tile_store<BM, A_T, BK>(ra[u], Ah + nxt, Al + nxt, tid, a_pre);
                     tile_store<BN, B_T, BK>(rb[u], Bh + nxt, Bl + nxt, tid, b_pre, bb4);
                 }
-                if (t + 1 + PF < NKT && !(GEMM_ABLATE & 1)) {
+                if (t + 1 + PF < NKT) {
                     tile_load<BM, A_T, BK>(ra[u], A, lda, m0, M, kbeg + (t + 1 + PF) * BK, kend, tid);
                     tile_load<BN, B_T, BK>(rb[u], B, ldb, n0, N, kbeg + (t + 1 + PF) * BK, kend, tid);
                 }

@@ -16,9 +16,6 @@
 #include "gemm_kernels.h"
 #include "dws_kernels.h"
 
-#ifndef PNL_ABLATE
-#define PNL_ABLATE 0      // profiling builds of scripts/r03_panel_bench.hip only: 1 no B loads in the loop, 2 no MFMAs, 4 no epilogue stores, 8 no panel staging
-#endif
 #define PNL_KC 256          // contraction chunk held in LDS (floats per row)
 #define PNL_THREADS 512     // 8 waves: two per SIMD
 #define PNL_WAVES 8
@@ -162,10 +159,7 @@ __device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT,
         const int p = sc / 8, cur = sc & 1;
         // the slot consumed by the previous step takes step sc + D - 1 (of this chunk, or of what follows it)
         const int sn = sc + D - 1, slot_n = sn % D;
-        if (PNL_ABLATE & 1) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) { asm volatile("" : "+v"(ring.v[slot_n][j][0]), "+v"(ring.v[slot_n][j][1])); }
-        } else if (sn < SC) pnl_ring_load<NT, D>(ring, slot_n, st, jt0 + (sn / 8) * NT, ks0 + sn % 8);
+        if (sn < SC) pnl_ring_load<NT, D>(ring, slot_n, st, jt0 + (sn / 8) * NT, ks0 + sn % 8);
         else pnl_ring_load<NT, D>(ring, slot_n, nst, njt0 + ((sn - SC) / 8) * NT, nks0 + (sn - SC) % 8);
         extra(sc);
         pnl_pin_vmem();
@@ -184,7 +178,6 @@ __device__ __forceinline__ void pnl_chunk_mma(f32x4 (&acc)[NTW][MT], PnlRing<NT,
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 f32x4 c = acc[p * NT + j][i];
-                if (PNL_ABLATE & 2) { asm volatile("" : "+v"(c) : "v"(bh), "v"(bl), "v"(ah[cur][i]), "v"(al[cur][i])); acc[p * NT + j][i] = c; continue; }
                 c = mfma16x16x32_bf16(bh, al[cur][i], c);
                 c = mfma16x16x32_bf16(bl, ah[cur][i], c);
                 c = mfma16x16x32_bf16(bh, ah[cur][i], c);
@@ -248,15 +241,8 @@ __device__ __forceinline__ uint32_t pnl_l2_touch(const void* w, long bytes, int 
     const long per = (nlines + nsl - 1) / nsl, l = rank * per + tid;
     return (tid < per && l < nlines) ? *(const uint32_t*)((const char*)w + (l << 7)) : 0u;
 }
-#ifndef PNL_TOUCH
-#define PNL_TOUCH 1
-#endif
-#ifndef PNL_STAGE_OUT
-#define PNL_STAGE_OUT 1   // plain panel GEMMs: output rows assembled in LDS and stored whole (k_panel_gemm epilogue)
-#endif
-#ifndef PNL_TOUCH_GEMM
-#define PNL_TOUCH_GEMM 0   // the plain panel GEMMs (q|k|v: 0.75 MB of weights): no difference measured (0.719-0.727 with, 0.715-0.731 without)
-#endif
+// (the fused kernels always warm the L2 with their fc1 / fc2 / proj weights; the plain panel GEMMs -- q|k|v: 0.75 MB of weights -- do not:
+//  no difference measured, 0.719-0.727 ms per step with, 0.715-0.731 without)
 // ---- plain panel GEMM: C[M][N] = A[M][K] W^T (+ bias), W in fragment order (NT or NN form decides what "W^T" means) ---------
 // grid = ceil(M / (16 MT)) workgroups of 512 threads; N = 8 waves x NTW tiles x 16; K a multiple of 256.
 // EPI: 0 plain fp32 (+bias) | 3 q|k|v: nothing in C; aux (h16 [M][ldc]) = f16(raw + bias), features < 256 (the q third) also times
@@ -305,12 +291,6 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
     pnl_pin_vmem();
     PnlStage<MT> sr;
     pnl_stage_load<MT>(sr, rsa, lda, m0, 0, tid);
-    uint32_t touch = 0;
-    if (PNL_TOUCH_GEMM) {      // L2 warm-up of the weight (pnl_l2_touch, defined below with the fused kernels)
-        pnl_pin_vmem();
-        touch = pnl_l2_touch(Wf, (long)N * K * 4, tid);
-        pnl_pin_vmem();
-    }
     pnl_stage_store<MT, A_PRE>(sr, img, img + PNL_IMG(MT), tid);
     PNL_COLSUM_PUT(0)
     if (NCH > 1) pnl_stage_load<MT>(sr, rsa, lda, m0, PNL_KC, tid);
@@ -334,11 +314,12 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
 #undef PNL_COLSUM_PUT
 #undef PNL_COLSUM_GET
     // epilogue: acc[t][i][r] = C[m0 + 16 i + l15][16 (jt0 + t) + 4 g + r]
-    if (PNL_STAGE_OUT && !(PNL_ABLATE & 4) && (EPI == 0 || EPI == 3)) {
+    {
         // Through LDS: a lane of the MFMA C layout owns 4 consecutive features of one row, so a store instruction writes 16 rows x 32 B
         // (f16 q|k|v) or x 64 B (fp32) -- short runs that drain at about half the rate of whole rows (the q|k|v forward spent 8 of its
         // 20 us on its 15.9 MB of stores).  The panel's output [16 MT rows][N] is assembled in the (now free) image buffers, rows padded by
         // 32 B against bank conflicts, and leaves as 16-byte units in row order: every wave instruction writes 1 KiB of one or two rows.
+        static_assert(EPI == 0 || EPI == 3, "k_panel_gemm epilogue");
         constexpr int ESZ = (EPI == 3) ? 2 : 4, NCOL = PNL_WAVES * NTW * 16, ROWB = NCOL * ESZ + 32, UPR = NCOL * ESZ / 16;
         static_assert(16 * MT * ROWB <= PNL_LDS(MT), "panel output does not fit the image buffers");
         char* out = (char*)smem;
@@ -368,30 +349,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_panel_gemm(const float* __restr
             const int r = u / UPR, c = u % UPR;
             if (m0 + r < M) *(f32x4*)(dst + ((long)(m0 + r) * ldc) * ESZ + 16 * c) = *(const f32x4*)(out + r * ROWB + 16 * c);
         }
-        if (PNL_TOUCH_GEMM && M < 0) *(volatile uint32_t*)aux = touch;
-        return;
     }
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const int n = 16 * (jt0 + t) + 4 * g;
-        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *(const f32x4*)(bias + n);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + 16 * i + l15;
-            if (PNL_ABLATE & 4) { if (acc[t][i][0] == 1.2345f && m < M) C[m] = 1.f; continue; }
-            if (EPI == 3) {
-                const float sc = n < CFFM_C ? 0.17677669529663687f : 1.f;
-                typedef h16 h16x4 __attribute__((ext_vector_type(4)));
-                h16x4 o;
-                for (int e = 0; e < 4; ++e) o[e] = (h16)((acc[t][i][e] + bv[e]) * sc);
-                if (m < M) *(h16x4*)((h16*)aux + (long)m * ldc + n) = o;
-                continue;
-            }
-            if (m < M) *(f32x4*)(C + (long)m * ldc + n) = acc[t][i] + bv;
-        }
-    }
-    if (PNL_TOUCH_GEMM && M < 0) *(volatile uint32_t*)aux = touch;     // (never taken: keeps the warm-up load)
 }
 
 // =====================================================================================================================
@@ -421,7 +379,6 @@ __device__ __forceinline__ float pnl_sum_g(float v) {
     v += __shfl_xor(v, 32, 64);
     return v;
 }
-#define PNL_ST(v) ((v) && !(PNL_ABLATE & 4))
 #define PNL_STORE4(p, v) (*(f32x4*)(p) = (v))
 #define PNL_FUSED_LDS(MT) (6 * PNL_IMG(MT) * 2 + 2 * PNL_WAVES * 16 * (MT) * 4)   // P + 2 x ACT (hi | lo each) + reduction scratch
 
@@ -455,17 +412,12 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
     {
         PnlStage<MT> sr;
         pnl_stage_load<MT>(sr, buf_make(a.ao, (uint32_t)((long)NP * 256 * 4)), 256, m0, 0, tid);
-        if (PNL_TOUCH) {     // behind the panel's loads in the memory queue: staging does not wait for them
-            pnl_pin_vmem();
-            const uint32_t t0 = pnl_l2_touch(a.w1, 1024L * 256 * 4, tid), t1 = pnl_l2_touch(a.w2, 1024L * 256 * 4, tid);
-            uint32_t t2 = 0;
-            if (PNL_TOUCH & 2) t2 = pnl_l2_touch(a.wp, 256L * 256 * 4, tid);
-            pnl_pin_vmem();
-            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
-            touch = t0 ^ t1 ^ t2;
-        } else {
-            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
-        }
+        // L2 warm-up (pnl_l2_touch), behind the panel's loads in the memory queue: staging does not wait for it
+        pnl_pin_vmem();
+        const uint32_t t0 = pnl_l2_touch(a.w1, 1024L * 256 * 4, tid), t1 = pnl_l2_touch(a.w2, 1024L * 256 * 4, tid);
+        pnl_pin_vmem();
+        pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+        touch = t0 ^ t1;
     }
     pnl_lds_barrier();
     const long NP32 = ((long)NP + 31) / 32 * 32;
@@ -502,7 +454,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
             }
             const f32x4 v = acc[t][i] + bv + r;
             x1v[t][i] = v;
-            if (PNL_ST(valid[i])) *(f32x4*)(a.x1 + mrow[i] * 256 + n) = v;
+            if (valid[i]) *(f32x4*)(a.x1 + mrow[i] * 256 + n) = v;
             s[i] += (v[0] + v[1]) + (v[2] + v[3]);
         }
     }
@@ -548,7 +500,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
             bf16x4 h, l;
             split4(zv, h, l);
             pnl_img_put(P, P + PNL_IMG(MT), 16 * i + l15, n, h, l);
-            if (PNL_ST(valid[i]) && a.z2s) *(f32x4*)(a.z2s + mrow[i] * 256 + n) = pnl_pack_hl(h, l);
+            if (valid[i] && a.z2s) *(f32x4*)(a.z2s + mrow[i] * 256 + n) = pnl_pack_hl(h, l);
         }
     }
     pnl_lds_barrier();
@@ -579,7 +531,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
                 bf16x4 h, l;
                 split4(av, h, l);
                 pnl_img_put(Ah, Ah + PNL_IMG(MT), 16 * i + l15, nl, h, l);
-                if (PNL_ST(valid[i])) {
+                if (valid[i]) {
                     *(f32x4*)(a.hraw + mrow[i] * 1024 + n) = raw;
                     if (a.acts) *(f32x4*)(a.acts + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
                 }
@@ -596,9 +548,9 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_fwd(MlpFwdArgs a) {
         const f32x4 bv = *(const f32x4*)(a.b2 + n);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-            if (PNL_ST(valid[i])) *(f32x4*)(a.x2 + mrow[i] * 256 + n) = x1v[t][i] + acc2[t][i] + bv;
+            if (valid[i]) *(f32x4*)(a.x2 + mrow[i] * 256 + n) = x1v[t][i] + acc2[t][i] + bv;
     }
-    if (PNL_TOUCH && a.NP < 0) a.mean2[tid] = (float)touch;     // (never taken: keeps the warm-up loads)
+    if (a.NP < 0) a.mean2[tid] = (float)touch;     // (never taken: keeps the warm-up loads)
 }
 
 struct MlpBwdArgs {
@@ -636,15 +588,12 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
     {
         PnlStage<MT> sr;
         pnl_stage_load<MT>(sr, rs_dout, 256, m0, 0, tid);
-        if (PNL_TOUCH) {     // see pnl_l2_touch; behind the panel's loads in the memory queue
-            pnl_pin_vmem();
-            const uint32_t t0 = pnl_l2_touch(a.w2n, 1024L * 256 * 4, tid), t1 = pnl_l2_touch(a.w1n, 1024L * 256 * 4, tid), t2 = pnl_l2_touch(a.wpn, 256L * 256 * 4, tid);
-            pnl_pin_vmem();
-            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
-            touch = t0 ^ t1 ^ t2;
-        } else {
-            pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
-        }
+        // L2 warm-up (pnl_l2_touch), behind the panel's loads in the memory queue
+        pnl_pin_vmem();
+        const uint32_t t0 = pnl_l2_touch(a.w2n, 1024L * 256 * 4, tid), t1 = pnl_l2_touch(a.w1n, 1024L * 256 * 4, tid), t2 = pnl_l2_touch(a.wpn, 256L * 256 * 4, tid);
+        pnl_pin_vmem();
+        pnl_stage_store<MT, false>(sr, P, P + PNL_IMG(MT), tid);
+        touch = t0 ^ t1 ^ t2;
     }
     pnl_lds_barrier();
     const long NP32 = ((long)NP + 31) / 32 * 32;
@@ -693,7 +642,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
                 bf16x4 h, l;
                 split4(dh, h, l);
                 pnl_img_put(Ah, Ah + PNL_IMG(MT), 16 * i + l15, nl, h, l);
-                if (PNL_ST(valid[i]) && a.dhs) *(f32x4*)(a.dhs + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
+                if (valid[i] && a.dhs) *(f32x4*)(a.dhs + mrow[i] * 1024 + n) = pnl_pack_hl(h, l);
                 cs += dh;
             }
             for (int e = 0; e < 4; ++e) cs[e] = row16_sum(cs[e]);
@@ -768,7 +717,7 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
             bf16x4 h, l;
             split4(dxv, h, l);
             pnl_img_put(P, P + PNL_IMG(MT), 16 * i + l15, n, h, l);     // (the dout image is dead since the last hidden chunk)
-            if (PNL_ST(valid[i])) *(f32x4*)(a.dx1 + mrow[i] * 256 + n) = dxv;
+            if (valid[i]) *(f32x4*)(a.dx1 + mrow[i] * 256 + n) = dxv;
         }
         for (int e = 0; e < 4; ++e) {
             ag[t][e] = row16_sum(ag[t][e]);
@@ -797,8 +746,8 @@ __global__ void __launch_bounds__(PNL_THREADS) k_mlp_bwd(MlpBwdArgs a) {
         const int n = 32 * wave + 16 * t + 4 * g;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-            if (PNL_ST(valid[i])) *(f32x4*)(a.dao + mrow[i] * 256 + n) = dq[t][i];
+            if (valid[i]) *(f32x4*)(a.dao + mrow[i] * 256 + n) = dq[t][i];
     }
-    if (PNL_TOUCH && a.NP < 0) a.dao[tid] = (float)touch;       // (never taken: keeps the warm-up loads)
+    if (a.NP < 0) a.dao[tid] = (float)touch;       // (never taken: keeps the warm-up loads)
 }
 

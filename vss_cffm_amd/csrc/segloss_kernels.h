@@ -45,14 +45,7 @@ __device__ __forceinline__ float upce_exp2(float x) {
     return __builtin_amdgcn_exp2f(x);
 #endif
 }
-#ifndef UPCE_ABLATE
-#define UPCE_ABLATE 0
-#endif
-#if UPCE_ABLATE & 1          // timing experiments only: no exponential
-#define UPCE_EXP(x) (x)
-#else
 #define UPCE_EXP(x) upce_exp2(x)
-#endif
 #define UPCE_ROWS_KPER 32        // forward staging of token-row logits: threads per cell (one 128-byte run of classes per pass)
 #define UPCE_KP(K) (((K) + 3) & ~3)       // classes padded to whole 16-byte groups (padding logits = -1e30: exp -> 0, never the arg-max)
 
@@ -121,12 +114,7 @@ __device__ __forceinline__ float upce_max3(float a, float b, float c) {
 // ~1e-7 relative), plus `off` (minus the bound / the log-sum-exp): two class pairs x (1 mul + 4 fma)
 __device__ __forceinline__ void upce_interp4(const float* s_l, int a, int b, int c, int d, int k4, const UpceW& w, f32x2 off, f32x2& lo, f32x2& hi) {
     const f32x4 ta = ((const f32x4*)(s_l + a))[k4];
-#if UPCE_ABLATE & 2          // timing experiments only: one LDS read instead of four
-    const f32x4 tb = ta, tc = ta, td = ta;
-    (void)b; (void)c; (void)d;
-#else
     const f32x4 tb = ((const f32x4*)(s_l + b))[k4], tc = ((const f32x4*)(s_l + c))[k4], td = ((const f32x4*)(s_l + d))[k4];
-#endif
     lo = pk_fma(UPCE_LO(td), w.w11, pk_fma(UPCE_LO(tc), w.w10, pk_fma(UPCE_LO(tb), w.w01, pk_fma(UPCE_LO(ta), w.w00, off))));
     hi = pk_fma(UPCE_HI(td), w.w11, pk_fma(UPCE_HI(tc), w.w10, pk_fma(UPCE_HI(tb), w.w01, pk_fma(UPCE_HI(ta), w.w00, off))));
 }
