@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 9
+#define CFFM_ABI_VERSION 10
 
 typedef struct cffm_geom {
     int B, H0, W0;      /* clips, unpadded 1/8-scale grid                                   */
@@ -73,6 +73,19 @@ long cffm_layer_scratch_floats(const cffm_geom* g);
 int cffm_profile_enable(long long stage_mask); /* bit i = stage i; 0 off; -1 all (perturbs: two event records per launch) */
 int cffm_profile_sample_every(int period); /* time every period-th launch of an enabled stage only (1 = all; counted from the next cffm_profile_enable) */
 int cffm_side_streams(int on); /* 0: parameter-gradient work stays on the caller's stream (per-kernel timing); returns the previous setting */
+/* ABI 10: branches for the caller.  cffm_branch_begin(stream, i), i = 0..3: a library-owned stream ordered behind everything issued on `stream`
+ * so far (or `stream` itself when side streams are off / unavailable); pass it as the `stream` argument of independent stage calls (the head's
+ * per-scale embedding chains of cffm_head.py:102-119, weight vs input gradients of a classifier); cffm_branch_join(stream): `stream` continues
+ * behind every branch.  Tensors a branch touches must outlive the join.  Stage calls that use library-owned scratch (cffm_linear_bwd_weight,
+ * cffm_linear_bwd_weight_group, cffm_colsum) take it from a pool of the branch they are issued on, so they may run on different branches at
+ * the same time; every other entry point with scratch of its own (the layer / block / gtc calls) belongs on the caller's stream. */
+void* cffm_branch_begin(void* stream, int i);
+int cffm_branch_join(void* stream);
+/* the same in two steps, for callers that launch their own (longest) chain FIRST: under stream capture the first-launched dependant of a node keeps
+ * the node's hardware queue.  cffm_branch_mark(stream): remember this point of `stream` (returns 1 when branches are available);
+ * cffm_branch_take(stream, i): branch i ordered behind the marked point (or `stream` itself). */
+int cffm_branch_mark(void* stream);
+void* cffm_branch_take(void* stream, int i);
 int cffm_profile_stage_count(void);
 int cffm_profile_null_pair(void* stream); /* stage "event_pair_null": two event records with nothing between (the interval's own cost) */
 const char* cffm_profile_stage_name(int i);
@@ -236,6 +249,15 @@ int cffm_gtc_block_forward(const cffm_gtc_params* p, const float* x, const float
 int cffm_gtc_block_backward(const cffm_gtc_params* p, const cffm_gtc_grads* g, const float* x, const float* centers, const float* dout,
                             float* dx, float* dcenters, float* ws, int B, int T, int K, void* stream);
 
+/* ABI 10: the composed embedding weights of ops.segformer_fuse (cffm_head.py:102-119 without the 1024-channel concat): mats[i] [e][C_i] =
+ * Wf_i W_i (Wf_i = input-channel block k - 1 - i of linear_fuse.conv.weight [e][k e], W_i = linear_c{i+1}.proj.weight), d [e] = sum_i Wf_i b_i;
+ * and the gradients of the nine tensors from dmats / dd.  The k products run on branches of their own (cffm_branch_begin). */
+int cffm_fuse_compose_fwd(const float* fuse_w, const float* const* lin_w /* host [k] */, const float* const* lin_b /* host [k] */,
+                          const int* C_in /* host [k] */, int k /* <= 4 */, int e /* 256 */, float* const* mats /* host [k] */, float* d, void* stream);
+int cffm_fuse_compose_bwd(const float* fuse_w, const float* const* lin_w, const float* const* lin_b, const int* C_in, int k, int e,
+                          const float* const* dmats /* host [k] */, const float* dd, float* dfuse_w /* [e][k e] */, float* const* dlin_w /* host [k] */,
+                          float* const* dlin_b /* host [k] */, void* stream);
+
 /* ---- SegFormer embedding in front of the hot path, without the 1024-channel concat ----
  * Replaces cffm_head.py:102-119 (4 x `MLP` embed, 3 x bilinear resize to the 1/4 map, torch.cat, 1x1 `linear_fuse.conv`):
  * conv(cat_i up_i(W_i c_i + b_i)) = sum_i up_i((Wf_i W_i) c_i) + sum_i Wf_i b_i.  The host embeds every scale once at its own
@@ -268,6 +290,9 @@ int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse
  * decode_head.py:805-835); part records are ordered map-major (cffm_upce_blocks(M,H,W) / M per map), so the caller weights them. */
 int cffm_upce_maps_fwd(const float* logits, const long long* labels, const int* label_idx, float* lse, float* part, int M, int K, int h,
                        int w, int H, int W, int ignore_index, int inner, long ms_outer, long ms_inner, int ks, int ps, void* stream);
+/* ABI 10: the two loss scalars from those records on the device: out[0] = sum_m wl[m] * sum(loss records of map m), out[1] = sum_m wh[m] *
+ * sum(hit records of map m), accumulated in double in a fixed order (wl, wh: M doubles each, device) -- decode_head.py:805-835's weighting. */
+int cffm_upce_maps_finalize(const float* part, int M, long per, const double* wl, const double* wh, float* out /* [2] */, void* stream);
 int cffm_upce_maps_bwd(const float* logits, const long long* labels, const int* label_idx, const float* lse, const float* gscale,
                        const float* map_scale, float scale, float* dlogits, int M, int K, int h, int w, int H, int W, int ignore_index,
                        int inner, long ms_outer, long ms_inner, int ks, int ps, void* stream);

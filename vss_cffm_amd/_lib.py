@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcffm_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp, ci, cl, cd, cf = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float
 
@@ -51,6 +51,12 @@ SIGNATURES = {
     'cffm_profile_enable': (ci, [C.c_longlong]),
     'cffm_profile_sample_every': (ci, [ci]),
     'cffm_side_streams': (ci, [ci]),
+    'cffm_branch_begin': (vp, [vp, ci]),
+    'cffm_branch_join': (ci, [vp]),
+    'cffm_branch_mark': (ci, [vp]),
+    'cffm_branch_take': (vp, [vp, ci]),
+    'cffm_fuse_compose_fwd': (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp]),
+    'cffm_fuse_compose_bwd': (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
     'cffm_profile_stage_count': (ci, []),
     'cffm_profile_null_pair': (ci, [vp]),
     'cffm_profile_stage_name': (C.c_char_p, [ci]),
@@ -130,6 +136,7 @@ SIGNATURES = {
     'cffm_upce_blocks': (cl, [ci, ci, ci]),
     'cffm_upce_fwd': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     'cffm_upce_bwd': (ci, [vp, vp, vp, vp, C.c_float, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    'cffm_upce_maps_finalize': (ci, [vp, ci, cl, vp, vp, vp, vp]),
     'cffm_upce_maps_fwd': (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, ci, ci, vp]),
     'cffm_upce_maps_bwd': (ci, [vp, vp, vp, vp, vp, vp, C.c_float, vp, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, ci, ci, vp]),
     'cffm_adamw_step': (ci, [vp, ci, cd, cd, cd, cd, cd, ci, vp]),

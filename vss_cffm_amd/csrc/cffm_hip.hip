@@ -299,19 +299,25 @@ long cffm_layer_scratch_floats(const cffm_geom* g) { return scratch_layout(g).to
 // ------------------------------------------------------------------------------------------- internal scratch
 // Small library-owned device buffer for the block-partial records of the two-stage reductions
 // (grows on demand; stream-ordered reuse, one stream at a time as the ABI's threading rule says).
-static float* g_scr = nullptr;
-static size_t g_scr_floats = 0;
+// One pool per stream a stage call can arrive on: the caller's (0) and the four branches of cffm_branch_begin / _take (1..4) -- stage calls
+// that need scratch (split-K slabs of the weight gradients, column-sum records) may then run on different branches at the same time.
+// ScratchFor selects the pool for the duration of a public stage call from its `stream` argument; everything else uses pool 0.
+static float* g_scr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+static size_t g_scr_floats[5] = {0, 0, 0, 0, 0};
+static int g_scr_sel = 0;
 extern "C++" __attribute__((visibility("hidden"))) float* lib_scratch(size_t nfloats) {
-    if (nfloats <= g_scr_floats) return g_scr;
+    float*& buf = g_scr[g_scr_sel];
+    size_t& have = g_scr_floats[g_scr_sel];
+    if (nfloats <= have) return buf;
 #ifdef CFFM_EMU
-    free(g_scr);
-    g_scr = (float*)malloc(nfloats * sizeof(float));
+    free(buf);
+    buf = (float*)malloc(nfloats * sizeof(float));
 #else
-    if (g_scr) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr); }
-    if (hipMalloc((void**)&g_scr, nfloats * sizeof(float)) != hipSuccess) g_scr = nullptr;
+    if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); }
+    if (hipMalloc((void**)&buf, nfloats * sizeof(float)) != hipSuccess) buf = nullptr;
 #endif
-    g_scr_floats = g_scr ? nfloats : 0;
-    return g_scr;
+    have = buf ? nfloats : 0;
+    return buf;
 }
 // second scratch buffer, for work issued on the library's side stream (runs concurrently with users of lib_scratch)
 static float* g_scr2 = nullptr;
@@ -368,6 +374,17 @@ struct SideStream {
 #endif
 };
 static SideStream g_side;
+struct ScratchFor {       // RAII: pool of the branch `stream` is (cffm_branch_begin / _take), else the caller's pool
+    explicit ScratchFor(void* stream) {
+        g_scr_sel = 0;
+#ifndef CFFM_EMU
+        for (int i = 0; i < 4; ++i)
+            if (stream && (hipStream_t)stream == g_side.st[i]) g_scr_sel = i + 1;
+#endif
+        (void)stream;
+    }
+    ~ScratchFor() { g_scr_sel = 0; }
+};
 static int stream_is_capturing(hipStream_t st) {
 #ifdef CFFM_EMU
     (void)st;
@@ -517,6 +534,65 @@ static void side_join_all(hipStream_t main) {
     (void)hipGetLastError();
 #endif
     (void)main;
+}
+// ---- branches for the CALLER (ABI 10): independent stage calls of the head's rows path side by side -------------------------------
+// The head around the hot path (rows f.1 / f.2 of SURVEY 8: embedding per scale, composed weights, classifiers) is a sequence of stage
+// calls from Python, most of them 5-15 us kernels that do not depend on each other (four scales, weight vs input gradients): on ONE
+// stream a replayed step pays ~5 us of launch latency per kernel (profiles/r06_head_timeline_before.txt: ~60 such kernels).
+// cffm_branch_begin(stream, i) hands out library-owned stream i (0..3), ordered behind everything issued on `stream` so far; the caller
+// passes it as the `stream` argument of the stage calls of that branch; cffm_branch_join(stream) makes `stream` continue behind all
+// branches.  Under stream capture the branches become parallel branches of the graph.  Rules: every tensor a branch touches stays alive
+// until the join; the stage calls that use the library's own scratch (weight gradients, column sums) take it from the pool of the
+// branch they are issued on (ScratchFor); with side streams off (cffm_side_streams(0)), on failure, or in the emulator build the
+// caller's own stream comes back and everything simply runs in order.
+// Launch ORDER matters under capture (see side_fork_mark): of the dependants of one node the graph executor keeps the FIRST-launched on the
+// node's own hardware queue, the others start on other queues ~10 us later each.  So the caller marks the fork point (cffm_branch_mark), launches
+// its own -- longest -- chain on `stream` first and only then takes the branches (cffm_branch_take) for the shorter ones.
+// cffm_branch_begin = mark + take of one branch at the current point.
+int cffm_branch_mark(void* stream) {
+#ifndef CFFM_EMU
+    hipStream_t main = (hipStream_t)stream;
+    if (!side_init(main)) return 0;
+    g_side.ns = 4;
+    for (int i = 0; i < 4; ++i)
+        if (hipEventRecord(g_side.fork[i], main) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return 1;
+#else
+    (void)stream;
+    return 0;
+#endif
+}
+void* cffm_branch_take(void* stream, int i) {
+#ifndef CFFM_EMU
+    if (i < 0 || i > 3 || !g_side.on) return stream;
+    hipStream_t s = g_side.st[i];
+    if (hipStreamWaitEvent(s, g_side.fork[i], 0) == hipSuccess) {
+        g_side.used |= 1u << i;
+        return (void*)s;
+    }
+    (void)hipGetLastError();
+#endif
+    (void)i;
+    return stream;
+}
+void* cffm_branch_begin(void* stream, int i) {
+    hipStream_t main = (hipStream_t)stream;
+#ifndef CFFM_EMU
+    if (i < 0 || i > 3 || !side_init(main)) return stream;
+    g_side.ns = 4;
+    hipStream_t s = g_side.st[i];
+    if (hipEventRecord(g_side.fork[i], main) == hipSuccess && hipStreamWaitEvent(s, g_side.fork[i], 0) == hipSuccess) {
+        g_side.used |= 1u << i;
+        return (void*)s;
+    }
+    (void)hipGetLastError();
+#endif
+    (void)i;
+    return (void*)main;
+}
+int cffm_branch_join(void* stream) {
+    side_join_all((hipStream_t)stream);
+    return 0;
 }
 // event helpers of the deferred join (no-ops when the work ran on `main` itself)
 static void side_record(hipStream_t side, hipStream_t main, void* ev) {
@@ -946,6 +1022,7 @@ int cffm_linear_bwd_input(const float* dy, const float* w, float* dx, long M, in
     return gemm_nn(dy, w, dx, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_input: gemm failed") : 0;
 }
 int cffm_linear_bwd_weight(const float* dy, const float* x, float* dw, long M, int N, int K, void* stream) {
+    ScratchFor pool(stream);
     PROF(ST_GEMM);
     return gemm_tn(dy, x, dw, M, N, K, (hipStream_t)stream) ? fail(-3, "linear_bwd_weight: gemm failed") : 0;
 }
@@ -954,6 +1031,7 @@ int cffm_linear_bwd_weight_group(const cffm_wgrad* problems, int n, void* stream
     REQUIRE(problems && n >= 1 && n <= 4, "linear_bwd_weight_group: 1..4 problems");
     static_assert(sizeof(cffm_wgrad) == sizeof(GemmTN), "wgrad layout");
     for (int i = 0; i < n; ++i) REQUIRE(problems[i].dy && problems[i].x && problems[i].dw, "linear_bwd_weight_group: null operand");
+    ScratchFor pool(stream);
     PROF(ST_GEMM);
     if (gemm_tn_group((const GemmTN*)problems, n, (hipStream_t)stream)) return fail(-3, "linear_bwd_weight_group: gemm failed");
     CHECK_LAUNCH("linear_bwd_weight_group");
@@ -1043,6 +1121,7 @@ int cffm_linear_residual_fwd(const float* x, const float* w, const float* b, con
 }
 
 int cffm_colsum(const float* a, long rows, int cols, float* out, void* stream) {
+    ScratchFor pool(stream);
     PROF(ST_COLSUM);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(a && out && cols >= 4 && cols % 4 == 0, "colsum: cols must be a multiple of 4");
@@ -2077,6 +2156,57 @@ static int segf_maps(SegfMaps& mp, const int* h, const int* w, int nmaps, int H,
     }
     return 0;
 }
+// ---- composed embedding weights (ABI 10) --------------------------------------------------------------------------------------------
+// A_i = Wf_i W_i for the k <= 4 scales (Wf_i = input-channel block k - 1 - i of linear_fuse.conv.weight [e][k e], read in place through
+// its leading dimension; W_i = linear_c{i+1}.proj.weight [e][C_i]) and d = sum_i Wf_i b_i -- what ops.segformer_fuse feeds the per-scale
+// embedding GEMMs (cffm_head.py:102-119 without the 1024-channel concat).  The k products are independent 10-MFLOP GEMMs: in the backward
+// (2 k of them) each scale on its own branch; round 5 ran them from Python behind two layout copies of the fuse weight, with torch's
+// cat / gemv / ger for the constant (97 us of a replayed head step, 120 us for the backward).
+static void fuse_bias_ptrs(FuseBias& fb, const float* const* lin_b, float* const* dlin_b, int k) {
+    for (int j = 0; j < 4; ++j) { fb.b[j] = j < k ? lin_b[k - 1 - j] : nullptr; fb.db[j] = (j < k && dlin_b) ? dlin_b[k - 1 - j] : nullptr; }
+}
+int cffm_fuse_compose_fwd(const float* fuse_w, const float* const* lin_w, const float* const* lin_b, const int* C_in, int k, int e,
+                          float* const* mats, float* d, void* stream) {
+    REQUIRE(fuse_w && lin_w && lin_b && C_in && mats && d && k >= 1 && k <= 4 && e >= 64 && e % 64 == 0, "fuse_compose_fwd: bad arguments");
+    for (int i = 0; i < k; ++i) REQUIRE(lin_w[i] && lin_b[i] && mats[i] && C_in[i] >= 4 && C_in[i] % 4 == 0, "fuse_compose_fwd: bad scale %d", i);
+    hipStream_t st = (hipStream_t)stream;
+    FuseBias fb;
+    fuse_bias_ptrs(fb, lin_b, nullptr, k);
+    // (one behind the other: these are the first nodes of a replayed step, where starting a second hardware queue costs more -- ~11 us per
+    // branch, profiles/r06_head_timeline_branches_first_version.txt -- than a 7 us GEMM)
+    for (int i = 0; i < k; ++i) {
+        // A_i [e][C_i] = Wf_i [e][e] (lda = k e) x W_i [e][C_i]
+        if (gemm_split_launch<false, true>(fuse_w + (long)(k - 1 - i) * e, lin_w[i], mats[i], e, C_in[i], e, k * e, C_in[i], C_in[i], 1, st))
+            return fail(-3, "fuse_compose_fwd: gemm failed");
+    }
+    CFFM_LAUNCH(k_fuse_const, ((e + 3) / 4), (256), 0, st, fuse_w, fb, k, e, d);
+    CHECK_LAUNCH("fuse_compose_fwd");
+    return 0;
+}
+// gradients of the nine tensors from dmats[i] [e][C_i] and dd [e]: dfuse_w [e][k e] (every element written), dlin_w[i] [e][C_i], dlin_b[i] [e]
+int cffm_fuse_compose_bwd(const float* fuse_w, const float* const* lin_w, const float* const* lin_b, const int* C_in, int k, int e,
+                          const float* const* dmats, const float* dd, float* dfuse_w, float* const* dlin_w, float* const* dlin_b, void* stream) {
+    REQUIRE(fuse_w && lin_w && lin_b && C_in && dmats && dd && dfuse_w && dlin_w && dlin_b && k >= 1 && k <= 4 && e >= 64 && e % 64 == 0,
+            "fuse_compose_bwd: bad arguments");
+    for (int i = 0; i < k; ++i)
+        REQUIRE(lin_w[i] && lin_b[i] && dmats[i] && dlin_w[i] && dlin_b[i] && C_in[i] >= 4 && C_in[i] % 4 == 0, "fuse_compose_bwd: bad scale %d", i);
+    hipStream_t st = (hipStream_t)stream;
+    cffm_branch_mark(stream);
+    for (int i = 0; i < k; ++i) {          // (the caller's own chain first: see cffm_branch_mark)
+        hipStream_t s = i ? (hipStream_t)cffm_branch_take(stream, i) : st;
+        const float* wf = fuse_w + (long)(k - 1 - i) * e;
+        // dWf_i [e][e] (ldc = k e) = dA_i [e][C_i] x W_i^T;  dW_i [e][C_i] = Wf_i^T x dA_i (one slice: no library scratch on a branch)
+        if (gemm_split_launch<false, false>(dmats[i], lin_w[i], dfuse_w + (long)(k - 1 - i) * e, e, e, C_in[i], C_in[i], C_in[i], k * e, 1, s) ||
+            gemm_split_launch<true, true>(wf, dmats[i], dlin_w[i], e, C_in[i], e, k * e, C_in[i], C_in[i], 1, s))
+            return fail(-3, "fuse_compose_bwd: gemm failed");
+    }
+    cffm_branch_join(stream);
+    FuseBias fb;
+    fuse_bias_ptrs(fb, lin_b, dlin_b, k);
+    CFFM_LAUNCH(k_fuse_const_bwd, (k * e / 64), (256), 0, st, fuse_w, dd, fb, k, e, dfuse_w);
+    CHECK_LAUNCH("fuse_compose_bwd");
+    return 0;
+}
 int cffm_segfuse_fwd(float* y, const float* d, const float* const z[3], const int h[3], const int w[3], int nmaps, int N, int H,
                      int W, void* stream) {
     REQUIRE(y && d && N >= 0 && (nmaps == 0 || (z && h && w)), "segfuse_fwd: bad arguments");
@@ -2196,6 +2326,14 @@ int cffm_upce_maps_fwd(const float* logits, const long long* labels, const int* 
     REQUIRE(cffm_upce_blocks(M, H, W) < (1L << 31), "upce_fwd: too many tiles");
     CFFM_LAUNCH(k_upce_fwd, ((unsigned)cffm_upce_blocks(M, H, W)), (256), lds, st, logits, labels, lse, part, G);
     CHECK_LAUNCH("upce_fwd");
+    return 0;
+}
+// out[0] = sum_m wl[m] * (sum of map m's loss records), out[1] = sum_m wh[m] * (sum of its hit records); part as cffm_upce_maps_fwd left it
+// (cffm_upce_blocks(M, H, W) / M records per map, map-major); wl / wh: M doubles each on the device
+int cffm_upce_maps_finalize(const float* part, int M, long per, const double* wl, const double* wh, float* out, void* stream) {
+    REQUIRE(part && wl && wh && out && M >= 1 && per >= 1 && per < (1L << 30), "upce_maps_finalize: bad arguments");
+    CFFM_LAUNCH(k_upce_finalize, (1), (256), 0, (hipStream_t)stream, part, M, (int)per, wl, wh, out);
+    CHECK_LAUNCH("upce_maps_finalize");
     return 0;
 }
 int cffm_upce_bwd(const float* logits, const long long* labels, const float* lse, const float* gscale, float scale,

@@ -117,7 +117,7 @@ template <bool DY_PRE = false, bool X_PRE = false>
 static int gemm_tn_split(const float* dy, const float* x, float* dw, long M, int N, int K, hipStream_t st) {
     // 128x128 tiles halve the operand re-reads through the CU load path (the bound of these kernels: see gemm_kernels.h);
     // enough contraction splits to give every CU a workgroup
-    const int big = (N >= 128 && K >= 128);
+    const int big = (N > 96 && K >= 128);   // (N = 124: the head's classifiers -- one ragged 128-row tile beats two 64-row ones: 84 -> ? us)
     const int tiles = big ? ((N + 127) / 128) * ((K + 127) / 128) : ((N + 63) / 64) * ((K + 63) / 64);
     int ksplit = (320 + tiles - 1) / tiles;
     const int maxsplit = (int)((M + 127) / 128);   // at least 128 rows of the contraction per split

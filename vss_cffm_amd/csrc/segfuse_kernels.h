@@ -218,3 +218,47 @@ __global__ void __launch_bounds__(256) k_segfuse_bwd(const float* __restrict__ g
         ((f32x4*)(mp.dz[m] + ((long)n * h * w + (long)qy * w + qx0 + wave) * SEGF_C))[lane] = t;
     }
 }
+
+// --------------------------------------------------------------------------- composed embedding weights: the constant and its backward
+// d[r] = sum_j fuse_w[r][j * e + c] * b_j[c] (column block j of the [e][k e] fuse weight carries scale k - 1 - j: the reference's cat order
+// c4, c3, c2, c1 -- cffm_head.py:112-119): the bias of the four embeddings pushed through linear_fuse.conv.  One wave per output row.
+struct FuseBias { const float* b[4]; float* db[4]; };      // b[j] = bias of column block j (i.e. of scale k - 1 - j), e floats each
+__global__ void __launch_bounds__(256) k_fuse_const(const float* __restrict__ fw, FuseBias fb, int k, int e, float* __restrict__ d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= e) return;
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j)
+        for (int c = lane; c < e; c += 64) acc += fw[(long)row * k * e + j * e + c] * fb.b[j][c];
+    acc = wave_sum(acc);
+    if (lane == 0) d[row] = acc;
+}
+// backward of the constant: dfw[r][j e + c] += dd[r] * b_j[c] (dfw already holds dA W^T of the composed matrices), db_j[c] = sum_r fw[r][j e + c] dd[r].
+// A workgroup owns 64 columns of the [e][k e] matrix; its four waves take every fourth row, the four column sums meet in LDS in a fixed order.
+__global__ void __launch_bounds__(256) k_fuse_const_bwd(const float* __restrict__ fw, const float* __restrict__ dd, FuseBias fb, int k, int e,
+                                                         float* __restrict__ dfw) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6, j = col / e, c = col % e;
+    const float b = fb.b[j][c];
+    float acc = 0.f;
+    for (int r0 = wv; r0 < e; r0 += 32) {          // eight rows in flight per lane (a row at a time: 64 dependent round trips, 22 us)
+        float w8[8], d8[8], g8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            const long o = (long)r * k * e + col;
+            g8[u] = r < e ? dd[r] : 0.f;
+            w8[u] = r < e ? fw[o] : 0.f;
+            d8[u] = r < e ? dfw[o] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            acc += w8[u] * g8[u];
+            if (r < e) dfw[(long)r * k * e + col] = d8[u] + g8[u] * b;
+        }
+    }
+    red[wv][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (wv == 0) fb.db[j][c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+

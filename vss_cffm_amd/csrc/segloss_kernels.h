@@ -632,3 +632,33 @@ __global__ void __launch_bounds__(256) k_vc_counts(const long long* __restrict__
         if (v) atomicAdd(&counts[2 * i + threadIdx.x], (unsigned long long)v);
     }
 }
+
+// The loss scalars on the device (round 6): out[0] = sum_m wl[m] * sum_j part[m][j][0] (the weighted cross-entropy sum), out[1] = sum_m wh[m] *
+// sum_j part[m][j][1] (the weighted hit count) from the per-workgroup records of k_upce_fwd, in double, in a fixed order (thread t sums records
+// t, t + 256, ... of every map, then a tree over the 256 partial sums): what ~10 torch kernels (view / double / sum / mul / sum / float, twice)
+// did after every forward -- 60 us of a replayed head step.  One workgroup.
+__global__ void __launch_bounds__(256) k_upce_finalize(const float* __restrict__ part, int M, int per, const double* __restrict__ wl,
+                                                        const double* __restrict__ wh, float* __restrict__ out) {
+    __shared__ double red[2][256];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int m = 0; m < M; ++m) {
+        double sa = 0.0, sb = 0.0;
+        for (int j = t; j < per; j += 256) {
+            const f32x2 v = *(const f32x2*)(part + 2 * ((long)m * per + j));
+            sa += (double)v[0];
+            sb += (double)v[1];
+        }
+        a += sa * wl[m];
+        b += sb * wh[m];
+    }
+    red[0][t] = a;
+    red[1][t] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) { out[0] = (float)red[0][0]; out[1] = (float)red[1][0]; }
+}
+

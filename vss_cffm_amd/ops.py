@@ -46,6 +46,31 @@ def _stream(t):
     return C.c_void_p(0)
 
 
+def _branch(lib, st, i):
+    """library stream i (0..3) ordered behind everything issued on `st` so far (cffm_branch_begin); everything a branch touches must stay
+    referenced until _join(lib, st)"""
+    return C.c_void_p(lib.cffm_branch_begin(st, i))
+
+
+def _mark(lib, st):
+    """remember this point of `st` for _take: the caller launches its own (longest) chain first, the branches afterwards (under stream
+    capture the first-launched dependant of a node keeps the node's hardware queue)"""
+    lib.cffm_branch_mark(st)
+
+
+def _take(lib, st, i):
+    return C.c_void_p(lib.cffm_branch_take(st, i))
+
+
+def _join(lib, st):
+    lib.cffm_branch_join(st)
+
+
+class _WGrad(C.Structure):
+    """cffm_wgrad"""
+    _fields_ = [('dy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('M', C.c_long), ('N', C.c_int), ('K', C.c_int)]
+
+
 def _require_device(t, what):
     if _lib._override is None and not t.is_cuda:
         raise _lib.CffmError('%s: the CFFM hot path runs only on the GPU (got a %s tensor); there is no CPU '
@@ -381,19 +406,26 @@ class _SegFuseFn(torch.autograd.Function):
             _require_device(c, 'segformer_fuse operand')
         n, _, H, W = feats[0].shape
         st, dev = _stream(feats[0]), feats[0].device
-        toks, zs = [], []
+        toks, zs, keep = [], [], []
         for c, a in zip(feats, mats):
             if c.dim() != 4 or c.shape[0] != n or a.shape != (256, c.shape[1]):
                 raise _lib.CffmError('segformer_fuse: feature %s does not fit matrix %s' % (tuple(c.shape), tuple(a.shape)))
-            c = c.contiguous()
+        # every scale is an independent chain NCHW -> token rows -> Linear: the 1/4-scale one (three quarters of the bytes) on the caller's
+        # stream, the others on branches beside it (one stream: 107 us of a replayed head step for 64 us of the largest chain)
+        _mark(lib, st)
+        for i in range(k):
+            c, a = feats[i].contiguous(), mats[i]
             ci, p = c.shape[1], c.shape[2] * c.shape[3]
             t = torch.empty(n * p, ci, dtype=torch.float32, device=dev)        # token rows [N*h*w, C_i]
             z = torch.empty(n * p, 256, dtype=torch.float32, device=dev)
             if n * p:
-                _lib.check(lib.cffm_transpose(_ptr(c), _ptr(t), n, ci, p, ci * p, ci * p, st), lib)
-                _lib.check(lib.cffm_linear_fwd(_ptr(t), _ptr(a), _ptr(z), n * p, 256, ci, st), lib)
+                s = _take(lib, st, i) if i else st
+                _lib.check(lib.cffm_transpose(_ptr(c), _ptr(t), n, ci, p, ci * p, ci * p, s), lib)
+                _lib.check(lib.cffm_linear_fwd(_ptr(t), _ptr(a), _ptr(z), n * p, 256, ci, s), lib)
             toks.append(t)
             zs.append(z)
+            keep.append(c)
+        _join(lib, st)
         hs = (C.c_int * 3)(*([c.shape[2] for c in feats[1:]] + [1] * (4 - k)))
         ws = (C.c_int * 3)(*([c.shape[3] for c in feats[1:]] + [1] * (4 - k)))
         zp = (C.c_void_p * 3)(*([z.data_ptr() for z in zs[1:]] + [None] * (4 - k)))
@@ -417,76 +449,100 @@ class _SegFuseFn(torch.autograd.Function):
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         dd = new(256)
         rows = n * H * W
+        dzs = [g.view(rows, 256)] + [new(n * s_[2] * s_[3], 256) for s_ in shapes[1:]]
+        if k > 1 and rows:
+            hs = (C.c_int * 3)(*([s_[2] for s_ in shapes[1:]] + [1] * (4 - k)))
+            ws = (C.c_int * 3)(*([s_[3] for s_ in shapes[1:]] + [1] * (4 - k)))
+            zp = (C.c_void_p * 3)(*([z.data_ptr() for z in dzs[1:]] + [None] * (4 - k)))
+            _lib.check(lib.cffm_segfuse_bwd(_ptr(g), zp, hs, ws, k - 1, n, H, W, st), lib)
+        # Behind the adjoint of the resizes everything is independent: branch 1 = the k weight gradients as ONE grouped launch and the
+        # column sum of g (both use the library's scratch: one after the other on one branch); the input gradients (Linear + back to NCHW)
+        # of the 1/4-scale map on the caller's stream, of the small maps on branches 2 / 3.  (One stream: 213 + 34 us of a replayed step.)
+        dmats = [new(256, s_[1]) for s_ in shapes]
+        live = [i for i, s_ in enumerate(shapes) if n * s_[2] * s_[3]]
+        for i in range(k):
+            if i not in live:
+                dmats[i].zero_()
+        _mark(lib, st)
+        dfeats, keep = [None] * k, []
+
+        def dx_chain(i, sx):
+            s_, a, dz = shapes[i], mats[i], dzs[i]
+            ci, p = s_[1], s_[2] * s_[3]
+            if ctx.needs_input_grad[1 + i]:
+                dt, dc = new(n * p, ci), new(*s_)
+                if n * p:
+                    _lib.check(lib.cffm_linear_bwd_input(_ptr(dz), _ptr(a), _ptr(dt), n * p, 256, ci, sx), lib)
+                    _lib.check(lib.cffm_transpose(_ptr(dt), _ptr(dc), n, p, ci, ci * p, ci * p, sx), lib)
+                dfeats[i] = dc
+                keep.append(dt)
+        dx_chain(0, st)                                            # the 1/4-scale chain first: it keeps the caller's stream (and its queue)
         if rows:
-            _lib.check(lib.cffm_colsum(_ptr(g), rows, 256, _ptr(dd), st), lib)
+            # branch 1: the 1/4-scale weight gradient (three quarters of the rows); branch 2: the other scales' (one grouped call: the
+            # library groups what its grouped kernel takes and runs the rest one by one) and the column sum of g; branch 3: the small
+            # scales' input gradients.  (Weight gradients and column sums take their scratch from the branch's own pool.)
+            def wgrads(sel, sx):
+                sel = [i for i in sel if i in live]
+                if sel:
+                    pr = (_WGrad * len(sel))(*[_WGrad(dzs[i].data_ptr(), toks[i].data_ptr(), dmats[i].data_ptr(), n * shapes[i][2] * shapes[i][3], 256,
+                                                      shapes[i][1]) for i in sel])
+                    _lib.check(lib.cffm_linear_bwd_weight_group(pr, len(sel), sx), lib)
+            wgrads([0], _take(lib, st, 1))
+            s2 = _take(lib, st, 2)
+            _lib.check(lib.cffm_colsum(_ptr(g), rows, 256, _ptr(dd), s2), lib)
+            wgrads(range(1, k), s2)
         else:
             dd.zero_()
-        dzs = [g.view(rows, 256)] + [new(n * s[2] * s[3], 256) for s in shapes[1:]]
         if k > 1:
-            hs = (C.c_int * 3)(*([s[2] for s in shapes[1:]] + [1] * (4 - k)))
-            ws = (C.c_int * 3)(*([s[3] for s in shapes[1:]] + [1] * (4 - k)))
-            zp = (C.c_void_p * 3)(*([z.data_ptr() for z in dzs[1:]] + [None] * (4 - k)))
-            if rows:
-                _lib.check(lib.cffm_segfuse_bwd(_ptr(g), zp, hs, ws, k - 1, n, H, W, st), lib)
-        dfeats, dmats = [], []
-        for i, (s, t, a, dz) in enumerate(zip(shapes, toks, mats, dzs)):
-            ci, p = s[1], s[2] * s[3]
-            da = new(256, ci)
-            if n * p:
-                _lib.check(lib.cffm_linear_bwd_weight(_ptr(dz), _ptr(t), _ptr(da), n * p, 256, ci, st), lib)
-            else:
-                da.zero_()
-            dmats.append(da)
-            if ctx.needs_input_grad[1 + i]:
-                dt, dc = new(n * p, ci), new(*s)
-                if n * p:
-                    _lib.check(lib.cffm_linear_bwd_input(_ptr(dz), _ptr(a), _ptr(dt), n * p, 256, ci, st), lib)
-                    _lib.check(lib.cffm_transpose(_ptr(dt), _ptr(dc), n, p, ci, ci * p, ci * p, st), lib)
-                dfeats.append(dc)
-            else:
-                dfeats.append(None)
+            s3 = _take(lib, st, 3)
+            for i in range(1, k):
+                dx_chain(i, s3)
+        _join(lib, st)
         return (dd,) + tuple(dfeats) + tuple(dmats)
 
 
+def _ptr_array(ts):
+    """host array of the tensors' device pointers (NULL for None)"""
+    return (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
 class _ComposeFn(torch.autograd.Function):
-    """A_i = Wf_i W_i for every scale (Wf_i = the i-th [256,256] input-channel block of the fuse weight, cat order c_k..c_1) with
-    the library's GEMMs.  (As torch matmuls these 70-MFLOP products and their backward took 0.4 ms per step: rocBLAS runs each
-    on one 256x256 workgroup tile.)"""
+    """(A_1 .. A_k, d): A_i = Wf_i W_i for every scale (Wf_i = the i-th [256,256] input-channel block of the fuse weight, cat order
+    c_k..c_1, read in place through its leading dimension) and d = sum_i Wf_i b_i, as ONE library call per direction
+    (cffm_fuse_compose_fwd / _bwd: the k products side by side on branches of the library's streams).  (As torch matmuls these
+    70-MFLOP products and their backward took 0.4 ms per step; round 5 ran them as 4 + 8 stage GEMMs one behind the other with two
+    layout copies of the fuse weight and torch's cat / gemv / ger for the constant: 97 + 120 us of a replayed head step.)"""
 
     @staticmethod
-    def forward(ctx, fuse_w2d, *lin_w):
+    def forward(ctx, fuse_w2d, *wb):
         lib = _lib.get()
-        k, e = len(lin_w), fuse_w2d.shape[0]
-        st = _stream(fuse_w2d)
-        # the k input-channel blocks of the fuse weight as ONE [k, e, e] copy (block i = columns (k-1-i) e .. of the [e, k e] matrix)
-        stacked = fuse_w2d.view(e, k, e).permute(1, 0, 2).flip(0).contiguous()
-        blocks = [stacked[i] for i in range(k)]
-        lin_w = [w.contiguous() for w in lin_w]
-        mats = []
-        for wf, w in zip(blocks, lin_w):
-            a = torch.empty(e, w.shape[1], dtype=torch.float32, device=w.device)
-            _lib.check(lib.cffm_linear_bwd_input(_ptr(wf), _ptr(w), _ptr(a), e, e, w.shape[1], st), lib)      # Wf_i @ W_i
-            mats.append(a)
-        ctx.save_for_backward(*blocks, *lin_w)
-        return tuple(mats)
+        k, e = len(wb) // 2, fuse_w2d.shape[0]
+        fuse_w2d = fuse_w2d.contiguous()
+        lin_w, lin_b = [w.contiguous() for w in wb[:k]], [b_.contiguous() for b_ in wb[k:]]
+        dev = fuse_w2d.device
+        mats = [torch.empty(e, w.shape[1], dtype=torch.float32, device=dev) for w in lin_w]
+        d = torch.empty(e, dtype=torch.float32, device=dev)
+        cin = (C.c_int * k)(*[w.shape[1] for w in lin_w])
+        _lib.check(lib.cffm_fuse_compose_fwd(_ptr(fuse_w2d), _ptr_array(lin_w), _ptr_array(lin_b), cin, k, e, _ptr_array(mats), _ptr(d),
+                                             _stream(fuse_w2d)), lib)
+        ctx.save_for_backward(fuse_w2d, *lin_w, *lin_b)
+        return tuple(mats) + (d,)
 
     @staticmethod
-    def backward(ctx, *dmats):
+    def backward(ctx, *grads):
         lib = _lib.get()
-        k = len(dmats)
-        blocks, lin_w = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
-        e = blocks[0].shape[0]
-        st = _stream(blocks[0])
-        dstack = torch.empty(k, e, e, dtype=torch.float32, device=blocks[0].device)      # block i's gradient at [k-1-i]: column order of the weight
-        dws = []
-        for i, (wf, w, da) in enumerate(zip(blocks, lin_w, dmats)):
-            da = da.contiguous()
-            c = w.shape[1]
-            dw = torch.empty_like(w)
-            _lib.check(lib.cffm_linear_fwd(_ptr(da), _ptr(w), _ptr(dstack[k - 1 - i]), e, e, c, st), lib)      # dA W_i^T
-            _lib.check(lib.cffm_linear_bwd_weight(_ptr(wf), _ptr(da), _ptr(dw), e, e, c, st), lib)             # Wf_i^T dA
-            dws.append(dw)
-        return (dstack.permute(1, 0, 2).reshape(e, k * e),) + tuple(dws)                   # one copy into the [e, k e] layout
+        fuse_w2d = ctx.saved_tensors[0]
+        k = (len(ctx.saved_tensors) - 1) // 2
+        lin_w, lin_b = ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:]
+        e, dev = fuse_w2d.shape[0], fuse_w2d.device
+        dmats = [torch.zeros(e, w.shape[1], dtype=torch.float32, device=dev) if g is None else g.contiguous() for g, w in zip(grads[:k], lin_w)]
+        dd = torch.zeros(e, dtype=torch.float32, device=dev) if grads[k] is None else grads[k].contiguous()
+        dfw = torch.empty_like(fuse_w2d)
+        dws, dbs = [torch.empty_like(w) for w in lin_w], [torch.empty_like(b_) for b_ in lin_b]
+        cin = (C.c_int * k)(*[w.shape[1] for w in lin_w])
+        _lib.check(lib.cffm_fuse_compose_bwd(_ptr(fuse_w2d), _ptr_array(lin_w), _ptr_array(lin_b), cin, k, e, _ptr_array(dmats), _ptr(dd), _ptr(dfw),
+                                             _ptr_array(dws), _ptr_array(dbs), _stream(fuse_w2d)), lib)
+        return (dfw,) + tuple(dws) + tuple(dbs)
 
 
 def segformer_fuse(feats, lin_w, lin_b, fuse_w):
@@ -496,8 +552,8 @@ def segformer_fuse(feats, lin_w, lin_b, fuse_w):
     feats: [c1, c2, c3, c4] NCHW (c1 = the 1/4-scale map the others are resized to); lin_w / lin_b: the four `MLP.proj`
     weights [256,C_i] / biases in the same order; fuse_w: `linear_fuse.conv.weight` [256, 4*256, 1, 1] whose input-channel
     blocks are ordered c4, c3, c2, c1 (the reference's cat order).  Returns the pre-BatchNorm map [N,256,H,W].
-    The composed matrices Wf_i W_i come from the library's GEMMs too (_ComposeFn), the constant sum_i Wf_i b_i is one torch
-    matrix-vector product; autograd returns the gradients of the nine original tensors."""
+    The composed matrices Wf_i W_i and the constant sum_i Wf_i b_i come from one library call (_ComposeFn); autograd returns the
+    gradients of the nine original tensors."""
     k = len(feats)
     e = fuse_w.shape[0]
     if e != 256 or fuse_w.shape[1] != k * e:
@@ -506,9 +562,11 @@ def segformer_fuse(feats, lin_w, lin_b, fuse_w):
         _require_device(w, 'segformer_fuse weight')
         if w.shape[0] != e or w.shape[1] % 4:
             raise _lib.CffmError('segformer_fuse: embedding weight %s (rows of 16-byte multiples expected)' % (tuple(w.shape),))
-    w2d = fuse_w.reshape(e, k * e)
-    mats = _ComposeFn.apply(w2d, *lin_w)
-    d = w2d @ torch.cat([lin_b[k - 1 - j] for j in range(k)])          # sum_i Wf_i b_i: one matrix-vector product
+    for b_ in lin_b:
+        _require_device(b_, 'segformer_fuse bias')
+        if b_.shape != (e,):
+            raise _lib.CffmError('segformer_fuse: embedding bias %s, [%d] expected' % (tuple(b_.shape), e))
+    *mats, d = _ComposeFn.apply(fuse_w.reshape(e, k * e), *lin_w, *lin_b)
     return _SegFuseFn.apply(d, *feats, *mats)
 
 
@@ -565,34 +623,43 @@ class _Conv1x1Fn(torch.autograd.Function):
         if blocks is None:
             blocks = [(_to_rows(lib, dy.reshape(n, o, h, w) if dy.dim() == 5 else dy), 0, m)]
         dx = dwm = db = None
+        live = [(blk, r0, nr) for blk, r0, nr in blocks if nr]
+        # weight + bias gradient on a branch (ONE grouped launch over the blocks, then their column sums: both use the library's scratch, so
+        # one after the other), the input gradient beside them on the caller's stream
+        wparts, bparts = [], []
+        _mark(lib, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dy.device)
-            for blk, r0, nr in blocks:
-                if nr:
-                    _lib.check(lib.cffm_linear_bwd_input(_ptr(blk), _ptr(wm), C.c_void_p(dx.data_ptr() + 4 * r0 * c), nr, o, c, st), lib)
+            for blk, r0, nr in live:
+                _lib.check(lib.cffm_linear_bwd_input(_ptr(blk), _ptr(wm), C.c_void_p(dx.data_ptr() + 4 * r0 * c), nr, o, c, st), lib)
             if ctx.x_plain and m:
                 dxp = torch.empty(n, c, h, w, dtype=torch.float32, device=dy.device)
                 _lib.check(lib.cffm_transpose(_ptr(dx), _ptr(dxp), n, h * w, c, c * h * w, c * h * w, st), lib)
                 dx = dxp
             else:
                 dx = dx.permute(0, 3, 1, 2)
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and live:
+            # weight gradient of block j on branch 1 + j % 2, the column sums on branch 3 (each with the scratch pool of its branch)
+            if ctx.needs_input_grad[1]:
+                wparts = [torch.empty(o, c, dtype=torch.float32, device=dy.device) for _ in live]
+                sw = [_take(lib, st, 1), _take(lib, st, 2)] if len(live) > 1 else [_take(lib, st, 1)]
+                for j, ((blk, r0, nr), t) in enumerate(zip(live, wparts)):
+                    _lib.check(lib.cffm_linear_bwd_weight(_ptr(blk), C.c_void_p(rows.data_ptr() + 4 * r0 * c), _ptr(t), nr, o, c, sw[j % len(sw)]), lib)
+            if ctx.needs_input_grad[2]:
+                bparts = [torch.empty(o, dtype=torch.float32, device=dy.device) for _ in live]
+                sb = _take(lib, st, 3)
+                for (blk, r0, nr), t in zip(live, bparts):
+                    _lib.check(lib.cffm_colsum(_ptr(blk), nr, o, _ptr(t), sb), lib)
+        _join(lib, st)
         if ctx.needs_input_grad[1]:
-            dwm = (torch.empty if m else torch.zeros)(o, c, dtype=torch.float32, device=dy.device)     # (written whole by the first block)
-            for i, (blk, r0, nr) in enumerate(blocks):
-                if nr:
-                    tgt = dwm if i == 0 else torch.empty_like(dwm)
-                    _lib.check(lib.cffm_linear_bwd_weight(_ptr(blk), C.c_void_p(rows.data_ptr() + 4 * r0 * c), _ptr(tgt), nr, o, c, st), lib)
-                    if i:
-                        dwm += tgt
+            dwm = wparts[0] if wparts else torch.zeros(o, c, dtype=torch.float32, device=dy.device)
+            for t in wparts[1:]:
+                dwm += t
             dwm = dwm.view(o, c, 1, 1)
         if ctx.needs_input_grad[2]:
-            db = (torch.empty if m else torch.zeros)(o, dtype=torch.float32, device=dy.device)
-            for i, (blk, r0, nr) in enumerate(blocks):
-                if nr:
-                    tgt = db if i == 0 else torch.empty_like(db)
-                    _lib.check(lib.cffm_colsum(_ptr(blk), nr, o, _ptr(tgt), st), lib)
-                    if i:
-                        db += tgt
+            db = bparts[0] if bparts else torch.zeros(o, dtype=torch.float32, device=dy.device)
+            for t in bparts[1:]:
+                db += t
         return dx, dwm, db, None
 
 
@@ -868,7 +935,8 @@ def _maps_tables(dev, b, t, label_idx, loss_w, hits_w):
             _MAPS_TABLES.clear()
         hit = (torch.tensor([bi * t + int(i) for bi in range(b) for i in label_idx], dtype=torch.int32, device=dev),
                torch.tensor([float(x) for x in loss_w] * b, dtype=torch.float64, device=dev),
-               torch.tensor([float(x) for x in hits_w] * b, dtype=torch.float64, device=dev))
+               torch.tensor([float(x) for x in hits_w] * b, dtype=torch.float64, device=dev),
+               torch.tensor([float(x) for x in loss_w] * b, dtype=torch.float32, device=dev))      # (the backward's per-map scale)
         _MAPS_TABLES[key] = hit
     return hit
 
@@ -899,16 +967,18 @@ class _UpceMapsFn(torch.autograd.Function):
             st, rows, plain = logits.stride(), False, True
         labels = labels.contiguous()
         dev, m = logits.device, b * n
-        lidx, wl, wh = _maps_tables(dev, b, t, label_idx, loss_w, hits_w)
+        lidx, wl, wh, wl32 = _maps_tables(dev, b, t, label_idx, loss_w, hits_w)
         lse = torch.empty(m, H, W, dtype=torch.float32, device=dev)
         nblk = lib.cffm_upce_blocks(m, H, W)
         part = torch.empty(nblk, 2, dtype=torch.float32, device=dev)
         ks, ps = (1, k) if rows else (h * w, 1)
         _lib.check(lib.cffm_upce_maps_fwd(_ptr(logits), _ptr(labels), _ptr(lidx), _ptr(lse), _ptr(part), m, k, h, w, H, W, int(ignore_index),
                                           n, st[0], st[1], ks, ps, _stream(logits)), lib)
-        per_map = part.view(m, nblk // m, 2).double().sum(1) if m else part.new_zeros(0, 2).double()     # deterministic record sums
-        loss, hits = (per_map[:, 0] * wl).sum().float(), (per_map[:, 1] * wh).sum().float()
-        ctx.save_for_backward(logits, labels, lse, lidx, wl.float())
+        out = torch.zeros(2, dtype=torch.float32, device=dev) if not m else torch.empty(2, dtype=torch.float32, device=dev)
+        if m:       # deterministic record sums and the per-map weighting in one launch (it was ~10 torch kernels: 60 us of a replayed step)
+            _lib.check(lib.cffm_upce_maps_finalize(_ptr(part), m, nblk // m, _ptr(wl), _ptr(wh), _ptr(out), _stream(logits)), lib)
+        loss, hits = out[0], out[1]
+        ctx.save_for_backward(logits, labels, lse, lidx, wl32)
         ctx.geom = (n, ks, ps, int(ignore_index))
         ctx.mark_non_differentiable(hits)
         return loss, hits
