@@ -278,3 +278,64 @@ def test_head_rows_path_equals_torch_glue_emulated():
 @pytest.mark.gpu
 def test_head_rows_path_equals_torch_glue_gpu():
     run_head_ab(torch.device('cuda:0'), size=128, chans=(64, 128, 320, 512), depths=2)
+
+
+def run_head_pieces(device):
+    """The round-6 pieces of the rows path, each against stock torch under autograd:
+    (a) ops.conv1x1(..., clips=B, extra=1) + ops.cat_into == torch.cat([conv(x) per clip, x2], 1) -- and really without copying the frame
+        logits (the result shares their memory); gradients of x, weight, bias, x2;
+    (b) the composed embedding weights and their constant (cffm_fuse_compose_fwd / _bwd behind ops.segformer_fuse's _ComposeFn): A_i = Wf_i W_i,
+        d = sum_i Wf_i b_i, gradients of the nine tensors;
+    (c) the loss scalars of ops.head_cross_entropy (cffm_upce_maps_finalize) are covered by tests/test_segloss.py's goldens."""
+    from vss_cffm_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    b, t, c, o, h, w = 2, 3, 16, 12, 5, 6
+    x = torch.randn(b * t, c, h, w, generator=gen).to(device).requires_grad_(True)
+    wt = torch.randn(o, c, 1, 1, generator=gen).to(device).requires_grad_(True)
+    bs = torch.randn(o, generator=gen).to(device).requires_grad_(True)
+    x2 = torch.randn(b, 1, o, h, w, generator=gen).to(device).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3).requires_grad_(True)
+    gy = torch.randn(b, t + 1, o, h, w, generator=gen).to(device)
+    y = ops.conv1x1(x, wt, bs, clips=b, extra=1)
+    assert ops.cat_room(y, 1) and not ops.cat_room(y, 2)
+    z = ops.cat_into(y, x2)
+    assert z.shape == (b, t + 1, o, h, w) and z.data_ptr() == y.data_ptr()            # the frame logits did not move
+    (z * gy).sum().backward()
+    xr, wr, br, x2r = [v.detach().double().cpu().requires_grad_(True) for v in (x, wt, bs, x2)]
+    zr = torch.cat([torch.nn.functional.conv2d(xr, wr, br).view(b, t, o, h, w), x2r], 1)
+    (zr * gy.double().cpu()).sum().backward()
+    assert H.rel_err(z.detach(), zr.detach()) < 2e-5
+    for got, ref in ((x, xr), (wt, wr), (bs, br), (x2, x2r)):
+        assert H.rel_err(got.grad, ref.grad) < 2e-5
+    assert not ops.cat_room(ops.conv1x1(x, wt, bs, clips=b), 1)                       # no room asked for: torch.cat's job
+    # (b)
+    k, e, cins = 3, 256, (8, 20, 64)
+    fw = (torch.randn(e, k * e, generator=gen) * 0.05).to(device).requires_grad_(True)
+    lw = [(torch.randn(e, ci, generator=gen) * 0.1).to(device).requires_grad_(True) for ci in cins]
+    lb = [torch.randn(e, generator=gen).to(device).requires_grad_(True) for _ in cins]
+    outs = ops._ComposeFn.apply(fw, *lw, *lb)
+    gm = [torch.randn(e, ci, generator=gen).to(device) for ci in cins]
+    gd = torch.randn(e, generator=gen).to(device)
+    (sum((a * g_).sum() for a, g_ in zip(outs[:k], gm)) + (outs[k] * gd).sum()).backward()
+    fr = fw.detach().double().cpu().requires_grad_(True)
+    lwr = [v.detach().double().cpu().requires_grad_(True) for v in lw]
+    lbr = [v.detach().double().cpu().requires_grad_(True) for v in lb]
+    blocks = [fr[:, (k - 1 - i) * e:(k - i) * e] for i in range(k)]                   # cat order c_k .. c_1
+    mats = [blocks[i] @ lwr[i] for i in range(k)]
+    d = sum(blocks[i] @ lbr[i] for i in range(k))
+    (sum((a * g_.double().cpu()).sum() for a, g_ in zip(mats, gm)) + (d * gd.double().cpu()).sum()).backward()
+    for a, r in zip(outs[:k], mats):
+        assert H.rel_err(a.detach(), r.detach()) < 2e-5
+    assert H.rel_err(outs[k].detach(), d.detach()) < 1e-5
+    assert H.rel_err(fw.grad, fr.grad) < 2e-5
+    for got, ref in zip(lw + lb, lwr + lbr):
+        assert H.rel_err(got.grad, ref.grad) < 2e-5
+
+
+def test_head_pieces_emulated():
+    with emu.active():
+        run_head_pieces(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_head_pieces_gpu():
+    run_head_pieces(torch.device('cuda'))

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .modules import BasicLayer3d3, BasicLayer_cluster
 from . import _lib
-from .ops import bn_relu_pool, conv1x1, head_cross_entropy, resize_cross_entropy, rows_resize, segformer_fuse
+from .ops import bn_relu_pool, cat_into, cat_room, conv1x1, head_cross_entropy, resize_cross_entropy, rows_resize, segformer_fuse
 from .registry import HEADS, LOSSES, build_loss
 
 
@@ -267,18 +267,18 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
             maps.append(m if c is c1 else resize(m, size=size, mode='bilinear', align_corners=False))
         return self.linear_fuse(torch.cat(maps, dim=1))
 
-    def _classify(self, conv, feat, clips=0):
+    def _classify(self, conv, feat, clips=0, extra=0):
         """a 1x1 classifier (`linear_pred*`): libcffm_hip.so's GEMM on token rows for GPU tensors, nn.Conv2d otherwise"""
         if (self.fuse_impl == 'hip' and (feat.is_cuda or _lib._override is not None) and feat.dtype == torch.float32
                 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0):      # 16-byte token rows (e.g. not 19 classes)
-            return conv1x1(feat, conv.weight, conv.bias, clips)
+            return conv1x1(feat, conv.weight, conv.bias, clips, extra)
         y = conv(feat)
         return y.reshape(clips, y.shape[0] // clips, *y.shape[1:]) if clips else y
 
-    def _frame_logits(self, fused, batch_size, num_clips, dropped=False):
+    def _frame_logits(self, fused, batch_size, num_clips, dropped=False, extra=0):
         # (the [B,T,K,h,w] view comes straight out of the classifier op: its gradient -- slices of the loss kernel's buffer, one
         #  block of rows per clip -- is then consumed in place instead of being gathered into one [B*T,...] tensor by autograd)
-        return self._classify(self.linear_pred, self.dropout(fused) if (self.dropout is not None and not dropped) else fused, batch_size)
+        return self._classify(self.linear_pred, self.dropout(fused) if (self.dropout is not None and not dropped) else fused, batch_size, extra)
 
     def _clip_features(self, fused, batch_size, num_clips):
         """1/4 -> 1/8 resize, then the hot path (cffm_head.py:131-145)."""
@@ -336,6 +336,8 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
 
     @staticmethod
     def _rows_cat(x, x2):
+        if cat_room(x, x2.shape[1]) and x2.shape[0] == x.shape[0] and x2.shape[2:] == x.shape[2:]:
+            return cat_into(x, x2)      # the frame logits were written with room behind them: only x2 moves
         if x.permute(0, 1, 3, 4, 2).is_contiguous() and x2.permute(0, 1, 3, 4, 2).is_contiguous():
             # the classifiers wrote token rows [.., h, w, K]: concatenate THERE (a plain copy; torch.cat of the [B,T,K,h,w] views
             # would transpose 71 MB into plain memory) and hand the result out as the [B,T+1,K,h,w] view the caller expects --
@@ -349,7 +351,8 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
 class CFFMHead_clips_resize1_8(_CffmHeadBase):
     def _forward_rows(self, inputs, batch_size, num_clips):
         fused, stack, dropped = self._rows_front(inputs, batch_size, num_clips)
-        x = self._frame_logits(fused, batch_size, num_clips, dropped=dropped)
+        # (training: the frame logits are written with room for the clip-level map behind them -- _rows_cat then copies only that map)
+        x = self._frame_logits(fused, batch_size, num_clips, dropped=dropped, extra=1 if (self.training and stack is not None) else 0)
         if stack is None:
             return x[:, -1]                                   # short-circuit before CFFM (cffm_head.py:127-129)
         h, w = fused.shape[2:]
@@ -462,7 +465,7 @@ class CFFMHead_clips_resize1_8_finetune_w_prototype3(_CffmHeadBase):
         with torch.no_grad():                                  # the fuse conv is frozen in eval (cffm_head.py:478-480)
             self.linear_fuse.eval()
             fused, stack, dropped = self._rows_front(inputs, batch_size, num_clips)
-        x = self._frame_logits(fused, batch_size, num_clips, dropped=dropped)
+        x = self._frame_logits(fused, batch_size, num_clips, dropped=dropped, extra=1 if (self.training and stack is not None) else 0)
         if stack is None:
             return x[:, -1]
         h, w = fused.shape[2:]

@@ -578,7 +578,7 @@ class _Conv1x1Fn(torch.autograd.Function):
     rows (slices of a [B, T+1, H, W, O] buffer, the loss kernel's output) and is consumed block by block, not copied together."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, clips):
+    def forward(ctx, x, weight, bias, clips, extra=0):
         lib = _lib.get()
         for t in (x, weight, bias):
             _require_device(t, 'conv1x1 operand')
@@ -593,11 +593,22 @@ class _Conv1x1Fn(torch.autograd.Function):
             raise _lib.CffmError('conv1x1: %d maps do not split into %d clips' % (n, clips))
         rows = _to_rows(lib, x)                                   # [N,H,W,C] token rows
         wm, b = weight.reshape(o, c).contiguous(), bias.contiguous()
-        y = torch.empty(n, h, w, o, dtype=torch.float32, device=x.device)
-        _lib.check(lib.cffm_linear_bias_fwd(_ptr(rows), _ptr(wm), _ptr(b), _ptr(y), n * h * w, o, c, _stream(x)), lib)
         ctx.save_for_backward(rows, wm)
         ctx.x_plain = x.is_contiguous()            # hand the input gradient back in the input's own memory layout
         ctx.clips = clips
+        if clips and extra:
+            # room for `extra` more maps per clip behind the n / clips this call writes (cat_into fills them): the head's [B, T+1, K, h, w]
+            # logits are then assembled where they lie -- torch.cat copied the 57 MB of frame logits once more (30 us of a replayed step)
+            t = n // clips
+            buf = torch.empty(clips, t + extra, h, w, o, dtype=torch.float32, device=x.device)
+            per = t * h * w
+            for i in range(clips):
+                if per:
+                    _lib.check(lib.cffm_linear_bias_fwd(C.c_void_p(rows.data_ptr() + 4 * i * per * c), _ptr(wm), _ptr(b), _ptr(buf[i]), per, o, c, _stream(x)), lib)
+            ctx.room = buf
+            return buf[:, :t].permute(0, 1, 4, 2, 3)
+        y = torch.empty(n, h, w, o, dtype=torch.float32, device=x.device)
+        _lib.check(lib.cffm_linear_bias_fwd(_ptr(rows), _ptr(wm), _ptr(b), _ptr(y), n * h * w, o, c, _stream(x)), lib)
         if clips:
             return y.view(clips, n // clips, h, w, o).permute(0, 1, 4, 2, 3)
         return y.permute(0, 3, 1, 2)
@@ -660,13 +671,50 @@ class _Conv1x1Fn(torch.autograd.Function):
             db = bparts[0] if bparts else torch.zeros(o, dtype=torch.float32, device=dy.device)
             for t in bparts[1:]:
                 db += t
-        return dx, dwm, db, None
+        return dx, dwm, db, None, None
 
 
-def conv1x1(x, weight, bias, clips=0):
+def conv1x1(x, weight, bias, clips=0, extra=0):
     """nn.Conv2d(C, O, kernel_size=1)(x) (the head's classifiers `linear_pred*`, cffm_head.py:121,147,524) as a split-bf16 MFMA
-    GEMM on token rows; returns [N,O,H,W] in channels-last memory, or [clips, N/clips, O, H, W] (same memory) when `clips` is given."""
-    return _Conv1x1Fn.apply(x, weight, bias, int(clips))
+    GEMM on token rows; returns [N,O,H,W] in channels-last memory, or [clips, N/clips, O, H, W] (same memory) when `clips` is given.
+    `extra` (with `clips`): the rows are written into a [clips, N/clips + extra, H, W, O] buffer, so that `cat_into` can append the clip-level
+    maps (cffm_head.py:150 `torch.cat([x, x2], 1)`) without copying these."""
+    return _Conv1x1Fn.apply(x, weight, bias, int(clips), int(extra))
+
+
+class _CatIntoFn(torch.autograd.Function):
+    """torch.cat([x, x2], 1) of logits maps that live as token rows, where x = buf[:, :T] is the front of a [B, T+e, h, w, K] buffer
+    (conv1x1(..., extra=e)): only x2 is copied; the result is the whole buffer viewed as [B, T+e, K, h, w].  Backward: two views."""
+
+    @staticmethod
+    def forward(ctx, x, x2):
+        t, e = x.shape[1], x2.shape[1]
+        rows = x.permute(0, 1, 3, 4, 2)                                   # [B, T, h, w, K]: contiguous slices of the buffer
+        buf = torch.as_strided(rows, (x.shape[0], t + e, rows.shape[2], rows.shape[3], rows.shape[4]), rows.stride(), rows.storage_offset())
+        buf[:, t:].copy_(x2.permute(0, 1, 3, 4, 2))
+        ctx.t = t
+        return buf.permute(0, 1, 4, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.t], g[:, ctx.t:]
+
+
+def cat_room(x, extra):
+    """True when x [B,T,K,h,w] is the front of a buffer with room for `extra` more maps per clip (conv1x1(..., extra=...))"""
+    if x.dim() != 5:
+        return False
+    b, t, k, h, w = x.shape
+    per = h * w * k
+    try:
+        ok = x.stride() == ((t + extra) * per, per, 1, w * k, k) and x.untyped_storage().nbytes() >= 4 * (x.storage_offset() + b * (t + extra) * per)
+    except Exception:       # noqa: BLE001
+        ok = False
+    return bool(ok)
+
+
+def cat_into(x, x2):
+    return _CatIntoFn.apply(x, x2)
 
 
 # ---------------------------------------------------------------------------------------------- the layer on token rows
