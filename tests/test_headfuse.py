@@ -339,3 +339,62 @@ def test_head_pieces_emulated():
 @pytest.mark.gpu
 def test_head_pieces_gpu():
     run_head_pieces(torch.device('cuda'))
+
+
+@pytest.mark.gpu
+def test_head_step_replayed_equals_eager_gpu():
+    """The whole head's training step (rows path: stage calls on branches of the library's streams, a scratch pool per branch) captured in a HIP
+    graph and replayed against the same step launched eagerly: logits, loss, feature gradients and every parameter gradient BIT-identical --
+    the branches run in another interleaving under the graph executor, and nothing on them uses atomics, so any difference would be a missing
+    dependency (a join taken too early, two branches on one scratch).  Exception as in tests/test_gpu_parity.py: the four Linear weight
+    gradients of a CFFM block are split over the contraction differently under capture (rounding-level differences)."""
+    from tests.golden.make_golden_head import feature_maps, labels
+    device = torch.device('cuda')
+    chans, size = (64, 128, 320, 512), 256
+    head = build_head(RI.head_cfg(in_channels=chans, depths=2))
+    head.load_state_dict(R.synth_state(head, seed=71), strict=False)
+    head.dropout.p = 0.0
+    Hd.revert_sync_batchnorm(head)
+    head.to(device).train()
+    feats = [f.to(device).requires_grad_(True) for f in feature_maps(2, 4, size, chans=chans, seed=72)]
+    lab = labels(2, 4, size, seed=73).to(device)
+
+    def step():
+        for p in head.parameters():
+            p.grad = None
+        for f in feats:
+            f.grad = None
+        out = head(feats, 2, 4)
+        loss = head.losses(out, lab)
+        loss['loss_seg'].backward()
+        return out, loss['loss_seg']
+
+    snap = lambda out, loss: (out.detach().clone(), loss.detach().clone(), [f.grad.clone() for f in feats],
+                              {k: p.grad.clone() for k, p in head.named_parameters() if p.grad is not None})
+    for _ in range(2):
+        ref = snap(*step())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_g, loss_g = step()
+    reps = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        reps.append(snap(out_g, loss_g))
+    for r in reps:
+        assert torch.equal(r[0], ref[0]) and torch.equal(r[1], ref[1])
+        for a, b in zip(r[2], ref[2]):
+            assert torch.equal(a, b)
+        assert set(r[3]) == set(ref[3])
+        for k in ref[3]:
+            if 'decoder_focal' in k and k.endswith('.weight') and ref[3][k].dim() == 2 and 'pool' not in k:
+                assert float((r[3][k] - ref[3][k]).abs().max()) <= 2e-6 * float(ref[3][k].abs().max()), k
+                assert torch.equal(r[3][k], reps[0][3][k]), k         # replay to replay: always bit-identical
+            else:
+                assert torch.equal(r[3][k], ref[3][k]), k
