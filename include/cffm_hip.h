@@ -86,6 +86,13 @@ int cffm_branch_join(void* stream);
  * cffm_branch_take(stream, i): branch i ordered behind the marked point (or `stream` itself). */
 int cffm_branch_mark(void* stream);
 void* cffm_branch_take(void* stream, int i);
+/* a DEFERRED branch: a library-owned stream of its own for work whose results `stream` needs only much later (the frame classifier's backward
+ * of the CFFM heads, cffm_head.py:121, beside the whole CFFM layer's backward).  cffm_defer_begin(stream): that stream, ordered behind `stream`
+ * (or `stream` itself); cffm_defer_join(stream): `stream` continues behind it (no-op when nothing is pending).  Nothing on `stream` may read the
+ * deferred results before the join.  cffm_add_inplace: a += b (n floats, n % 4 == 0) on a stream. */
+void* cffm_defer_begin(void* stream);
+int cffm_defer_join(void* stream);
+int cffm_add_inplace(float* a, const float* b, long n, void* stream);
 int cffm_profile_stage_count(void);
 int cffm_profile_null_pair(void* stream); /* stage "event_pair_null": two event records with nothing between (the interval's own cost) */
 const char* cffm_profile_stage_name(int i);

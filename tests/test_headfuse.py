@@ -307,6 +307,20 @@ def run_head_pieces(device):
     for got, ref in ((x, xr), (wt, wr), (bs, br), (x2, x2r)):
         assert H.rel_err(got.grad, ref.grad) < 2e-5
     assert not ops.cat_room(ops.conv1x1(x, wt, bs, clips=b), 1)                       # no room asked for: torch.cat's job
+    # (a') the same concatenation as ONE node whose backward runs on the library's deferred branch (ops.frame_logits_cat; parameters through
+    #      ops.late_params so that autograd accumulates their gradients behind the join): same values, same gradients
+    for v in (x, wt, bs, x2):
+        v.grad = None
+    xc = x.detach().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)       # channels-last, as the rows path hands it
+    lw, lb = ops.late_params(wt, bs)
+    z2 = ops.frame_logits_cat(xc, lw, lb, x2, b)
+    assert torch.equal(z2.detach(), z.detach())
+    (z2 * gy).sum().backward()
+    if device.type == 'cuda':
+        torch.cuda.synchronize()
+    for got, ref in ((xc, xr), (wt, wr), (bs, br), (x2, x2r)):
+        assert H.rel_err(got.grad, ref.grad) < 2e-5
+    assert not ops._DEFERRED                                                          # joined by the end of the backward pass
     # (b)
     k, e, cins = 3, 256, (8, 20, 64)
     fw = (torch.randn(e, k * e, generator=gen) * 0.05).to(device).requires_grad_(True)

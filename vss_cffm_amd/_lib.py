@@ -54,6 +54,9 @@ SIGNATURES = {
     'cffm_branch_begin': (vp, [vp, ci]),
     'cffm_branch_join': (ci, [vp]),
     'cffm_branch_mark': (ci, [vp]),
+    'cffm_defer_begin': (vp, [vp]),
+    'cffm_defer_join': (ci, [vp]),
+    'cffm_add_inplace': (ci, [vp, vp, cl, vp]),
     'cffm_branch_take': (vp, [vp, ci]),
     'cffm_fuse_compose_fwd': (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp]),
     'cffm_fuse_compose_bwd': (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]),

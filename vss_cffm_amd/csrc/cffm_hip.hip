@@ -299,11 +299,12 @@ long cffm_layer_scratch_floats(const cffm_geom* g) { return scratch_layout(g).to
 // ------------------------------------------------------------------------------------------- internal scratch
 // Small library-owned device buffer for the block-partial records of the two-stage reductions
 // (grows on demand; stream-ordered reuse, one stream at a time as the ABI's threading rule says).
-// One pool per stream a stage call can arrive on: the caller's (0) and the four branches of cffm_branch_begin / _take (1..4) -- stage calls
+// One pool per stream a stage call can arrive on: the caller's (0), the four branches of cffm_branch_begin / _take (1..4) and the deferred
+// branch of cffm_defer_begin (5) -- stage calls
 // that need scratch (split-K slabs of the weight gradients, column-sum records) may then run on different branches at the same time.
 // ScratchFor selects the pool for the duration of a public stage call from its `stream` argument; everything else uses pool 0.
-static float* g_scr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-static size_t g_scr_floats[5] = {0, 0, 0, 0, 0};
+static float* g_scr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static size_t g_scr_floats[6] = {0, 0, 0, 0, 0, 0};
 static int g_scr_sel = 0;
 extern "C++" __attribute__((visibility("hidden"))) float* lib_scratch(size_t nfloats) {
     float*& buf = g_scr[g_scr_sel];
@@ -374,12 +375,16 @@ struct SideStream {
 #endif
 };
 static SideStream g_side;
-struct ScratchFor {       // RAII: pool of the branch `stream` is (cffm_branch_begin / _take), else the caller's pool
+#ifndef CFFM_EMU
+static struct { hipStream_t st = nullptr; hipEvent_t fork = nullptr, done = nullptr; bool used = false; int state = -1; } g_defer;   // cffm_defer_begin
+#endif
+struct ScratchFor {       // RAII: pool of the branch `stream` is (cffm_branch_begin / _take, cffm_defer_begin), else the caller's pool
     explicit ScratchFor(void* stream) {
         g_scr_sel = 0;
 #ifndef CFFM_EMU
         for (int i = 0; i < 4; ++i)
             if (stream && (hipStream_t)stream == g_side.st[i]) g_scr_sel = i + 1;
+        if (stream && (hipStream_t)stream == g_defer.st) g_scr_sel = 5;
 #endif
         (void)stream;
     }
@@ -594,6 +599,41 @@ int cffm_branch_join(void* stream) {
     side_join_all((hipStream_t)stream);
     return 0;
 }
+// A DEFERRED branch for the caller (ABI 10): work whose results the caller's stream needs much later than the next call -- the frame
+// classifier's backward of the CFFM heads (cffm_head.py:121: its input gradient is needed by linear_fuse's BatchNorm backward, its weight /
+// bias gradients by the optimizer, and the whole CFFM layer's backward lies between).  cffm_defer_begin(stream): a library-owned stream
+// of its own (not one of the four branches: the layer's own side work uses those and must not queue behind 270 us of classifier kernels),
+// ordered behind everything issued on `stream` so far; cffm_defer_join(stream): `stream` continues behind it (a no-op when nothing is
+// pending).  Everything the deferred work touches must stay alive, and nothing on `stream` may read its results, until the join.
+void* cffm_defer_begin(void* stream) {
+#ifndef CFFM_EMU
+    hipStream_t main = (hipStream_t)stream;
+    if (g_side_off) return stream;
+    if (g_defer.state < 0) {
+        g_defer.state = (hipStreamCreateWithFlags(&g_defer.st, hipStreamNonBlocking) == hipSuccess &&
+                         hipEventCreateWithFlags(&g_defer.fork, hipEventDisableTiming) == hipSuccess &&
+                         hipEventCreateWithFlags(&g_defer.done, hipEventDisableTiming) == hipSuccess) ? 1 : 0;
+        (void)hipGetLastError();
+    }
+    if (g_defer.state == 1 && hipEventRecord(g_defer.fork, main) == hipSuccess && hipStreamWaitEvent(g_defer.st, g_defer.fork, 0) == hipSuccess) {
+        g_defer.used = true;
+        return (void*)g_defer.st;
+    }
+    (void)hipGetLastError();
+#endif
+    return stream;
+}
+int cffm_defer_join(void* stream) {
+#ifndef CFFM_EMU
+    if (g_defer.used) {
+        if (hipEventRecord(g_defer.done, g_defer.st) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, g_defer.done, 0);
+        g_defer.used = false;
+        (void)hipGetLastError();
+    }
+#endif
+    (void)stream;
+    return 0;
+}
 // event helpers of the deferred join (no-ops when the work ran on `main` itself)
 static void side_record(hipStream_t side, hipStream_t main, void* ev) {
 #ifndef CFFM_EMU
@@ -694,6 +734,14 @@ static int transpose_add(const float* src, float* dst, int batch, int rows, int 
     CFFM_LAUNCH(k_transpose, ((cols + 63) / 64, (rows + 63) / 64, batch), (256), 0, (hipStream_t)stream, src, dst, rows, cols,
                 src_bs, dst_bs, addend, add_mod > 0 ? add_mod : 1, add_skip, copy_dst);
     CHECK_LAUNCH("transpose");
+    return 0;
+}
+// a += b over n floats (n % 4 == 0): summing the per-clip pieces of a gradient on the stream they were computed on
+int cffm_add_inplace(float* a, const float* b, long n, void* stream) {
+    REQUIRE(a && b && n >= 0 && n % 4 == 0, "add_inplace: n must be a multiple of 4");
+    if (!n) return 0;
+    CFFM_LAUNCH(k_add_inplace, (ew_grid(n / 4)), (256), 0, (hipStream_t)stream, a, b, n / 4);
+    CHECK_LAUNCH("add_inplace");
     return 0;
 }
 int cffm_transpose(const float* src, float* dst, int batch, int rows, int cols, long src_bs, long dst_bs, void* stream) {

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .modules import BasicLayer3d3, BasicLayer_cluster
 from . import _lib
-from .ops import bn_relu_pool, cat_into, cat_room, conv1x1, head_cross_entropy, resize_cross_entropy, rows_resize, segformer_fuse
+from .ops import bn_relu_pool, cat_into, cat_room, conv1x1, frame_logits_cat, late_params, head_cross_entropy, resize_cross_entropy, rows_resize, segformer_fuse
 from .registry import HEADS, LOSSES, build_loss
 
 
@@ -350,9 +350,16 @@ class _CffmHeadBase(BaseDecodeHead_clips_flow):
 @HEADS.register_module()
 class CFFMHead_clips_resize1_8(_CffmHeadBase):
     def _forward_rows(self, inputs, batch_size, num_clips):
+        # (the frame classifier's parameters as they will be used at the END of the forward, through a node created FIRST: its backward runs
+        #  late and joins the deferred branch before autograd accumulates their gradients -- ops._LateGradFn)
+        lp_w, lp_b = late_params(self.linear_pred.weight, self.linear_pred.bias) if self.training else (self.linear_pred.weight, self.linear_pred.bias)
         fused, stack, dropped = self._rows_front(inputs, batch_size, num_clips)
-        # (training: the frame logits are written with room for the clip-level map behind them -- _rows_cat then copies only that map)
-        x = self._frame_logits(fused, batch_size, num_clips, dropped=dropped, extra=1 if (self.training and stack is not None) else 0)
+        # Training with the clip-level path: the frame classifier `linear_pred` runs LAST, fused with the concatenation (ops.frame_logits_cat),
+        # so that its backward is the first node of the backward pass and runs on the library's deferred branch beside the layer's backward.
+        need_drop = self.dropout is not None and not dropped and self.dropout.p > 0          # (Dropout2d not yet folded into the BatchNorm pass)
+        late = (self.training and stack is not None and not need_drop and fused.dtype == torch.float32
+                and self.linear_pred.in_channels % 4 == 0 and self.linear_pred.out_channels % 4 == 0)
+        x = None if late else self._frame_logits(fused, batch_size, num_clips, dropped=dropped, extra=1 if (self.training and stack is not None) else 0)
         if stack is None:
             return x[:, -1]                                   # short-circuit before CFFM (cffm_head.py:127-129)
         h, w = fused.shape[2:]
@@ -362,6 +369,8 @@ class CFFMHead_clips_resize1_8(_CffmHeadBase):
         x2 = self._rows_logits(self.linear_pred2, torch.cat([x_rows[:, -1], mined], dim=-1).view(batch_size, h2, w2, -1), self.dropout, (h, w))
         if not self.training:
             return x2.squeeze(1)
+        if late:
+            return frame_logits_cat(fused, lp_w, lp_b, x2, batch_size)
         return self._rows_cat(x, x2)
 
     def forward(self, inputs, batch_size=None, num_clips=None, imgs=None):

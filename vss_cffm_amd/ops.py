@@ -700,6 +700,129 @@ class _CatIntoFn(torch.autograd.Function):
         return g[:, :ctx.t], g[:, ctx.t:]
 
 
+_DEFERRED = []         # tensors the deferred branch (cffm_defer_begin) still touches; cleared by _join_deferred
+
+
+def _join_deferred(t=None):
+    """the caller's stream continues behind the deferred branch (no-op when nothing is pending): called by whoever consumes deferred results
+    (bn_relu_pool's backward) and once more at the end of every backward pass that deferred something"""
+    if _DEFERRED:
+        lib = _lib.get()
+        lib.cffm_defer_join(_stream(_DEFERRED[0][0]))
+        del _DEFERRED[:]
+
+
+class _LateGradFn(torch.autograd.Function):
+    """Identity on parameters whose gradients will come from the deferred branch.  Autograd accumulates a parameter gradient (and may CLONE
+    it) the moment the producing node returns -- for a gradient still being computed on another stream that is a race (found by
+    tests/test_headfuse.py::test_head_step_replayed_equals_eager_gpu: linear_pred.bias.grad was a copy of stale memory).  Applied EARLY in the
+    forward, this node runs LATE in the backward (the engine takes ready nodes in reverse creation order); it joins the deferred branch and
+    hands the gradients on, so whatever autograd does with them happens behind the join."""
+
+    @staticmethod
+    def forward(ctx, *ps):
+        return tuple(p.view_as(p) for p in ps)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        _join_deferred()
+        return gs
+
+
+def late_params(*ps):
+    return _LateGradFn.apply(*ps)
+
+
+class _FrameLogitsCatFn(torch.autograd.Function):
+    """torch.cat([linear_pred(fused) viewed [B,T,K,h,w], x2], 1) (cffm_head.py:121 + :150) as ONE node, created LAST in the forward -- so it
+    is the FIRST node of the backward, and the classifier's backward (input gradient: needed by linear_fuse's BatchNorm backward; weight /
+    bias gradients: needed by the optimizer) goes to the library's deferred branch and runs BESIDE the clip-level path's and the whole CFFM
+    layer's backward instead of behind them (110 us of a replayed head step).  The returned input gradient must not be read on the caller's
+    stream before _join_deferred(): ops.bn_relu_pool's backward -- its only consumer on the heads' rows path -- joins first, and the end of
+    the backward pass joins in any case.  `weight` / `bias` must come through ops.late_params (their gradients are deferred too)."""
+
+    @staticmethod
+    def forward(ctx, fused, weight, bias, x2, clips):
+        lib = _lib.get()
+        for t in (fused, weight, bias, x2):
+            _require_device(t, 'frame_logits_cat operand')
+        n, c, h, w = fused.shape
+        o = weight.shape[0]
+        if weight.dim() != 4 or tuple(weight.shape[1:]) != (c, 1, 1) or bias.shape != (o,) or c % 4 or o % 4 or n % clips:
+            raise _lib.CffmError('frame_logits_cat: fused %s, weight %s, bias %s, %d clips do not fit' % (tuple(fused.shape), tuple(weight.shape), tuple(bias.shape), clips))
+        t = n // clips
+        e = x2.shape[1]
+        if x2.shape != (clips, e, o, h, w):
+            raise _lib.CffmError('frame_logits_cat: clip-level maps %s, [%d, e, %d, %d, %d] expected' % (tuple(x2.shape), clips, o, h, w))
+        rows = _to_rows(lib, fused)
+        wm, b = weight.reshape(o, c).contiguous(), bias.contiguous()
+        buf = torch.empty(clips, t + e, h, w, o, dtype=torch.float32, device=fused.device)
+        per, st = t * h * w, _stream(fused)
+        for i in range(clips):
+            if per:
+                _lib.check(lib.cffm_linear_bias_fwd(C.c_void_p(rows.data_ptr() + 4 * i * per * c), _ptr(wm), _ptr(b), _ptr(buf[i]), per, o, c, st), lib)
+        buf[:, t:].copy_(x2.permute(0, 1, 3, 4, 2))
+        ctx.save_for_backward(rows, wm)
+        ctx.dims = (clips, t, e)
+        ctx.x_plain = fused.is_contiguous()
+        return buf.permute(0, 1, 4, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.get()
+        rows, wm = ctx.saved_tensors
+        clips, t, e = ctx.dims
+        n, h, w, c = rows.shape
+        o = wm.shape[0]
+        g5 = g.permute(0, 1, 3, 4, 2)                                      # [B, T+e, h, w, K] as the loss kernel wrote it
+        if not all(g5[i].is_contiguous() for i in range(clips)):
+            g5 = g5.contiguous()
+        per, st, dev = t * h * w, _stream(rows), rows.device
+        dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dwm = torch.zeros(o, c, dtype=torch.float32, device=dev) if (ctx.needs_input_grad[1] and not per) else (torch.empty(o, c, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None)
+        db = torch.zeros(o, dtype=torch.float32, device=dev) if (ctx.needs_input_grad[2] and not per) else (torch.empty(o, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None)
+        keep = [rows, wm, g5, dx, dwm, db]
+        if per:
+            sd = C.c_void_p(lib.cffm_defer_begin(st))
+            blk = [g5[i, :t] for i in range(clips)]
+            if dx is not None:
+                for i in range(clips):
+                    _lib.check(lib.cffm_linear_bwd_input(_ptr(blk[i]), _ptr(wm), C.c_void_p(dx.data_ptr() + 4 * i * per * c), per, o, c, sd), lib)
+            for i in range(clips):
+                xi = C.c_void_p(rows.data_ptr() + 4 * i * per * c)
+                if dwm is not None:
+                    tw = dwm if i == 0 else torch.empty_like(dwm)
+                    _lib.check(lib.cffm_linear_bwd_weight(_ptr(blk[i]), xi, _ptr(tw), per, o, c, sd), lib)
+                    if i:
+                        _lib.check(lib.cffm_add_inplace(_ptr(dwm), _ptr(tw), o * c, sd), lib)
+                        keep.append(tw)
+                if db is not None:
+                    tb = db if i == 0 else torch.empty_like(db)
+                    _lib.check(lib.cffm_colsum(_ptr(blk[i]), per, o, _ptr(tb), sd), lib)
+                    if i:
+                        _lib.check(lib.cffm_add_inplace(_ptr(db), _ptr(tb), o, sd), lib)
+                        keep.append(tb)
+            if sd.value != st.value:
+                if not _DEFERRED:
+                    torch.autograd.Variable._execution_engine.queue_callback(_join_deferred)
+                _DEFERRED.append(keep)
+        dfused = None
+        if dx is not None:
+            if ctx.x_plain and per:                     # (plain NCHW input: the heads' rows path hands channels-last memory, this is the general case)
+                _join_deferred()
+                dxp = torch.empty(n, c, h, w, dtype=torch.float32, device=dev)
+                _lib.check(lib.cffm_transpose(_ptr(dx), _ptr(dxp), n, h * w, c, c * h * w, c * h * w, st), lib)
+                dfused = dxp
+            else:
+                dfused = dx.permute(0, 3, 1, 2)
+        return dfused, (dwm.view(o, c, 1, 1) if dwm is not None else None), db, g[:, t:], None
+
+
+def frame_logits_cat(fused, weight, bias, x2, clips):
+    """[B, T+e, K, h, w] = cat([conv1x1(fused) per clip, x2], 1): see _FrameLogitsCatFn (o % 4 == 0 and c % 4 == 0 as for conv1x1)"""
+    return _FrameLogitsCatFn.apply(fused, weight, bias, x2, int(clips))
+
+
 def cat_room(x, extra):
     """True when x [B,T,K,h,w] is the front of a buffer with room for `extra` more maps per clip (conv1x1(..., extra=...))"""
     if x.dim() != 5:
@@ -831,6 +954,7 @@ class _BnReluPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfused, dstack):
         lib = _lib.get()
+        _join_deferred()          # dfused may come from the deferred branch (frame_logits_cat's backward)
         rows, coef, weight, mask = ctx.saved_tensors
         mask = mask if mask.numel() else None
         n, h, w = ctx.dims
